@@ -1,0 +1,167 @@
+/*
+ * instag_hip.h -- C ABI of libinstag_hip.so: the MI355X (gfx950) implementation of the
+ * InsTaG 3D-Gaussian-Splatting render/train hot path.
+ *
+ * Plain pointers and sizes only; every pointer is DEVICE memory unless marked (host).
+ * Every function enqueues work on the given HIP stream (`instag_stream_t` is a
+ * `hipStream_t`) and returns 0 on success or a non-zero code; `instag_last_error()`
+ * returns a human-readable message for the calling thread.  The caller allocates every
+ * output / scratch buffer (the ownership rule of the reference's Python autograd
+ * Functions: gridencoder/grid.py:47-54,77-84, shencoder/sphere_harmonics.py:25-32,50-51).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference checkout).
+ */
+#ifndef INSTAG_HIP_H
+#define INSTAG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* instag_stream_t; /* hipStream_t */
+
+#define INSTAG_OK 0
+#define INSTAG_E_ARG 1     /* invalid argument (shape / unsupported D, C, degree ...) */
+#define INSTAG_E_HIP 2     /* a HIP runtime call or kernel launch failed */
+#define INSTAG_E_SPACE 3   /* caller-provided workspace too small */
+
+const char* instag_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int instag_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Multiresolution grid encoder.
+ * Replaces gridencoder/src/gridencoder.h:12-15 / bindings.cpp:5-7:
+ *   grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype, align_corners, interp)
+ *   grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx, grad_inputs, ...)
+ *   grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H, gridtype, align_corners)
+ * inputs [B,D] fp32 in [0,1]; embeddings [sO,C] fp32; offsets [L+1] int32; outputs [L,B,C];
+ * dy_dx [B, L*D*C] or NULL; grad [L,B,C]; grad_embeddings [sO,C] and grad_inputs [B,D] arrive
+ * zero-filled and are accumulated into.  D in {2,3}, C in {1,2,4,8}.
+ * `workspace` (device, `instag_grid_backward_workspace_bytes` bytes, may be NULL when that is 0)
+ * is scratch for the contention-free table-gradient path.
+ * ------------------------------------------------------------------------------------------ */
+int instag_grid_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets,
+                               float* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                               uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
+                               uint32_t interp, instag_stream_t stream);
+size_t instag_grid_backward_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                            uint32_t total_params);
+int instag_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings,
+                                const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
+                                uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx,
+                                float* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
+                                void* workspace, size_t workspace_bytes, uint32_t total_params,
+                                instag_stream_t stream);
+int instag_grid_total_variation(const float* inputs, const float* embeddings, float* grad,
+                                const int32_t* offsets, float weight, uint32_t B, uint32_t D, uint32_t C,
+                                uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spherical-harmonics encoder.  Replaces shencoder/src/shencoder.h:8-9:
+ *   sh_encode_forward(inputs, outputs, B, D, C, dy_dx)
+ *   sh_encode_backward(grad, inputs, B, D, C, dy_dx, grad_inputs)
+ * inputs [B,3]; outputs [B,C*C]; dy_dx [B,3*C*C] or NULL; C = degree in [1,8]; D must be 3.
+ * grad_inputs [B,3] is accumulated into (arrives zero-filled).
+ * ------------------------------------------------------------------------------------------ */
+int instag_sh_encode_forward(const float* inputs, float* outputs, uint32_t B, uint32_t D, uint32_t C,
+                             float* dy_dx, instag_stream_t stream);
+int instag_sh_encode_backward(const float* grad, const float* inputs, uint32_t B, uint32_t D, uint32_t C,
+                              const float* dy_dx, float* grad_inputs, instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Differentiable tile rasterizer.  Replaces the `_C.rasterize_gaussians` /
+ * `_C.rasterize_gaussians_backward` pair behind `diff_gauss.GaussianRasterizer`
+ * (absent third-party module; call sites gaussian_renderer/__init__.py:58-73,111-121).
+ *
+ * Forward is split in two calls because the number of (tile, Gaussian) instances R is only
+ * known after the per-Gaussian stage: stage1 returns R to the HOST (it synchronises the
+ * stream once), the caller sizes the binning buffer with instag_raster_binning_bytes(R),
+ * stage2 does duplicate -> sort -> tile ranges -> blend.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct instag_raster_args {
+  /* sizes */
+  int32_t N;             /* Gaussians */
+  int32_t M;             /* SH coefficients per Gaussian in `shs` (0 when colors_precomp is used) */
+  int32_t sh_degree;     /* active degree, (sh_degree+1)^2 <= M, 0..3 */
+  int32_t E;             /* extra attribute channels: 0 or 1 */
+  int32_t image_height, image_width;
+  float tanfovx, tanfovy, scale_modifier;
+  int32_t prefiltered, debug;
+  /* camera (device): bg[3], viewmatrix[16], projmatrix[16] (row-vector convention, i.e. the
+     transposed matrices of scene/cameras.py:61-64), campos[3] */
+  const float *bg, *viewmatrix, *projmatrix, *campos;
+  /* per-Gaussian inputs (device). Exactly one of shs / colors_precomp, and exactly one of
+     (scales, rotations) / cov3Ds_precomp, is non-NULL. */
+  const float* means3D;        /* [N,3] */
+  const float* shs;            /* [N,M,3] */
+  const float* colors_precomp; /* [N,3] */
+  const float* opacities;      /* [N,1] */
+  const float* scales;         /* [N,3] */
+  const float* rotations;      /* [N,4] (r,x,y,z), already normalised */
+  const float* cov3Ds_precomp; /* [N,6] xx,xy,xz,yy,yz,zz */
+  const float* extra_attrs;    /* [N,E] or NULL */
+} instag_raster_args;
+
+size_t instag_raster_geom_bytes(int32_t N);
+size_t instag_raster_image_bytes(int32_t image_height, int32_t image_width);
+size_t instag_raster_binning_bytes(int64_t R);
+/* scratch for backward: per-instance gradient rows */
+size_t instag_raster_backward_workspace_bytes(int32_t N, int64_t R);
+
+/* stage 1: preprocess + scan.  radii [N] int32 (output).  *num_rendered (host) receives R. */
+int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t geom_bytes,
+                                 int32_t* radii, int64_t* num_rendered /* (host) */,
+                                 instag_stream_t stream);
+/* stage 2: outputs color [3,H,W], depth [1,H,W], normal [3,H,W], alpha [1,H,W], extra [E,H,W] (NULL if E==0) */
+int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes,
+                                 void* binning, size_t binning_bytes, void* image, size_t image_bytes,
+                                 int64_t R, float* out_color, float* out_depth, float* out_normal,
+                                 float* out_alpha, float* out_extra, instag_stream_t stream);
+/* backward.  dL_dout_* may be NULL (treated as zero).  Gradient outputs may be NULL when not
+ * needed; non-NULL ones are fully written (not accumulated).  dL_dmeans2D is [N,3]
+ * (x,y in NDC units = pixel gradient * 0.5*(W,H); z = 0), the quantity
+ * scene/gaussian_model.py:684 consumes. */
+int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes,
+                           const void* binning, size_t binning_bytes, const void* image,
+                           size_t image_bytes, int64_t R, const int32_t* radii,
+                           const float* dL_dout_color, const float* dL_dout_depth,
+                           const float* dL_dout_normal, const float* dL_dout_alpha,
+                           const float* dL_dout_extra, void* workspace, size_t workspace_bytes,
+                           float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
+                           float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                           float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
+                           instag_stream_t stream);
+
+/* Debug / test access to the integer state (bit-exact parity checks against the oracle).
+ * Copies are enqueued on `stream`; destination pointers are DEVICE memory. */
+int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* binning,
+                               size_t binning_bytes, const void* image, size_t image_bytes,
+                               int32_t N, int64_t R, int32_t image_height, int32_t image_width,
+                               uint32_t* tiles_touched /*[N]*/, uint32_t* point_offsets /*[N]*/,
+                               uint64_t* keys_sorted /*[R]*/, uint32_t* point_list /*[R]*/,
+                               int32_t* ranges /*[tiles,2]*/, uint32_t* n_contrib /*[H*W]*/,
+                               float* final_T /*[H*W]*/, float* rec2d /*[N,16]*/,
+                               instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-kernel timing (bench.py roofline leg).  When enabled, the launcher brackets the named
+ * kernel with hipEvents on the launch stream; instag_prof_read synchronises those events and
+ * returns accumulated milliseconds and launch count since the last reset.
+ * Kernel ids: 0 preprocess, 1 duplicate, 2 sort, 3 ranges, 4 blend_fwd, 5 blend_bwd,
+ *             6 preprocess_bwd, 7 grid_fwd, 8 grid_bwd, 9 sh_fwd, 10 sh_bwd.
+ * ------------------------------------------------------------------------------------------ */
+#define INSTAG_PROF_KERNELS 16
+int instag_prof_enable(int kernel_mask_or_minus1);
+int instag_prof_reset(void);
+int instag_prof_read(int kernel_id, double* total_ms /* (host) */, int64_t* launches /* (host) */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSTAG_HIP_H */

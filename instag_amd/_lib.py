@@ -1,0 +1,103 @@
+"""ctypes binding of libinstag_hip.so (the C ABI declared in include/instag_hip.h).
+
+There is no CPU fallback: if the shared library cannot be loaded (and cannot be built with
+hipcc), importing any operator raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libinstag_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+vp = C.c_void_p
+u32 = C.c_uint32
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+sz = C.c_size_t
+
+
+class RasterArgs(C.Structure):
+    """struct instag_raster_args (include/instag_hip.h)."""
+    _fields_ = [
+        ("N", i32), ("M", i32), ("sh_degree", i32), ("E", i32),
+        ("image_height", i32), ("image_width", i32),
+        ("tanfovx", f32), ("tanfovy", f32), ("scale_modifier", f32),
+        ("prefiltered", i32), ("debug", i32),
+        ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp),
+        ("means3D", vp), ("shs", vp), ("colors_precomp", vp), ("opacities", vp),
+        ("scales", vp), ("rotations", vp), ("cov3Ds_precomp", vp), ("extra_attrs", vp),
+    ]
+
+
+_PROTOS = {
+    "instag_last_error": (C.c_char_p, []),
+    "instag_abi_version": (C.c_int, []),
+    "instag_grid_encode_forward": (C.c_int, [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, C.c_int, u32, vp]),
+    "instag_grid_backward_workspace_bytes": (sz, [u32, u32, u32, u32, u32]),
+    "instag_grid_encode_backward": (C.c_int, [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32,
+                                              C.c_int, u32, vp, sz, u32, vp]),
+    "instag_grid_total_variation": (C.c_int, [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, C.c_int, vp]),
+    "instag_sh_encode_forward": (C.c_int, [vp, vp, u32, u32, u32, vp, vp]),
+    "instag_sh_encode_backward": (C.c_int, [vp, vp, u32, u32, u32, vp, vp, vp]),
+    "instag_raster_geom_bytes": (sz, [i32]),
+    "instag_raster_image_bytes": (sz, [i32, i32]),
+    "instag_raster_binning_bytes": (sz, [i64]),
+    "instag_raster_backward_workspace_bytes": (sz, [i32, i64]),
+    "instag_raster_forward_stage1": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, C.POINTER(i64), vp]),
+    "instag_raster_forward_stage2": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, sz, vp, sz, i64,
+                                               vp, vp, vp, vp, vp, vp]),
+    "instag_raster_backward": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, sz, vp, sz, i64, vp,
+                                         vp, vp, vp, vp, vp, vp, sz,
+                                         vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "instag_raster_debug_export": (C.c_int, [vp, sz, vp, sz, vp, sz, i32, i64, i32, i32,
+                                             vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "instag_prof_enable": (C.c_int, [C.c_int]),
+    "instag_prof_reset": (C.c_int, []),
+    "instag_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            from . import build as _build
+            _build.build(verbose=False)          # raises if hipcc is missing: no silent fallback
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    """Turn a non-zero C-ABI return code into RuntimeError (the reference raises from C++)."""
+    if code != 0:
+        msg = lib().instag_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg}" if what else msg)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

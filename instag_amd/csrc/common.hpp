@@ -1,0 +1,78 @@
+// Shared host/device helpers for libinstag_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#include "instag_hip.h"
+
+namespace instag {
+
+void set_error(const std::string& msg);
+
+#define INSTAG_CHECK_HIP(expr)                                                                  \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess) {                                                                     \
+      ::instag::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+      return INSTAG_E_HIP;                                                                      \
+    }                                                                                           \
+  } while (0)
+
+#define INSTAG_REQUIRE(cond, msg)                                                               \
+  do {                                                                                          \
+    if (!(cond)) {                                                                              \
+      ::instag::set_error(std::string(msg));                                                    \
+      return INSTAG_E_ARG;                                                                      \
+    }                                                                                           \
+  } while (0)
+
+#define INSTAG_CHECK_LAUNCH() INSTAG_CHECK_HIP(hipGetLastError())
+
+// ---- per-kernel event timing (bench.py roofline leg) -----------------------------------------
+enum ProfKernel {
+  K_PREPROCESS = 0, K_DUPLICATE = 1, K_SORT = 2, K_RANGES = 3, K_BLEND_FWD = 4, K_BLEND_BWD = 5,
+  K_PREPROCESS_BWD = 6, K_GRID_FWD = 7, K_GRID_BWD = 8, K_SH_FWD = 9, K_SH_BWD = 10,
+};
+struct ProfScope {
+  ProfScope(int kernel, hipStream_t stream);
+  ~ProfScope();
+  int kernel_;
+  hipStream_t stream_;
+  hipEvent_t start_ = nullptr;
+};
+
+template <typename T>
+static inline T div_up(T a, T b) { return (a + b - 1) / b; }
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- rasterizer buffer layouts (device memory, opaque to the caller) ----------------------------
+constexpr int TILE_X = 16;
+constexpr int TILE_Y = 16;
+constexpr int REC_FLOATS = 16;  // 64-byte per-Gaussian blend record
+
+// rec2d[g][0..15]:
+//  0 x   1 y   2 conA  3 conB  4 conC  5 opacity  6 r  7 g  8 b  9 depth  10 nx  11 ny  12 nz  13 extra
+//  14 (u32) exclusive instance offset   15 (u32) rect_min_x | rect_min_y<<10 | rect_w<<20
+enum RecSlot { R_X = 0, R_Y, R_CA, R_CB, R_CC, R_OP, R_R, R_G, R_B, R_DEPTH, R_NX, R_NY, R_NZ, R_EXTRA,
+               R_OFFSET, R_RECT };
+
+// flags[g]: bit0..2 rgb clamped, bit3..4 normal axis, bit5 normal flipped, bit6 tx clamped, bit7 ty clamped
+struct GeomLayout {
+  size_t rec2d, cov3d, tiles_touched, point_offsets, flags, scan_temp, scan_temp_bytes, total;
+};
+GeomLayout geom_layout(int32_t N);
+
+struct ImageLayout {
+  size_t ranges, n_contrib, final_T, total;
+};
+ImageLayout image_layout(int32_t H, int32_t W);
+
+struct BinningLayout {
+  size_t keys_unsorted, vals_unsorted, keys, vals, sort_temp, sort_temp_bytes, total;
+};
+BinningLayout binning_layout(int64_t R);
+
+}  // namespace instag

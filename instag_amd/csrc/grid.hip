@@ -1,0 +1,458 @@
+// Multiresolution grid ("hashgrid") encoder for gfx950.
+//
+// Replaces gridencoder/src/gridencoder.cu of the reference:
+//   kernel_grid :87-245, kernel_grid_backward :248-340, kernel_input_backward :343-369,
+//   kernel_grad_tv :506-610 (same index function :50-84, same level scale exp2f(l*S)*H-1).
+//
+// MI355X design (not the reference's (B/512, L) launch of per-(point,level) threads):
+//  * one thread owns a point for ALL levels: the input is read once, not L times;
+//  * consecutive levels whose tables fit the LDS budget are staged into LDS once per workgroup
+//    (InsTaG's face planes are 9,464 floats = 37.9 KB for all 12 levels, the mouth planes
+//    17 KB per level) and the 2^D corner gathers become LDS reads; levels too large for LDS
+//    fall back to global gathers;
+//  * backward accumulates the table gradient in an LDS-private copy with LDS float atomics and
+//    flushes each non-zero cell with ONE global atomic per workgroup, instead of one contended
+//    global atomic per (point, corner) -- 100k points x 4 corners into <=1600 cells otherwise;
+//  * the input gradient (kernel_input_backward) is fused into the same pass.
+#include "common.hpp"
+
+namespace instag {
+namespace {
+
+constexpr int GRID_BLOCK = 256;
+constexpr uint32_t LDS_BUDGET_FLOATS = 16384;  // 64 KB -> 2 workgroups per CU
+
+template <uint32_t D>
+__device__ __forceinline__ uint32_t fast_hash(const uint32_t pos_grid[D]) {
+  constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+  uint32_t result = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < D; ++i) result ^= pos_grid[i] * primes[i];
+  return result;
+}
+
+// index of a grid vertex inside its level, in units of vertices (caller multiplies by C)
+template <uint32_t D>
+__device__ __forceinline__ uint32_t grid_index(uint32_t gridtype, bool align_corners, uint32_t hashmap_size,
+                                               uint32_t resolution, const uint32_t pos_grid[D]) {
+  uint32_t stride = 1, index = 0;
+#pragma unroll
+  for (uint32_t d = 0; d < D; ++d) {
+    if (stride <= hashmap_size) {
+      index += pos_grid[d] * stride;
+      stride *= align_corners ? resolution : (resolution + 1);
+    }
+  }
+  if (gridtype == 0 && stride > hashmap_size) index = fast_hash<D>(pos_grid);
+  return index % hashmap_size;
+}
+
+struct LevelGeom {
+  float scale;
+  uint32_t resolution, hashmap_size;
+};
+__device__ __forceinline__ LevelGeom level_geom(const int32_t* __restrict__ offsets, uint32_t level, float S, uint32_t H) {
+  LevelGeom g;
+  g.hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+  g.scale = exp2f(level * S) * H - 1.0f;
+  g.resolution = (uint32_t)ceilf(g.scale) + 1;
+  return g;
+}
+
+template <uint32_t D>
+__device__ __forceinline__ bool load_point(const float* __restrict__ inputs, uint32_t b, float x[D]) {
+  bool oob = false;
+#pragma unroll
+  for (uint32_t d = 0; d < D; ++d) {
+    x[d] = inputs[b * D + d];
+    if (x[d] < 0.f || x[d] > 1.f) oob = true;
+  }
+  return oob;
+}
+
+template <uint32_t D>
+__device__ __forceinline__ void locate(const float x[D], float scale, bool align_corners, uint32_t interp,
+                                       float pos[D], float pos_deriv[D], uint32_t pos_grid[D]) {
+#pragma unroll
+  for (uint32_t d = 0; d < D; ++d) {
+    pos[d] = x[d] * scale + (align_corners ? 0.0f : 0.5f);
+    const float fl = floorf(pos[d]);
+    pos_grid[d] = (uint32_t)fl;
+    pos[d] -= fl;
+    if (interp == 1) {
+      pos_deriv[d] = 6.f * pos[d] * (1.0f - pos[d]);
+      pos[d] = pos[d] * pos[d] * (3.0f - 2.0f * pos[d]);
+    } else {
+      pos_deriv[d] = 1.0f;
+    }
+  }
+}
+
+// One level of one point.  `tab` points at the level's table (LDS or global).
+template <uint32_t D, uint32_t C, typename TabPtr>
+__device__ __forceinline__ void encode_level(TabPtr tab, const LevelGeom& lg, const float x[D], bool oob,
+                                             uint32_t gridtype, bool align_corners, uint32_t interp,
+                                             float* __restrict__ out, float* __restrict__ dy_dx_row) {
+  if (oob) {
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ++ch) out[ch] = 0.f;
+    if (dy_dx_row) {
+#pragma unroll
+      for (uint32_t i = 0; i < D * C; ++i) dy_dx_row[i] = 0.f;
+    }
+    return;
+  }
+  float pos[D], pos_deriv[D];
+  uint32_t pos_grid[D];
+  locate<D>(x, lg.scale, align_corners, interp, pos, pos_deriv, pos_grid);
+  float results[C];
+#pragma unroll
+  for (uint32_t ch = 0; ch < C; ++ch) results[ch] = 0.f;
+#pragma unroll
+  for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+    float w = 1.f;
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+      if ((idx & (1u << d)) == 0) { w *= 1.f - pos[d]; pg[d] = pos_grid[d]; }
+      else { w *= pos[d]; pg[d] = pos_grid[d] + 1; }
+    }
+    const uint32_t index = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pg) * C;
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ++ch) results[ch] += w * tab[index + ch];
+  }
+#pragma unroll
+  for (uint32_t ch = 0; ch < C; ++ch) out[ch] = results[ch];
+  if (dy_dx_row) {
+#pragma unroll
+    for (uint32_t gd = 0; gd < D; ++gd) {
+      float rg[C];
+#pragma unroll
+      for (uint32_t ch = 0; ch < C; ++ch) rg[ch] = 0.f;
+#pragma unroll
+      for (uint32_t idx = 0; idx < (1u << (D - 1)); ++idx) {
+        float w = lg.scale;
+        uint32_t pg[D];
+#pragma unroll
+        for (uint32_t nd = 0; nd < D - 1; ++nd) {
+          const uint32_t d = (nd >= gd) ? (nd + 1) : nd;
+          if ((idx & (1u << nd)) == 0) { w *= 1.f - pos[d]; pg[d] = pos_grid[d]; }
+          else { w *= pos[d]; pg[d] = pos_grid[d] + 1; }
+        }
+        pg[gd] = pos_grid[gd];
+        const uint32_t il = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pg) * C;
+        pg[gd] = pos_grid[gd] + 1;
+        const uint32_t ir = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pg) * C;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) rg[ch] += w * (tab[ir + ch] - tab[il + ch]) * pos_deriv[gd];
+      }
+#pragma unroll
+      for (uint32_t ch = 0; ch < C; ++ch) dy_dx_row[gd * C + ch] = rg[ch];
+    }
+  }
+}
+
+// Group consecutive levels [level, lend) whose tables fit the LDS budget (0 levels -> global path).
+__device__ __forceinline__ uint32_t group_end(const int32_t* __restrict__ offsets, uint32_t level, uint32_t L, uint32_t C) {
+  const uint32_t base = (uint32_t)offsets[level];
+  uint32_t lend = level;
+  while (lend < L && ((uint32_t)offsets[lend + 1] - base) * C <= LDS_BUDGET_FLOATS) ++lend;
+  return lend;
+}
+
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(GRID_BLOCK)
+grid_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ grid,
+                    const int32_t* __restrict__ offsets, float* __restrict__ outputs, uint32_t B, uint32_t L,
+                    float S, uint32_t H, float* __restrict__ dy_dx, uint32_t gridtype, bool align_corners,
+                    uint32_t interp) {
+  extern __shared__ __align__(16) float s_tab[];
+  const uint32_t per_block = (B + gridDim.x - 1) / gridDim.x;
+  const uint32_t b0 = blockIdx.x * per_block;
+  const uint32_t b1 = min(B, b0 + per_block);
+  uint32_t level = 0;
+  while (level < L) {
+    const uint32_t lend = group_end(offsets, level, L, C);
+    if (lend == level) {  // table larger than LDS: gather from global memory
+      const LevelGeom lg = level_geom(offsets, level, S, H);
+      const float* tab = grid + (size_t)(uint32_t)offsets[level] * C;
+      for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
+        float x[D];
+        const bool oob = load_point<D>(inputs, b, x);
+        float out[C], row[D * C];
+        encode_level<D, C>(tab, lg, x, oob, gridtype, align_corners, interp, out, dy_dx ? row : nullptr);
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) outputs[(size_t)level * B * C + (size_t)b * C + ch] = out[ch];
+        if (dy_dx) {
+#pragma unroll
+          for (uint32_t i = 0; i < D * C; ++i) dy_dx[(size_t)b * L * D * C + level * D * C + i] = row[i];
+        }
+      }
+      ++level;
+      continue;
+    }
+    const uint32_t base = (uint32_t)offsets[level];
+    const uint32_t n = ((uint32_t)offsets[lend] - base) * C;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += GRID_BLOCK) s_tab[i] = grid[(size_t)base * C + i];
+    __syncthreads();
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
+      float x[D];
+      const bool oob = load_point<D>(inputs, b, x);
+      for (uint32_t l = level; l < lend; ++l) {
+        const LevelGeom lg = level_geom(offsets, l, S, H);
+        const float* tab = s_tab + ((uint32_t)offsets[l] - base) * C;
+        float out[C], row[D * C];
+        encode_level<D, C>(tab, lg, x, oob, gridtype, align_corners, interp, out, dy_dx ? row : nullptr);
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) outputs[(size_t)l * B * C + (size_t)b * C + ch] = out[ch];
+        if (dy_dx) {
+#pragma unroll
+          for (uint32_t i = 0; i < D * C; ++i) dy_dx[(size_t)b * L * D * C + l * D * C + i] = row[i];
+        }
+      }
+    }
+    level = lend;
+  }
+}
+
+template <uint32_t D, uint32_t C, bool LDS>
+__device__ __forceinline__ void scatter_level(float* acc, const LevelGeom& lg, const float x[D],
+                                              uint32_t gridtype, bool align_corners, uint32_t interp,
+                                              const float g[C]) {
+  float pos[D], pos_deriv[D];
+  uint32_t pos_grid[D];
+  locate<D>(x, lg.scale, align_corners, interp, pos, pos_deriv, pos_grid);
+#pragma unroll
+  for (uint32_t idx = 0; idx < (1u << D); ++idx) {
+    float w = 1.f;
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; ++d) {
+      if ((idx & (1u << d)) == 0) { w *= 1.f - pos[d]; pg[d] = pos_grid[d]; }
+      else { w *= pos[d]; pg[d] = pos_grid[d] + 1; }
+    }
+    const uint32_t index = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pg) * C;
+#pragma unroll
+    for (uint32_t ch = 0; ch < C; ++ch) {
+      const float v = w * g[ch];
+      if (LDS) __hip_atomic_fetch_add(&acc[index + ch], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else atomicAdd(&acc[index + ch], v);
+    }
+  }
+}
+
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(GRID_BLOCK)
+grid_backward_kernel(const float* __restrict__ grad, const float* __restrict__ inputs,
+                     const int32_t* __restrict__ offsets, float* __restrict__ grad_grid, uint32_t B, uint32_t L,
+                     float S, uint32_t H, const float* __restrict__ dy_dx, float* __restrict__ grad_inputs,
+                     uint32_t gridtype, bool align_corners, uint32_t interp) {
+  extern __shared__ __align__(16) float s_acc[];
+  const uint32_t per_block = (B + gridDim.x - 1) / gridDim.x;
+  const uint32_t b0 = blockIdx.x * per_block;
+  const uint32_t b1 = min(B, b0 + per_block);
+
+  // fused kernel_input_backward: grad_inputs[b,d] += sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]
+  if (dy_dx && grad_inputs) {
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
+      float r[D];
+#pragma unroll
+      for (uint32_t d = 0; d < D; ++d) r[d] = 0.f;
+      for (uint32_t l = 0; l < L; ++l) {
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) {
+          const float gv = grad[(size_t)l * B * C + (size_t)b * C + ch];
+#pragma unroll
+          for (uint32_t d = 0; d < D; ++d) r[d] += gv * dy_dx[(size_t)b * L * D * C + l * D * C + d * C + ch];
+        }
+      }
+#pragma unroll
+      for (uint32_t d = 0; d < D; ++d) grad_inputs[(size_t)b * D + d] += r[d];
+    }
+  }
+
+  uint32_t level = 0;
+  while (level < L) {
+    const uint32_t lend = group_end(offsets, level, L, C);
+    if (lend == level) {
+      const LevelGeom lg = level_geom(offsets, level, S, H);
+      float* acc = grad_grid + (size_t)(uint32_t)offsets[level] * C;
+      for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
+        float x[D];
+        if (load_point<D>(inputs, b, x)) continue;
+        float g[C];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) g[ch] = grad[(size_t)level * B * C + (size_t)b * C + ch];
+        scatter_level<D, C, false>(acc, lg, x, gridtype, align_corners, interp, g);
+      }
+      ++level;
+      continue;
+    }
+    const uint32_t base = (uint32_t)offsets[level];
+    const uint32_t n = ((uint32_t)offsets[lend] - base) * C;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += GRID_BLOCK) s_acc[i] = 0.f;
+    __syncthreads();
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
+      float x[D];
+      if (load_point<D>(inputs, b, x)) continue;
+      for (uint32_t l = level; l < lend; ++l) {
+        const LevelGeom lg = level_geom(offsets, l, S, H);
+        float g[C];
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) g[ch] = grad[(size_t)l * B * C + (size_t)b * C + ch];
+        scatter_level<D, C, true>(s_acc + ((uint32_t)offsets[l] - base) * C, lg, x, gridtype, align_corners, interp, g);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += GRID_BLOCK) {
+      const float v = s_acc[i];
+      if (v != 0.f) atomicAdd(&grad_grid[(size_t)base * C + i], v);
+    }
+    level = lend;
+  }
+}
+
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(GRID_BLOCK)
+grid_tv_kernel(const float* __restrict__ inputs, const float* __restrict__ grid, float* __restrict__ grad,
+               const int32_t* __restrict__ offsets, float weight, uint32_t B, uint32_t L, float S, uint32_t H,
+               uint32_t gridtype, bool align_corners) {
+  const uint32_t b = blockIdx.x * GRID_BLOCK + threadIdx.x;
+  if (b >= B) return;
+  const uint32_t level = blockIdx.y;
+  float x[D];
+  if (load_point<D>(inputs, b, x)) return;
+  const LevelGeom lg = level_geom(offsets, level, S, H);
+  const float* tab = grid + (size_t)(uint32_t)offsets[level] * C;
+  float* gt = grad + (size_t)(uint32_t)offsets[level] * C;
+  uint32_t pos_grid[D];
+#pragma unroll
+  for (uint32_t d = 0; d < D; ++d) pos_grid[d] = (uint32_t)floorf(x[d] * lg.scale + (align_corners ? 0.0f : 0.5f));
+  float results[C], idelta[C];
+#pragma unroll
+  for (uint32_t ch = 0; ch < C; ++ch) { results[ch] = 0.f; idelta[ch] = 0.f; }
+  const uint32_t index = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pos_grid) * C;
+  const float w = weight / (2 * D);
+#pragma unroll
+  for (uint32_t d = 0; d < D; ++d) {
+    const uint32_t cur = pos_grid[d];
+    if (cur < lg.resolution) {
+      pos_grid[d] = cur + 1;
+      const uint32_t ir = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pos_grid) * C;
+#pragma unroll
+      for (uint32_t ch = 0; ch < C; ++ch) {
+        const float gv = tab[index + ch] - tab[ir + ch];
+        results[ch] += gv; idelta[ch] += gv * gv;
+      }
+    }
+    if (cur > 0) {
+      pos_grid[d] = cur - 1;
+      const uint32_t il = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pos_grid) * C;
+#pragma unroll
+      for (uint32_t ch = 0; ch < C; ++ch) {
+        const float gv = tab[index + ch] - tab[il + ch];
+        results[ch] += gv; idelta[ch] += gv * gv;
+      }
+    }
+    pos_grid[d] = cur;
+  }
+#pragma unroll
+  for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&gt[index + ch], w * results[ch] * rsqrtf(idelta[ch] + 1e-9f));
+}
+
+inline unsigned fwd_blocks(uint32_t B) { return (unsigned)std::min<uint32_t>(div_up<uint32_t>(B, GRID_BLOCK), 2048u); }
+inline unsigned bwd_blocks(uint32_t B) { return (unsigned)std::min<uint32_t>(div_up<uint32_t>(B, GRID_BLOCK), 512u); }
+
+template <uint32_t D, uint32_t C>
+int run_forward(const float* inputs, const float* emb, const int32_t* offsets, float* outputs, uint32_t B,
+                uint32_t L, float S, uint32_t H, float* dy_dx, uint32_t gridtype, bool align, uint32_t interp,
+                hipStream_t s) {
+  ProfScope p(K_GRID_FWD, s);
+  grid_forward_kernel<D, C><<<fwd_blocks(B), GRID_BLOCK, LDS_BUDGET_FLOATS * sizeof(float), s>>>(
+      inputs, emb, offsets, outputs, B, L, S, H, dy_dx, gridtype, align, interp);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+template <uint32_t D, uint32_t C>
+int run_backward(const float* grad, const float* inputs, const int32_t* offsets, float* grad_emb, uint32_t B,
+                 uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs, uint32_t gridtype,
+                 bool align, uint32_t interp, hipStream_t s) {
+  ProfScope p(K_GRID_BWD, s);
+  grid_backward_kernel<D, C><<<bwd_blocks(B), GRID_BLOCK, LDS_BUDGET_FLOATS * sizeof(float), s>>>(
+      grad, inputs, offsets, grad_emb, B, L, S, H, dy_dx, grad_inputs, gridtype, align, interp);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+template <uint32_t D, uint32_t C>
+int run_tv(const float* inputs, const float* emb, float* grad, const int32_t* offsets, float weight, uint32_t B,
+           uint32_t L, float S, uint32_t H, uint32_t gridtype, bool align, hipStream_t s) {
+  dim3 g(div_up<uint32_t>(B, GRID_BLOCK), L, 1);
+  grid_tv_kernel<D, C><<<g, GRID_BLOCK, 0, s>>>(inputs, emb, grad, offsets, weight, B, L, S, H, gridtype, align);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+#define DISPATCH_DC(D, C, FN, ...)                                                            \
+  switch (D) {                                                                                \
+    case 2: switch (C) { case 1: return FN<2, 1>(__VA_ARGS__); case 2: return FN<2, 2>(__VA_ARGS__); \
+                         case 4: return FN<2, 4>(__VA_ARGS__); case 8: return FN<2, 8>(__VA_ARGS__); } break; \
+    case 3: switch (C) { case 1: return FN<3, 1>(__VA_ARGS__); case 2: return FN<3, 2>(__VA_ARGS__); \
+                         case 4: return FN<3, 4>(__VA_ARGS__); case 8: return FN<3, 8>(__VA_ARGS__); } break; \
+    case 4: switch (C) { case 1: return FN<4, 1>(__VA_ARGS__); case 2: return FN<4, 2>(__VA_ARGS__); \
+                         case 4: return FN<4, 4>(__VA_ARGS__); case 8: return FN<4, 8>(__VA_ARGS__); } break; \
+    case 5: switch (C) { case 1: return FN<5, 1>(__VA_ARGS__); case 2: return FN<5, 2>(__VA_ARGS__); \
+                         case 4: return FN<5, 4>(__VA_ARGS__); case 8: return FN<5, 8>(__VA_ARGS__); } break; \
+  }
+
+}  // namespace
+}  // namespace instag
+
+using namespace instag;
+
+extern "C" {
+
+int instag_grid_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets, float* outputs,
+                               uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, float* dy_dx,
+                               uint32_t gridtype, int align_corners, uint32_t interp, instag_stream_t stream) {
+  INSTAG_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: NULL tensor");
+  INSTAG_REQUIRE(L >= 1 && L <= 64, "GridEncoding: L must be in [1,64]");
+  if (B == 0) return INSTAG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DC(D, C, run_forward, inputs, embeddings, offsets, outputs, B, L, S, H, dy_dx, gridtype,
+              align_corners != 0, interp, s);
+  set_error("GridEncoding: D must be 2..5 and C must be 1, 2, 4, or 8.");
+  return INSTAG_E_ARG;
+}
+
+size_t instag_grid_backward_workspace_bytes(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { return 0; }
+
+int instag_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings,
+                                const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
+                                uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs,
+                                uint32_t gridtype, int align_corners, uint32_t interp, void* workspace,
+                                size_t workspace_bytes, uint32_t total_params, instag_stream_t stream) {
+  (void)embeddings; (void)workspace; (void)workspace_bytes; (void)total_params;
+  INSTAG_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: NULL tensor");
+  INSTAG_REQUIRE(L >= 1 && L <= 64, "GridEncoding: L must be in [1,64]");
+  if (B == 0) return INSTAG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DC(D, C, run_backward, grad, inputs, offsets, grad_embeddings, B, L, S, H, dy_dx, grad_inputs,
+              gridtype, align_corners != 0, interp, s);
+  set_error("GridEncoding: D must be 2..5 and C must be 1, 2, 4, or 8.");
+  return INSTAG_E_ARG;
+}
+
+int instag_grid_total_variation(const float* inputs, const float* embeddings, float* grad, const int32_t* offsets,
+                                float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                uint32_t gridtype, int align_corners, instag_stream_t stream) {
+  INSTAG_REQUIRE(inputs && embeddings && grad && offsets, "grad_total_variation: NULL tensor");
+  if (B == 0) return INSTAG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_DC(D, C, run_tv, inputs, embeddings, grad, offsets, weight, B, L, S, H, gridtype, align_corners != 0, s);
+  set_error("GridEncoding: D must be 2..5 and C must be 1, 2, 4, or 8.");
+  return INSTAG_E_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,306 @@
+// C-ABI entry points of the rasterizer (see include/instag_hip.h) + buffer layouts, scan and sort.
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include <mutex>
+#include <vector>
+
+#include "raster_internal.hpp"
+
+namespace instag {
+
+// ---- thread-local error string ------------------------------------------------------------------
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+// ---- per-kernel event timing ------------------------------------------------------------------------
+namespace {
+struct ProfState {
+  std::mutex mu;
+  int mask = 0;
+  struct Pair { hipEvent_t a, b; };
+  std::vector<Pair> pending[INSTAG_PROF_KERNELS];
+  double total_ms[INSTAG_PROF_KERNELS] = {0};
+  int64_t launches[INSTAG_PROF_KERNELS] = {0};
+};
+ProfState& prof() { static ProfState p; return p; }
+}  // namespace
+
+ProfScope::ProfScope(int kernel, hipStream_t stream) : kernel_(kernel), stream_(stream) {
+  ProfState& p = prof();
+  if (!(p.mask & (1 << kernel))) return;
+  if (hipEventCreate(&start_) != hipSuccess) { start_ = nullptr; return; }
+  (void)hipEventRecord(start_, stream_);
+}
+ProfScope::~ProfScope() {
+  if (!start_) return;
+  hipEvent_t stop;
+  if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start_); return; }
+  (void)hipEventRecord(stop, stream_);
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  p.pending[kernel_].push_back({start_, stop});
+}
+
+// ---- layouts ----------------------------------------------------------------------------------------
+GeomLayout geom_layout(int32_t N) {
+  GeomLayout L;
+  const size_t n = (size_t)(N > 0 ? N : 1);
+  size_t o = 0;
+  L.rec2d = o; o = align_up(o + n * REC_FLOATS * sizeof(float), 256);
+  L.cov3d = o; o = align_up(o + n * 6 * sizeof(float), 256);
+  L.tiles_touched = o; o = align_up(o + n * sizeof(uint32_t), 256);
+  L.point_offsets = o; o = align_up(o + n * sizeof(uint32_t), 256);
+  L.flags = o; o = align_up(o + n * sizeof(uint32_t), 256);
+  size_t tmp = 0;
+  (void)rocprim::inclusive_scan(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, n, rocprim::plus<uint32_t>());
+  L.scan_temp = o; L.scan_temp_bytes = tmp; o = align_up(o + tmp, 256);
+  L.total = o;
+  return L;
+}
+
+ImageLayout image_layout(int32_t H, int32_t W) {
+  ImageLayout L;
+  const size_t tiles = (size_t)div_up(W, TILE_X) * div_up(H, TILE_Y);
+  const size_t P = (size_t)H * W;
+  size_t o = 0;
+  L.ranges = o; o = align_up(o + tiles * 2 * sizeof(int32_t), 256);
+  L.n_contrib = o; o = align_up(o + P * sizeof(uint32_t), 256);
+  L.final_T = o; o = align_up(o + P * sizeof(float), 256);
+  L.total = o;
+  return L;
+}
+
+BinningLayout binning_layout(int64_t R) {
+  BinningLayout L;
+  const size_t r = (size_t)(R > 0 ? R : 1);
+  size_t o = 0;
+  L.keys_unsorted = o; o = align_up(o + r * sizeof(uint64_t), 256);
+  L.vals_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
+  L.keys = o; o = align_up(o + r * sizeof(uint64_t), 256);
+  L.vals = o; o = align_up(o + r * sizeof(uint32_t), 256);
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, r, 0, 64);
+  L.sort_temp = o; L.sort_temp_bytes = tmp; o = align_up(o + tmp, 256);
+  L.total = o;
+  return L;
+}
+
+static int validate(const instag_raster_args* a) {
+  INSTAG_REQUIRE(a != nullptr, "raster args is NULL");
+  INSTAG_REQUIRE(a->N >= 0, "N must be >= 0");
+  INSTAG_REQUIRE(a->image_height > 0 && a->image_width > 0, "image size must be positive");
+  INSTAG_REQUIRE(a->image_height <= 16368 && a->image_width <= 16368, "image larger than 16368 px not supported");
+  INSTAG_REQUIRE((a->shs != nullptr) != (a->colors_precomp != nullptr),
+                 "Please provide excatly one of either SHs or precomputed colors!");
+  INSTAG_REQUIRE(((a->scales != nullptr && a->rotations != nullptr) && a->cov3Ds_precomp == nullptr) ||
+                     ((a->scales == nullptr && a->rotations == nullptr) && a->cov3Ds_precomp != nullptr),
+                 "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+  INSTAG_REQUIRE(a->E == 0 || a->E == 1, "extra_attrs: only 0 or 1 channel is supported");
+  INSTAG_REQUIRE(a->sh_degree >= 0 && a->sh_degree <= 3, "sh_degree must be in [0,3]");
+  if (a->shs) INSTAG_REQUIRE((a->sh_degree + 1) * (a->sh_degree + 1) <= a->M, "shs has fewer coefficients than sh_degree needs");
+  INSTAG_REQUIRE(a->bg && a->viewmatrix && a->projmatrix && a->campos, "camera pointers must not be NULL");
+  INSTAG_REQUIRE(a->N == 0 || (a->means3D && a->opacities), "means3D / opacities must not be NULL");
+  return INSTAG_OK;
+}
+
+}  // namespace instag
+
+using namespace instag;
+
+extern "C" {
+
+const char* instag_last_error(void) { return g_err.c_str(); }
+int instag_abi_version(void) { return 1; }
+
+size_t instag_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
+size_t instag_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
+size_t instag_raster_binning_bytes(int64_t R) { return binning_layout(R).total; }
+size_t instag_raster_backward_workspace_bytes(int32_t N, int64_t R) {
+  (void)N;
+  return align_up((size_t)(R > 0 ? R : 1) * REC_FLOATS * sizeof(float), 256);
+}
+
+int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t geom_bytes, int32_t* radii,
+                                 int64_t* num_rendered, instag_stream_t stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (int e = validate(a)) return e;
+  INSTAG_REQUIRE(num_rendered != nullptr, "num_rendered is NULL");
+  const GeomLayout L = geom_layout(a->N);
+  if (geom_bytes < L.total) { set_error("geom buffer too small"); return INSTAG_E_SPACE; }
+  *num_rendered = 0;
+  if (a->N == 0) return INSTAG_OK;
+  char* gb = (char*)geom;
+  const Camera c = make_camera(a);
+  uint32_t* tiles_touched = (uint32_t*)(gb + L.tiles_touched);
+  uint32_t* point_offsets = (uint32_t*)(gb + L.point_offsets);
+  if (int e = launch_preprocess(c, a, (float*)(gb + L.rec2d), (float*)(gb + L.cov3d), tiles_touched,
+                                (uint32_t*)(gb + L.flags), radii, s)) return e;
+  size_t tmp = L.scan_temp_bytes;
+  INSTAG_CHECK_HIP(rocprim::inclusive_scan(gb + L.scan_temp, tmp, tiles_touched, point_offsets, (size_t)a->N,
+                                           rocprim::plus<uint32_t>(), s));
+  uint32_t r32 = 0;
+  INSTAG_CHECK_HIP(hipMemcpyAsync(&r32, point_offsets + (a->N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  INSTAG_CHECK_HIP(hipStreamSynchronize(s));
+  *num_rendered = (int64_t)r32;
+  return INSTAG_OK;
+}
+
+int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
+                                 size_t binning_bytes, void* image, size_t image_bytes, int64_t R,
+                                 float* out_color, float* out_depth, float* out_normal, float* out_alpha,
+                                 float* out_extra, instag_stream_t stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (int e = validate(a)) return e;
+  INSTAG_REQUIRE(out_color && out_depth && out_normal && out_alpha, "output images must not be NULL");
+  INSTAG_REQUIRE(R >= 0 && R < (int64_t)1 << 31, "instance count out of range");
+  const GeomLayout GL = geom_layout(a->N);
+  const ImageLayout IL = image_layout(a->image_height, a->image_width);
+  const BinningLayout BL = binning_layout(R);
+  if (geom_bytes < GL.total) { set_error("geom buffer too small"); return INSTAG_E_SPACE; }
+  if (image_bytes < IL.total) { set_error("image buffer too small"); return INSTAG_E_SPACE; }
+  if (binning_bytes < BL.total) { set_error("binning buffer too small"); return INSTAG_E_SPACE; }
+  char *gb = (char*)geom, *bb = (char*)binning, *ib = (char*)image;
+  const Camera c = make_camera(a);
+  const int tiles = c.grid_x * c.grid_y;
+  int32_t* ranges = (int32_t*)(ib + IL.ranges);
+  INSTAG_CHECK_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(int32_t), s));
+  uint64_t* keys_u = (uint64_t*)(bb + BL.keys_unsorted);
+  uint32_t* vals_u = (uint32_t*)(bb + BL.vals_unsorted);
+  uint64_t* keys = (uint64_t*)(bb + BL.keys);
+  uint32_t* vals = (uint32_t*)(bb + BL.vals);
+  if (R > 0) {
+    if (int e = launch_duplicate(c, (float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched),
+                                 (const uint32_t*)(gb + GL.point_offsets), keys_u, vals_u, s)) return e;
+    int tile_bits = 0;
+    while ((1 << tile_bits) < tiles) ++tile_bits;
+    {
+      ProfScope p(K_SORT, s);
+      size_t tmp = BL.sort_temp_bytes;
+      INSTAG_CHECK_HIP(rocprim::radix_sort_pairs(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0,
+                                                 32 + tile_bits, s));
+    }
+    if (int e = launch_ranges(R, keys, ranges, s)) return e;
+  }
+  return launch_blend_forward(c, ranges, vals, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
+                              (float*)(ib + IL.final_T), out_color, out_depth, out_normal, out_alpha,
+                              a->E > 0 ? out_extra : nullptr, s);
+}
+
+int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes, const void* binning,
+                           size_t binning_bytes, const void* image, size_t image_bytes, int64_t R,
+                           const int32_t* radii, const float* dL_dout_color, const float* dL_dout_depth,
+                           const float* dL_dout_normal, const float* dL_dout_alpha, const float* dL_dout_extra,
+                           void* workspace, size_t workspace_bytes, float* dL_dmeans3D, float* dL_dmeans2D,
+                           float* dL_dshs, float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
+                           float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
+                           instag_stream_t stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (int e = validate(a)) return e;
+  INSTAG_REQUIRE(radii != nullptr || a->N == 0, "radii is NULL");
+  const GeomLayout GL = geom_layout(a->N);
+  const ImageLayout IL = image_layout(a->image_height, a->image_width);
+  const BinningLayout BL = binning_layout(R);
+  if (geom_bytes < GL.total || image_bytes < IL.total || binning_bytes < BL.total) {
+    set_error("state buffer too small"); return INSTAG_E_SPACE;
+  }
+  const size_t need = instag_raster_backward_workspace_bytes(a->N, R);
+  if (workspace_bytes < need || workspace == nullptr) { set_error("backward workspace too small"); return INSTAG_E_SPACE; }
+  if (a->N == 0) return INSTAG_OK;
+  const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)image;
+  const Camera c = make_camera(a);
+  float* inst_grad = (float*)workspace;
+  INSTAG_CHECK_HIP(hipMemsetAsync(inst_grad, 0, need, s));
+  if (R > 0) {
+    if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.vals),
+                                      (const float*)(gb + GL.rec2d), (const uint32_t*)(ib + IL.n_contrib),
+                                      (const float*)(ib + IL.final_T), dL_dout_color, dL_dout_depth,
+                                      dL_dout_normal, dL_dout_alpha, a->E > 0 ? dL_dout_extra : nullptr,
+                                      inst_grad, s)) return e;
+  }
+  return launch_preprocess_backward(c, a, (const float*)(gb + GL.rec2d), (const float*)(gb + GL.cov3d),
+                                    (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
+                                    radii, inst_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp,
+                                    dL_dopacities, dL_dscales, dL_drotations, dL_dcov3Ds_precomp,
+                                    a->E > 0 ? dL_dextra_attrs : nullptr, s);
+}
+
+int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+                               const void* image, size_t image_bytes, int32_t N, int64_t R, int32_t H, int32_t W,
+                               uint32_t* tiles_touched, uint32_t* point_offsets, uint64_t* keys_sorted,
+                               uint32_t* point_list, int32_t* ranges, uint32_t* n_contrib, float* final_T,
+                               float* rec2d, instag_stream_t stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  const GeomLayout GL = geom_layout(N);
+  const ImageLayout IL = image_layout(H, W);
+  const BinningLayout BL = binning_layout(R);
+  const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)image;
+  const size_t tiles = (size_t)div_up(W, TILE_X) * div_up(H, TILE_Y), P = (size_t)H * W;
+  auto cp = [&](void* dst, const void* src, size_t n) -> hipError_t {
+    if (!dst || n == 0) return hipSuccess;
+    return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, s);
+  };
+  if (geom) {
+    if (geom_bytes < GL.total) { set_error("geom buffer too small"); return INSTAG_E_SPACE; }
+    INSTAG_CHECK_HIP(cp(tiles_touched, gb + GL.tiles_touched, (size_t)N * 4));
+    INSTAG_CHECK_HIP(cp(point_offsets, gb + GL.point_offsets, (size_t)N * 4));
+    INSTAG_CHECK_HIP(cp(rec2d, gb + GL.rec2d, (size_t)N * REC_FLOATS * 4));
+  }
+  if (binning && R > 0) {
+    if (binning_bytes < BL.total) { set_error("binning buffer too small"); return INSTAG_E_SPACE; }
+    INSTAG_CHECK_HIP(cp(keys_sorted, bb + BL.keys, (size_t)R * 8));
+    INSTAG_CHECK_HIP(cp(point_list, bb + BL.vals, (size_t)R * 4));
+  }
+  if (image) {
+    if (image_bytes < IL.total) { set_error("image buffer too small"); return INSTAG_E_SPACE; }
+    INSTAG_CHECK_HIP(cp(ranges, ib + IL.ranges, tiles * 8));
+    INSTAG_CHECK_HIP(cp(n_contrib, ib + IL.n_contrib, P * 4));
+    INSTAG_CHECK_HIP(cp(final_T, ib + IL.final_T, P * 4));
+  }
+  return INSTAG_OK;
+}
+
+int instag_prof_enable(int mask) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  p.mask = mask;
+  return INSTAG_OK;
+}
+
+static void prof_drain(ProfState& p, int k) {
+  for (auto& pr : p.pending[k]) {
+    float ms = 0.f;
+    if (hipEventSynchronize(pr.b) == hipSuccess && hipEventElapsedTime(&ms, pr.a, pr.b) == hipSuccess) {
+      p.total_ms[k] += ms;
+      p.launches[k] += 1;
+    }
+    (void)hipEventDestroy(pr.a);
+    (void)hipEventDestroy(pr.b);
+  }
+  p.pending[k].clear();
+}
+
+int instag_prof_reset(void) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  for (int k = 0; k < INSTAG_PROF_KERNELS; ++k) {
+    prof_drain(p, k);
+    p.total_ms[k] = 0;
+    p.launches[k] = 0;
+  }
+  return INSTAG_OK;
+}
+
+int instag_prof_read(int k, double* total_ms, int64_t* launches) {
+  INSTAG_REQUIRE(k >= 0 && k < INSTAG_PROF_KERNELS, "kernel id out of range");
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  prof_drain(p, k);
+  if (total_ms) *total_ms = p.total_ms[k];
+  if (launches) *launches = p.launches[k];
+  return INSTAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Internal launcher declarations shared by the rasterizer translation units.
+#pragma once
+#include "common.hpp"
+
+namespace instag {
+
+struct Camera {  // kernel-side view of instag_raster_args' scalar part
+  int32_t N, M, sh_degree, E, H, W;
+  float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
+  int32_t grid_x, grid_y;
+  const float *bg, *view, *proj, *campos;
+};
+
+Camera make_camera(const instag_raster_args* a);
+
+// raster_preprocess.hip (built with -ffp-contract=off: bit-exact against the oracle)
+int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
+                      uint32_t* tiles_touched, uint32_t* flags, int32_t* radii, hipStream_t s);
+int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* tiles_touched,
+                     const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s);
+int launch_ranges(int64_t R, const uint64_t* keys_sorted, int32_t* ranges, hipStream_t s);
+
+// raster_blend.hip
+int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
+                         const float* rec2d, uint32_t* n_contrib, float* final_T, float* out_color,
+                         float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
+                         hipStream_t s);
+int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
+                          const float* rec2d, const uint32_t* n_contrib, const float* final_T,
+                          const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
+                          const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
+                          hipStream_t s);
+
+// raster_backward.hip
+int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, const float* rec2d,
+                               const float* cov3d, const uint32_t* tiles_touched, const uint32_t* flags,
+                               const int32_t* radii, const float* inst_grad, float* dL_dmeans3D,
+                               float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                               float* dL_dopacities, float* dL_dscales, float* dL_drotations,
+                               float* dL_dcov3D, float* dL_dextra, hipStream_t s);
+
+}  // namespace instag

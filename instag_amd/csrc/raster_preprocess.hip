@@ -1,0 +1,288 @@
+// Per-Gaussian stage of the rasterizer: projection, EWA covariance, tile rectangle, SH->RGB,
+// plus instance duplication and tile-range identification.
+//
+// This translation unit is compiled with -ffp-contract=off and every fp32 expression is written
+// in the exact order of oracle/rasterize_ref.py::preprocess so that radii, tile rectangles,
+// depths and therefore sort keys / bin counts are BIT-EXACT against the CPU oracle.
+//
+// Replaces the per-Gaussian stage of the reference's absent `diff_gauss` extension (call sites
+// gaussian_renderer/__init__.py:58-73,111-121); semantics = published 3DGS preprocess.
+#include "raster_internal.hpp"
+
+namespace instag {
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct PreIn {
+  const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *extra;
+};
+
+__global__ void __launch_bounds__(256)
+preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restrict__ cov3d,
+                  uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ flags_out,
+                  int32_t* __restrict__ radii) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= c.N) return;
+  radii[g] = 0;
+  tiles_touched[g] = 0;
+  const float* __restrict__ V = c.view;
+  const float* __restrict__ P = c.proj;
+  const float px = in.means3D[3 * g + 0], py = in.means3D[3 * g + 1], pz = in.means3D[3 * g + 2];
+
+  const float tx = ((V[0] * px + V[4] * py) + V[8] * pz) + V[12];
+  const float ty = ((V[1] * px + V[5] * py) + V[9] * pz) + V[13];
+  const float tz = ((V[2] * px + V[6] * py) + V[10] * pz) + V[14];
+  if (!(tz > 0.2f)) return;  // near-plane cull
+
+  const float hx = ((P[0] * px + P[4] * py) + P[8] * pz) + P[12];
+  const float hy = ((P[1] * px + P[5] * py) + P[9] * pz) + P[13];
+  const float hw = ((P[3] * px + P[7] * py) + P[11] * pz) + P[15];
+  const float p_w = 1.0f / (hw + 1e-7f);
+  const float ndc_x = hx * p_w;
+  const float ndc_y = hy * p_w;
+  const float pix_x = ((ndc_x + 1.0f) * (float)c.W - 1.0f) * 0.5f;
+  const float pix_y = ((ndc_y + 1.0f) * (float)c.H - 1.0f) * 0.5f;
+
+  uint32_t flags = 0;
+  float S00, S01, S02, S11, S12, S22;
+  float nvx = 0.f, nvy = 0.f, nvz = 0.f;
+  if (in.cov3Dp) {
+    S00 = in.cov3Dp[6 * g + 0]; S01 = in.cov3Dp[6 * g + 1]; S02 = in.cov3Dp[6 * g + 2];
+    S11 = in.cov3Dp[6 * g + 3]; S12 = in.cov3Dp[6 * g + 4]; S22 = in.cov3Dp[6 * g + 5];
+  } else {
+    const float sx = c.scale_modifier * in.scales[3 * g + 0];
+    const float sy = c.scale_modifier * in.scales[3 * g + 1];
+    const float sz = c.scale_modifier * in.scales[3 * g + 2];
+    const float r = in.rots[4 * g + 0], x = in.rots[4 * g + 1], y = in.rots[4 * g + 2], z = in.rots[4 * g + 3];
+    const float R00 = 1.0f - 2.0f * (y * y + z * z);
+    const float R01 = 2.0f * (x * y - r * z);
+    const float R02 = 2.0f * (x * z + r * y);
+    const float R10 = 2.0f * (x * y + r * z);
+    const float R11 = 1.0f - 2.0f * (x * x + z * z);
+    const float R12 = 2.0f * (y * z - r * x);
+    const float R20 = 2.0f * (x * z - r * y);
+    const float R21 = 2.0f * (y * z + r * x);
+    const float R22 = 1.0f - 2.0f * (x * x + y * y);
+    const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+    const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+    const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+    S00 = (M00 * M00 + M01 * M01) + M02 * M02;
+    S01 = (M00 * M10 + M01 * M11) + M02 * M12;
+    S02 = (M00 * M20 + M01 * M21) + M02 * M22;
+    S11 = (M10 * M10 + M11 * M11) + M12 * M12;
+    S12 = (M10 * M20 + M11 * M21) + M12 * M22;
+    S22 = (M20 * M20 + M21 * M21) + M22 * M22;
+    // shortest axis (first minimum) = column k of R, rotated into view space, facing the camera
+    const bool k0 = (sx <= sy) && (sx <= sz);
+    const bool k1 = (!k0) && (sy <= sz);
+    const int k = k0 ? 0 : (k1 ? 1 : 2);
+    const float nwx = k0 ? R00 : (k1 ? R01 : R02);
+    const float nwy = k0 ? R10 : (k1 ? R11 : R12);
+    const float nwz = k0 ? R20 : (k1 ? R21 : R22);
+    nvx = (nwx * V[0] + nwy * V[4]) + nwz * V[8];
+    nvy = (nwx * V[1] + nwy * V[5]) + nwz * V[9];
+    nvz = (nwx * V[2] + nwy * V[6]) + nwz * V[10];
+    const bool away = ((nvx * tx + nvy * ty) + nvz * tz) > 0.f;
+    const float sgn = away ? -1.0f : 1.0f;
+    nvx *= sgn; nvy *= sgn; nvz *= sgn;
+    flags |= (uint32_t)k << 3;
+    if (away) flags |= 1u << 5;
+  }
+
+  // EWA splat covariance
+  const float limx = 1.3f * c.tanfovx;
+  const float limy = 1.3f * c.tanfovy;
+  const float txtz = tx / tz;
+  const float tytz = ty / tz;
+  if (!(txtz >= -limx && txtz <= limx)) flags |= 1u << 6;
+  if (!(tytz >= -limy && tytz <= limy)) flags |= 1u << 7;
+  const float txc = fminf(limx, fmaxf(-limx, txtz)) * tz;
+  const float tyc = fminf(limy, fmaxf(-limy, tytz)) * tz;
+  const float J00 = c.focal_x / tz;
+  const float J02 = -(c.focal_x * txc) / (tz * tz);
+  const float J11 = c.focal_y / tz;
+  const float J12 = -(c.focal_y * tyc) / (tz * tz);
+  const float T00 = J00 * V[0] + J02 * V[2];
+  const float T01 = J00 * V[4] + J02 * V[6];
+  const float T02 = J00 * V[8] + J02 * V[10];
+  const float T10 = J11 * V[1] + J12 * V[2];
+  const float T11 = J11 * V[5] + J12 * V[6];
+  const float T12 = J11 * V[9] + J12 * V[10];
+  const float U00 = (S00 * T00 + S01 * T01) + S02 * T02;
+  const float U10 = (S01 * T00 + S11 * T01) + S12 * T02;
+  const float U20 = (S02 * T00 + S12 * T01) + S22 * T02;
+  const float U01 = (S00 * T10 + S01 * T11) + S02 * T12;
+  const float U11 = (S01 * T10 + S11 * T11) + S12 * T12;
+  const float U21 = (S02 * T10 + S12 * T11) + S22 * T12;
+  const float c00 = ((T00 * U00 + T01 * U10) + T02 * U20) + 0.3f;
+  const float c01 = (T00 * U01 + T01 * U11) + T02 * U21;
+  const float c11 = ((T10 * U01 + T11 * U11) + T12 * U21) + 0.3f;
+
+  const float det = c00 * c11 - c01 * c01;
+  if (det == 0.0f) return;
+  const float det_inv = 1.0f / det;
+  const float conA = c11 * det_inv;
+  const float conB = -c01 * det_inv;
+  const float conC = c00 * det_inv;
+  const float mid = 0.5f * (c00 + c11);
+  const float sq = sqrtf(fmaxf(mid * mid - det, 0.1f));
+  const float lam = fmaxf(mid + sq, mid - sq);
+  const float radius_f = ceilf(3.0f * sqrtf(lam));
+  if (!(radius_f > 0.0f) || !isfinite(radius_f) || !isfinite(pix_x) || !isfinite(pix_y)) return;
+  const int radius = (int)radius_f;
+  const float rf = (float)radius;
+  int rminx = min(c.grid_x, max(0, (int)((pix_x - rf) / (float)TILE_X)));
+  int rminy = min(c.grid_y, max(0, (int)((pix_y - rf) / (float)TILE_Y)));
+  int rmaxx = min(c.grid_x, max(0, (int)((((pix_x + rf) + (float)TILE_X) - 1.0f) / (float)TILE_X)));
+  int rmaxy = min(c.grid_y, max(0, (int)((((pix_y + rf) + (float)TILE_Y) - 1.0f) / (float)TILE_Y)));
+  const int tiles = (rmaxx - rminx) * (rmaxy - rminy);
+  if (tiles <= 0) return;
+
+  float cr, cg, cb;
+  if (in.shs) {
+    const float* __restrict__ sh = in.shs + (size_t)g * c.M * 3;
+    const float dx = px - c.campos[0], dy = py - c.campos[1], dz = pz - c.campos[2];
+    const float ln = sqrtf((dx * dx + dy * dy) + dz * dz);
+    const float x = dx / ln, y = dy / ln, z = dz / ln;
+    float res[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      float v = SH_C0 * sh[ch];
+      if (c.sh_degree > 0) {
+        v = v - SH_C1 * y * sh[3 + ch] + SH_C1 * z * sh[6 + ch] - SH_C1 * x * sh[9 + ch];
+        if (c.sh_degree > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          v = v + SH_C2[0] * xy * sh[12 + ch] + SH_C2[1] * yz * sh[15 + ch] +
+              SH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + SH_C2[3] * xz * sh[21 + ch] +
+              SH_C2[4] * (xx - yy) * sh[24 + ch];
+          if (c.sh_degree > 2) {
+            v = v + SH_C3[0] * y * (3.0f * xx - yy) * sh[27 + ch] + SH_C3[1] * xy * z * sh[30 + ch] +
+                SH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                SH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] + SH_C3[5] * z * (xx - yy) * sh[42 + ch] +
+                SH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
+          }
+        }
+      }
+      v = v + 0.5f;
+      if (v < 0.0f) flags |= 1u << ch;
+      res[ch] = fmaxf(v, 0.0f);
+    }
+    cr = res[0]; cg = res[1]; cb = res[2];
+  } else {
+    cr = in.colors[3 * g + 0]; cg = in.colors[3 * g + 1]; cb = in.colors[3 * g + 2];
+  }
+
+  radii[g] = radius;
+  tiles_touched[g] = (uint32_t)tiles;
+  flags_out[g] = flags;
+  float* c3 = cov3d + (size_t)g * 6;
+  c3[0] = S00; c3[1] = S01; c3[2] = S02; c3[3] = S11; c3[4] = S12; c3[5] = S22;
+
+  float4* rec = reinterpret_cast<float4*>(rec2d + (size_t)g * REC_FLOATS);
+  const uint32_t rect = (uint32_t)rminx | ((uint32_t)rminy << 10) | ((uint32_t)(rmaxx - rminx) << 20);
+  rec[0] = make_float4(pix_x, pix_y, conA, conB);
+  rec[1] = make_float4(conC, in.opac[g], cr, cg);
+  rec[2] = make_float4(cb, tz, nvx, nvy);
+  rec[3] = make_float4(nvz, (c.E > 0 && in.extra) ? in.extra[g] : 0.0f, 0.0f, __uint_as_float(rect));
+}
+
+// One thread per Gaussian: emit (tile<<32 | depth bits, gaussian id) for every touched tile and
+// record the exclusive instance offset in the blend record (used by blend-backward to address the
+// per-instance gradient row without an index array).
+__global__ void __launch_bounds__(256)
+duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ tiles_touched,
+                 const uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
+                 uint32_t* __restrict__ vals) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= N) return;
+  const uint32_t tt = tiles_touched[g];
+  if (tt == 0) return;
+  uint32_t off = point_offsets[g] - tt;
+  float* rec = rec2d + (size_t)g * REC_FLOATS;
+  const uint32_t rect = __float_as_uint(rec[R_RECT]);
+  const uint32_t depth_bits = __float_as_uint(rec[R_DEPTH]);
+  rec[R_OFFSET] = __uint_as_float(off);
+  const uint32_t rminx = rect & 1023u, rminy = (rect >> 10) & 1023u, rw = rect >> 20;
+  const uint32_t rh = tt / rw;
+  for (uint32_t y = rminy; y < rminy + rh; ++y) {
+    for (uint32_t x = rminx; x < rminx + rw; ++x) {
+      const uint64_t key = ((uint64_t)(y * (uint32_t)grid_x + x) << 32) | depth_bits;
+      keys[off] = key;
+      vals[off] = (uint32_t)g;
+      ++off;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, int32_t* __restrict__ ranges) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  const uint32_t tile = (uint32_t)(keys[i] >> 32);
+  if (i == 0) {
+    ranges[2 * tile] = 0;
+  } else {
+    const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+    if (prev != tile) {
+      ranges[2 * prev + 1] = (int32_t)i;
+      ranges[2 * tile] = (int32_t)i;
+    }
+  }
+  if (i == R - 1) ranges[2 * tile + 1] = (int32_t)R;
+}
+
+}  // namespace
+
+Camera make_camera(const instag_raster_args* a) {
+  Camera c;
+  c.N = a->N; c.M = a->M; c.sh_degree = a->sh_degree; c.E = a->E;
+  c.H = a->image_height; c.W = a->image_width;
+  c.tanfovx = a->tanfovx; c.tanfovy = a->tanfovy;
+  c.focal_x = (float)c.W / (2.0f * a->tanfovx);
+  c.focal_y = (float)c.H / (2.0f * a->tanfovy);
+  c.scale_modifier = a->scale_modifier;
+  c.grid_x = (c.W + TILE_X - 1) / TILE_X;
+  c.grid_y = (c.H + TILE_Y - 1) / TILE_Y;
+  c.bg = a->bg; c.view = a->viewmatrix; c.proj = a->projmatrix; c.campos = a->campos;
+  return c;
+}
+
+int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
+                      uint32_t* tiles_touched, uint32_t* flags, int32_t* radii, hipStream_t s) {
+  if (c.N == 0) return INSTAG_OK;
+  PreIn in{a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales, a->rotations,
+           a->cov3Ds_precomp, a->extra_attrs};
+  ProfScope p(K_PREPROCESS, s);
+  preprocess_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, in, rec2d, cov3d, tiles_touched, flags, radii);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* tiles_touched,
+                     const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s) {
+  if (c.N == 0) return INSTAG_OK;
+  ProfScope p(K_DUPLICATE, s);
+  duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, tiles_touched, point_offsets,
+                                                     keys, vals);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int launch_ranges(int64_t R, const uint64_t* keys_sorted, int32_t* ranges, hipStream_t s) {
+  if (R == 0) return INSTAG_OK;
+  ProfScope p(K_RANGES, s);
+  ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, keys_sorted, ranges);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+}  // namespace instag

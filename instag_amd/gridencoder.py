@@ -1,0 +1,148 @@
+"""Drop-in for the reference's ``gridencoder`` package on MI355X.
+
+Mirrors /root/reference/gridencoder/grid.py: ``_grid_encode`` (:24-89), ``grid_encode`` (:93),
+``GridEncoder`` (:96-185) -- same constructor arguments, attributes (``embeddings``, ``offsets``,
+``output_dim``, ...), state_dict keys and forward / grad_total_variation semantics, with the
+native calls replaced by libinstag_hip.so's C ABI (include/instag_hip.h).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, ptr
+
+_gridtype_to_id = {'hash': 0, 'tiled': 1}
+_interp_to_id = {'linear': 0, 'smoothstep': 1}
+
+
+def _check_inputs(**tensors):
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+class _grid_encode(Function):
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
+                gridtype=0, align_corners=False, interpolation=0):
+        # inputs: [B, D] float in [0, 1]; embeddings: [sO, C]; offsets: [L + 1] int32 -> [B, L * C]
+        inputs = inputs.contiguous().float()
+        embeddings = embeddings.contiguous().float()    # fp32 only (InsTaG never enables autocast, grid.py:43-44)
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = int(base_resolution)
+        if offsets.dtype != torch.int32:
+            raise RuntimeError("offsets must be an int tensor")
+        _check_inputs(inputs=inputs, embeddings=embeddings, offsets=offsets)
+
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=torch.float32)
+        dy_dx = torch.empty(B, L * D * C, device=inputs.device, dtype=torch.float32) if calc_grad_inputs else None
+        check(_lib.lib().instag_grid_encode_forward(ptr(inputs), ptr(embeddings), ptr(offsets), ptr(outputs),
+                                                    B, D, C, L, S, H, ptr(dy_dx), gridtype, int(align_corners),
+                                                    interpolation, _lib.current_stream()), "grid_encode_forward")
+        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.dims = [B, D, C, L, S, H, gridtype, interpolation]
+        ctx.align_corners = align_corners
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, interpolation = ctx.dims
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous().float()   # [L, B, C]
+        grad_embeddings = torch.zeros_like(embeddings)
+        grad_inputs = torch.zeros_like(inputs) if dy_dx is not None else None
+        check(_lib.lib().instag_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets),
+                                                     ptr(grad_embeddings), B, D, C, L, S, H, ptr(dy_dx),
+                                                     ptr(grad_inputs), gridtype, int(ctx.align_corners),
+                                                     interpolation, None, 0, embeddings.shape[0],
+                                                     _lib.current_stream()), "grid_encode_backward")
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+class GridEncoder(nn.Module):
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None, gridtype='hash', align_corners=False,
+                 interpolation='linear'):
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _gridtype_to_id[gridtype]
+        self.interpolation = interpolation
+        self.interp_id = _interp_to_id[interpolation]
+        self.align_corners = align_corners
+
+        offsets, offset = [], 0
+        self.max_params = 2 ** log2_hashmap_size
+        for i in range(num_levels):
+            resolution = int(np.ceil(base_resolution * per_level_scale ** i))
+            params_in_level = min(self.max_params, (resolution if align_corners else resolution + 1) ** input_dim)
+            params_in_level = int(np.ceil(params_in_level / 8) * 8)
+            offsets.append(offset)
+            offset += params_in_level
+        offsets.append(offset)
+        self.register_buffer('offsets', torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.n_params = offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(offset, level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        std = 1e-4
+        self.embeddings.data.uniform_(-std, std)
+
+    def __repr__(self):
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> "
+                f"{int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))} "
+                f"per_level_scale={self.per_level_scale:.4f} params={tuple(self.embeddings.shape)} "
+                f"gridtype={self.gridtype} align_corners={self.align_corners} interpolation={self.interpolation}")
+
+    def forward(self, inputs, bound=1):
+        inputs = (inputs + bound) / (2 * bound)          # map to [0, 1]
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        outputs = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                              inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
+        return outputs.view(prefix_shape + [self.output_dim])
+
+    @torch.no_grad()
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        D = self.input_dim
+        C = self.embeddings.shape[1]
+        L = self.offsets.shape[0] - 1
+        S = float(np.log2(self.per_level_scale))
+        H = self.base_resolution
+        if inputs is None:
+            inputs = torch.rand(B, self.input_dim, device=self.embeddings.device)
+        else:
+            inputs = ((inputs + bound) / (2 * bound)).view(-1, self.input_dim)
+            B = inputs.shape[0]
+        if self.embeddings.grad is None:
+            raise ValueError('grad is None, should be called after loss.backward() and before optimizer.step()!')
+        inputs = inputs.contiguous().float()
+        check(_lib.lib().instag_grid_total_variation(ptr(inputs), ptr(self.embeddings), ptr(self.embeddings.grad),
+                                                     ptr(self.offsets), float(weight), B, D, C, L, S, H,
+                                                     self.gridtype_id, int(self.align_corners),
+                                                     _lib.current_stream()), "grad_total_variation")

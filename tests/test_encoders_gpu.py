@@ -1,0 +1,126 @@
+"""GPU parity: HIP grid / SH encoders (through the C ABI) vs the CPU oracles and golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FACE = dict(input_dim=2, num_levels=12, level_dim=1, base_resolution=16, log2_hashmap_size=17,
+            desired_resolution=256 * 0.15)
+MOUTH = dict(input_dim=2, num_levels=12, level_dim=1, base_resolution=64, log2_hashmap_size=17,
+             desired_resolution=384 * 0.15)
+NGP3D = dict(input_dim=3, num_levels=8, level_dim=2, base_resolution=16, log2_hashmap_size=14,
+             desired_resolution=512)
+TILED = dict(input_dim=3, num_levels=4, level_dim=4, base_resolution=8, log2_hashmap_size=12,
+             desired_resolution=64, gridtype="tiled", align_corners=True, interpolation="smoothstep")
+
+
+def _pair(cfg, seed=0):
+    from instag_amd.gridencoder import GridEncoder
+    from oracle.grid_ref import GridEncoderRef
+    ref_cfg = dict(cfg)
+    ref = GridEncoderRef(seed=seed, **ref_cfg)
+    enc = GridEncoder(**cfg).cuda()
+    assert np.array_equal(enc.offsets.cpu().numpy(), ref.offsets)
+    # use O(1) embeddings so errors are visible (the 1e-4 init would hide them)
+    rng = np.random.default_rng(seed + 1)
+    ref.embeddings = rng.standard_normal(ref.embeddings.shape).astype(np.float32)
+    with torch.no_grad():
+        enc.embeddings.copy_(torch.from_numpy(ref.embeddings))
+    return enc, ref
+
+
+@pytest.mark.parametrize("cfg", [FACE, MOUTH, NGP3D, TILED], ids=["face", "mouth", "ngp3d-hash", "tiled-smooth"])
+def test_grid_forward_backward(cfg):
+    from oracle import grid_ref
+    enc, ref = _pair(cfg)
+    D = cfg["input_dim"]
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(5000, D, generator=g) * 2.2 - 1.1          # some points out of range -> zeros
+    x[0] = 1.0
+    x[1] = -1.0
+    xh = x.cuda().requires_grad_(True)
+    out = enc(xh, bound=1)
+    out_ref, dy_dx_ref = ref.forward(x.numpy(), bound=1, calc_grad_inputs=True)
+    assert out.shape == (5000, enc.output_dim)
+    assert float((out.detach().cpu() - torch.from_numpy(out_ref)).abs().max()) <= 2e-5
+    w = torch.randn(out.shape, generator=g)
+    (out * w.cuda()).sum().backward()
+    L, C = cfg["num_levels"], cfg["level_dim"]
+    grad_lbc = w.view(5000, L, C).permute(1, 0, 2).contiguous().numpy()
+    x01 = ((x.numpy().astype(np.float32) + np.float32(1)) / np.float32(2))
+    ge, gi = grid_ref.grid_encode_backward(grad_lbc, x01, ref.embeddings, ref.offsets, np.log2(ref.per_level_scale),
+                                           ref.base_resolution, dy_dx_ref, ref.gridtype_id, ref.align_corners,
+                                           ref.interp_id)
+    ge_h = enc.embeddings.grad.cpu().numpy()
+    assert np.abs(ge_h - ge).max() <= 2e-4 * max(1.0, np.abs(ge).max())
+    gi_h = xh.grad.cpu().numpy() * 2.0        # d/dx of (x+1)/2
+    assert np.abs(gi_h - gi).max() <= 2e-4 * max(1.0, np.abs(gi).max())
+
+
+def test_grid_known_answers():
+    """Vertex value = embedding, bilinear midpoint = mean of 4 corners, out-of-range -> 0 (gridencoder.cu:111-191)."""
+    from instag_amd.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=2, num_levels=1, level_dim=1, base_resolution=16, log2_hashmap_size=17,
+                      desired_resolution=16, align_corners=True).cuda()
+    with torch.no_grad():
+        enc.embeddings.copy_(torch.arange(enc.embeddings.numel(), dtype=torch.float32).view(-1, 1))
+    # align_corners: scale = 15, resolution 16, stride 16: vertex (i, j) -> index i + 16 j
+    v = torch.tensor([[3 / 15, 7 / 15], [3.5 / 15, 7.5 / 15], [1.5, 0.2], [-0.1, 0.5]]) * 2 - 1
+    out = enc(v.cuda(), bound=1).cpu().flatten()
+    assert abs(out[0].item() - (3 + 16 * 7)) < 1e-3
+    assert abs(out[1].item() - np.mean([3 + 16 * 7, 4 + 16 * 7, 3 + 16 * 8, 4 + 16 * 8])) < 1e-3
+    assert out[2].item() == 0.0 and out[3].item() == 0.0
+
+
+def test_grid_total_variation_runs():
+    from instag_amd.gridencoder import GridEncoder
+    enc = GridEncoder(**FACE).cuda()
+    x = torch.rand(1000, 2, device="cuda") * 2 - 1
+    with pytest.raises(ValueError):
+        enc.grad_total_variation(1e-3, x)
+    enc(x).sum().backward()
+    before = enc.embeddings.grad.clone()
+    enc.grad_total_variation(1e-3, x)
+    assert torch.isfinite(enc.embeddings.grad).all()
+    assert not torch.equal(before, enc.embeddings.grad)
+
+
+def test_grid_state_dict_names():
+    from instag_amd.gridencoder import GridEncoder
+    enc = GridEncoder(**FACE)
+    sd = enc.state_dict()
+    assert set(sd) == {"embeddings", "offsets"}
+    assert sd["embeddings"].shape == (9464, 1) and sd["offsets"].dtype == torch.int32
+    with pytest.raises(RuntimeError):
+        enc(torch.rand(4, 2))            # CPU tensor: no CPU path
+
+
+@pytest.mark.parametrize("degree", [1, 2, 4, 8])
+def test_sh_encoder_vs_golden(degree, golden_dir):
+    from instag_amd.shencoder import SHEncoder
+    g = np.load(f"{golden_dir}/g6_sh_encoder.npz")
+    x = torch.from_numpy(g["inputs"]).cuda().requires_grad_(True)
+    enc = SHEncoder(3, degree)
+    out = enc(x)
+    C2 = degree * degree
+    ref = g["outputs"][:, :C2]
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(out.detach().cpu().numpy() - ref).max() <= 5e-6 * scale
+    gen = torch.Generator().manual_seed(1)
+    w = torch.randn(out.shape, generator=gen)
+    (out * w.cuda()).sum().backward()
+    gi = np.stack([(g[k][:, :C2] * w.numpy()).sum(1) for k in ("dx", "dy", "dz")], axis=1)
+    assert np.abs(x.grad.cpu().numpy() - gi).max() <= 2e-5 * max(1.0, np.abs(gi).max())
+
+
+def test_sh_encoder_shapes_and_errors():
+    from instag_amd.shencoder import SHEncoder
+    enc = SHEncoder(3, 4)
+    y = enc(torch.rand(2, 5, 3, device="cuda"), size=2)
+    assert y.shape == (2, 5, 16)
+    assert abs(float(y[0, 0, 0]) - 0.28209479) < 1e-6
+    with pytest.raises(AssertionError):
+        SHEncoder(3, 9)
+    with pytest.raises(AssertionError):
+        SHEncoder(2, 4)
