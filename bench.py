@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: InsTaG face-branch train step at 512x512 with 100k Gaussians (config C3).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full train step on one synthetic frame per rank: PMF + UMF (6 grid encodes + MLPs)
+-> activations -> main raster pass + attention raster pass -> L1 + 0.2 DSSIM + regularisers -> backward
+-> fused-bucket gradient all-reduce (N>1) -> Adam/AdamW.  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+KERNEL_IDS = {"preprocess": 0, "duplicate": 1, "sort": 2, "ranges": 3, "blend_fwd": 4, "blend_bwd": 5,
+              "preprocess_bwd": 6, "grid_fwd": 7, "grid_bwd": 8}
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(kernel, N, M, R, P, grid_points=0):
+    """Per-launch algorithmic bytes, SURVEY.md section 8(d)."""
+    return {
+        "preprocess": N * (128 + 12 * M),
+        "duplicate": 12 * R,
+        "sort": 24 * R,
+        "ranges": 8 * R,
+        "blend_fwd": 60 * R + 44 * P,
+        "blend_bwd": 124 * R + 44 * P,
+        "preprocess_bwd": 64 * R + N * (128 + 24 * M),
+        "grid_fwd": grid_points * 152,
+        "grid_bwd": grid_points * 152,
+    }[kernel]
+
+
+def cpu_baseline(n_gaussians, size, sh_degree, budget_s=30.0):
+    """Oracle (pure-PyTorch CPU rasterizer) fwd+bwd of the same scene on the host cores."""
+    from instag_amd.scene_synth import activated, synthetic_gaussians, toy_cameras
+    from oracle import rasterize_ref as R
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))            # the GPU box gives one GPU a 16-core share
+    torch.set_num_threads(cores)
+    cam = toy_cameras(size)[0]
+    a = activated(synthetic_gaussians(n_gaussians, sh_degree=sh_degree, seed=0))
+    s = R.RasterSettings(size, size, cam.tanfovx, cam.tanfovy, torch.tensor([0.0, 1.0, 0.0]), 1.0,
+                         cam.world_view_transform, cam.full_proj_transform, sh_degree, cam.camera_center)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        inp = {k: v.clone().requires_grad_(True) for k, v in a.items()}
+        m2 = torch.zeros(n_gaussians, 3, requires_grad=True)
+        outs = R.rasterize(inp["means3D"], m2, inp["shs"], None, inp["opacities"], inp["scales"], inp["rotations"],
+                           None, torch.ones(n_gaussians, 1), s)
+        (outs[0].sum() + outs[3].sum()).backward()
+        frames += 1
+        el = time.perf_counter() - t0
+        if el * (frames + 1) / frames > budget_s or frames >= 2:
+            break
+    return {"value": frames / el, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} frame(s), main raster pass fwd+bwd only, {n_gaussians} Gaussians @{size}x{size} "
+                      f"(oracle/rasterize_ref.py, torch {torch.get_num_threads()} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=100000)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--sh-degree", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=30.0)
+    args = ap.parse_args()
+
+    t_start = time.perf_counter()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from instag_amd import _lib, diff_gauss
+    from instag_amd.scene_synth import synthetic_frame, toy_cameras
+    from instag_amd.train import build_trainer, make_frame
+
+    N, size = args.gaussians, args.size
+    trainer = build_trainer(N, dev, sh_degree=args.sh_degree, seed=0, densify=False)
+    cams = toy_cameras(size)
+    # rank r renders frames r, r+world, ... (all resident in HBM before timing)
+    frames = []
+    for k in range(8):
+        idx = (rank + k * world) % len(cams)
+        fd = synthetic_frame(size, seed=rank + k * world, device=dev)
+        frames.append(make_frame(cams[idx].to(dev), fd))
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    def run(n):
+        for i in range(n):
+            trainer.step(frames[i % len(frames)])
+
+    log(f"built trainer: {N} Gaussians, {size}x{size}, world {world}")
+    run(args.warmup)
+    log("warm-up done")
+    L = _lib.lib()
+    L.instag_prof_enable(-1)
+    L.instag_prof_reset()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region done: {1e3 * elapsed / args.steps:.3f} ms/step")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations from the HIP events recorded on the launch stream during the timed region
+    import ctypes as C
+    kern = {}
+    for name, kid in KERNEL_IDS.items():
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        L.instag_prof_read(kid, C.byref(ms), C.byref(cnt))
+        if cnt.value:
+            kern[name] = {"launches": int(cnt.value), "avg_us": 1e3 * ms.value / cnt.value,
+                          "total_ms": ms.value}
+    L.instag_prof_enable(0)
+
+    if rank == 0:
+        R = int(diff_gauss.LAST_STATS.get("num_rendered", 0))
+        P = size * size
+        M = (args.sh_degree + 1) ** 2
+        raster_kernels = [k for k in kern if k not in ("grid_fwd", "grid_bwd")]
+        dom = max(raster_kernels, key=lambda k: kern[k]["total_ms"]) if raster_kernels else None
+        roofline = None
+        if dom:
+            ab = algorithmic_bytes(dom, N, M, R, P, grid_points=N)
+            achieved = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(kern[dom]["avg_us"], 2),
+                        "launches": kern[dom]["launches"], "num_rendered": R}
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "train-step frames/sec @512x512, 100k Gaussians", "value": round(value, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: train_face step, 100k Gaussians + 6 grid encodes + UMF/PMF motion nets "
+                                   "(DeepSpeech feats), 512x512, SH degree 1, main + attention raster pass, "
+                                   "L1+DSSIM, Adam",
+                       "gaussians": N, "image": [size, size], "sh_degree": args.sh_degree,
+                       "frames_per_step_per_gpu": 1, "parallelism": f"dp{world}"},
+            "roofline": roofline,
+            "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
+            "raster_fwd_bwd_ms_per_frame": round(sum(v["total_ms"] for k, v in kern.items()
+                                                     if k not in ("grid_fwd", "grid_bwd")) / args.steps, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle baseline (bounded sample)")
+            out["cpu_baseline"] = cpu_baseline(N, size, args.sh_degree, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,10 @@ def _require_cuda(**tensors):
             raise RuntimeError(f"{name} must be a CUDA/HIP tensor (the MI355X rasterizer has no CPU path)")
 
 
+# statistics of the most recent forward (bench.py reads the instance count R for the roofline accounting)
+LAST_STATS = {"num_rendered": 0, "num_gaussians": 0}
+
+
 class _State:
     """Opaque device buffers kept between forward and backward (geom / binning / image)."""
     __slots__ = ("args", "keep", "geom", "binning", "image", "R", "radii", "N", "H", "W", "E", "M")
@@ -87,6 +91,7 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
     check(L.instag_raster_forward_stage1(C.byref(a), ptr(geom), geom.numel(), ptr(radii), C.byref(R), stream),
           "rasterize_gaussians")
     R = int(R.value)
+    LAST_STATS["num_rendered"], LAST_STATS["num_gaussians"] = R, N
     binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
     image = torch.empty(L.instag_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
     color = torch.empty(3, H, W, dtype=torch.float32, device=dev)

@@ -1,0 +1,286 @@
+"""Gaussian scene state for the MI355X train step: parameters, activations, Adam groups,
+densification statistics and densify / prune.
+
+Counterpart of /root/reference/scene/gaussian_model.py (only what the hot path touches):
+  activations            :43-51   softplus scale, sigmoid opacity, normalised rotation
+  getters                :168-196
+  create_from_pcd        :206-335 (random-cloud init; 3-NN scale init replaced by an explicit scale)
+  training_setup         :349-403 7 per-Gaussian Adam groups (eps 1e-15) + PMF groups
+  update_learning_rate   :421-427 with utils/general_utils.py get_expon_lr_func
+  prune / cat / densify  :563-681
+  add_densification_stats:683-685
+All per-Gaussian tensors stay resident on the GPU; nothing here is CPU-fallback code, it is plain
+torch bookkeeping that runs on whatever device the parameters live on (so the host logic is
+testable on CPU).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+PARAM_NAMES = ("xyz", "f_dc", "f_rest", "identity", "opacity", "scaling", "rotation")
+
+
+def inverse_sigmoid(x):
+    return torch.log(x / (1 - x))
+
+
+def inverse_softplus(x):
+    return x + torch.log(-torch.expm1(-x))
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """Log-linear learning-rate decay with optional warm-up (utils/general_utils.py:37-69)."""
+
+    def helper(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        if lr_delay_steps > 0:
+            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
+        else:
+            delay_rate = 1.0
+        t = np.clip(step / max_steps, 0, 1)
+        return delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
+
+    return helper
+
+
+def quat_to_rotmat(q):
+    """Normalised quaternion (r,x,y,z) -> [N,3,3] (utils/general_utils.py:87-105)."""
+    q = q / q.norm(dim=1, keepdim=True)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1)
+    return R.view(-1, 3, 3)
+
+
+class OptimizationParams:
+    """Hot-path values of /root/reference/arguments/__init__.py:79-99."""
+    iterations = 10000
+    position_lr_init = 0.00016
+    position_lr_final = 0.0000016
+    position_lr_delay_mult = 0.01
+    position_lr_max_steps = 45000
+    feature_lr = 0.0025
+    opacity_lr = 0.05
+    scaling_lr = 0.003
+    rotation_lr = 0.001
+    percent_dense = 0.005
+    lambda_dssim = 0.2
+    densification_interval = 100
+    opacity_reset_interval = 3000
+    densify_from_iter = 500
+    densify_until_iter = 9000
+    densify_grad_threshold = 0.0005
+
+
+class GaussianModel:
+    def __init__(self, sh_degree: int = 1, neural_motion_grid: Optional[nn.Module] = None):
+        self.max_sh_degree = sh_degree
+        self.active_sh_degree = sh_degree
+        self._p: Dict[str, nn.Parameter] = {}
+        self.max_radii2D = torch.empty(0)
+        self.xyz_gradient_accum = torch.empty(0)
+        self.denom = torch.empty(0)
+        self.optimizer = None
+        self.percent_dense = 0.0
+        self.spatial_lr_scale = 1.0
+        self.neural_motion_grid = neural_motion_grid
+        self.scaling_activation = torch.nn.functional.softplus
+        self.scaling_inverse_activation = inverse_softplus
+        self.opacity_activation = torch.sigmoid
+        self.inverse_opacity_activation = inverse_sigmoid
+        self.rotation_activation = torch.nn.functional.normalize
+
+    # ---- parameters ------------------------------------------------------------------------------
+    _xyz = property(lambda s: s._p["xyz"])
+    _features_dc = property(lambda s: s._p["f_dc"])
+    _features_rest = property(lambda s: s._p["f_rest"])
+    _identity = property(lambda s: s._p["identity"])
+    _opacity = property(lambda s: s._p["opacity"])
+    _scaling = property(lambda s: s._p["scaling"])
+    _rotation = property(lambda s: s._p["rotation"])
+
+    @property
+    def get_xyz(self):
+        return self._p["xyz"]
+
+    @property
+    def get_scaling(self):
+        return self.scaling_activation(self._p["scaling"])
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._p["rotation"])
+
+    @property
+    def get_opacity(self):
+        return self.opacity_activation(self._p["opacity"])
+
+    @property
+    def get_features(self):
+        return torch.cat((self._p["f_dc"], self._p["f_rest"]), dim=1)
+
+    @property
+    def num_points(self):
+        return self._p["xyz"].shape[0]
+
+    def load_raw(self, raw: Dict[str, torch.Tensor], device):
+        """raw: dict with xyz, scaling, rotation, opacity, features_dc, features_rest (pre-activation)."""
+        n = raw["xyz"].shape[0]
+        vals = dict(xyz=raw["xyz"], f_dc=raw["features_dc"], f_rest=raw["features_rest"],
+                    identity=torch.zeros(n, 1), opacity=raw["opacity"], scaling=raw["scaling"],
+                    rotation=raw["rotation"])
+        self._p = {k: nn.Parameter(v.detach().clone().float().to(device).contiguous().requires_grad_(True))
+                   for k, v in vals.items()}
+        self.max_radii2D = torch.zeros(n, device=device)
+        return self
+
+    def create_random(self, n, device, spatial_lr_scale=1.0, seed=0, init_scale=0.004):
+        """Random cloud in [-0.1,0.1]^3 like scene/dataset_readers.py:353 + create_from_pcd :206-335."""
+        g = torch.Generator().manual_seed(seed)
+        M = (self.max_sh_degree + 1) ** 2
+        scales = torch.full((n, 3), init_scale)
+        rot = torch.zeros(n, 4)
+        rot[:, 0] = 1
+        raw = dict(xyz=torch.rand(n, 3, generator=g) * 0.2 - 0.1, scaling=inverse_softplus(scales), rotation=rot,
+                   opacity=inverse_sigmoid(0.1 * torch.ones(n, 1)),
+                   features_dc=(torch.rand(n, 1, 3, generator=g) - 0.5) / 0.28209479177387814,
+                   features_rest=torch.zeros(n, M - 1, 3))
+        self.spatial_lr_scale = spatial_lr_scale
+        return self.load_raw(raw, device)
+
+    # ---- optimizer ---------------------------------------------------------------------------------
+    def training_setup(self, opt=OptimizationParams, fused: Optional[bool] = None):
+        dev = self._p["xyz"].device
+        n = self.num_points
+        self.percent_dense = opt.percent_dense
+        self.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
+        self.denom = torch.zeros(n, 1, device=dev)
+        lrs = dict(xyz=opt.position_lr_init * self.spatial_lr_scale, f_dc=opt.feature_lr,
+                   f_rest=opt.feature_lr / 20.0, identity=1e-2, opacity=opt.opacity_lr, scaling=opt.scaling_lr,
+                   rotation=opt.rotation_lr)
+        groups = [{"params": [self._p[k]], "lr": lrs[k], "name": k} for k in PARAM_NAMES]
+        if self.neural_motion_grid is not None:
+            groups += self.neural_motion_grid.get_params(lr=1e-3, lr_net=1e-4)
+        kw = {}
+        if fused is None:
+            fused = dev.type == "cuda"
+        if fused:
+            kw["fused"] = True
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **kw)
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=opt.position_lr_init * self.spatial_lr_scale, lr_final=opt.position_lr_final * self.spatial_lr_scale,
+            lr_delay_mult=opt.position_lr_delay_mult, max_steps=opt.position_lr_max_steps)
+
+    def update_learning_rate(self, iteration):
+        for group in self.optimizer.param_groups:
+            if group.get("name") == "xyz":
+                group["lr"] = self.xyz_scheduler_args(iteration)
+                return group["lr"]
+
+    # ---- densification ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def add_densification_stats(self, viewspace_grad, update_filter):
+        """viewspace_grad: means2D.grad [N,3] (NDC units), update_filter: radii > 0."""
+        norm = torch.norm(viewspace_grad[:, :2], dim=-1, keepdim=True)
+        m = update_filter[:, None].to(norm.dtype)
+        self.xyz_gradient_accum += norm * m
+        self.denom += m
+
+    @torch.no_grad()
+    def _rebuild(self, keep: Optional[torch.Tensor], extra: Optional[Dict[str, torch.Tensor]]):
+        """New parameter set = cat(old[keep], extra); Adam moments follow (zeros for new rows)."""
+        for group in self.optimizer.param_groups:
+            name = group.get("name", "")
+            if name not in self._p:
+                continue
+            old = group["params"][0]
+            state = self.optimizer.state.pop(old, None)
+
+            def remap(t, fill_zero):
+                t = t if keep is None else t[keep]
+                if extra is not None:
+                    add = torch.zeros_like(extra[name]) if fill_zero else extra[name]
+                    t = torch.cat((t, add), dim=0)
+                return t
+            new = nn.Parameter(remap(old.data, False).contiguous().requires_grad_(True))
+            if state is not None:
+                state["exp_avg"] = remap(state["exp_avg"], True).contiguous()
+                state["exp_avg_sq"] = remap(state["exp_avg_sq"], True).contiguous()
+                self.optimizer.state[new] = state
+            group["params"][0] = new
+            self._p[name] = new
+
+    @torch.no_grad()
+    def prune_points(self, mask):
+        keep = ~mask
+        self._rebuild(keep, None)
+        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
+        self.denom = self.denom[keep]
+        self.max_radii2D = self.max_radii2D[keep]
+
+    @torch.no_grad()
+    def _append(self, extra):
+        self._rebuild(None, extra)
+        dev, n = self._p["xyz"].device, self.num_points
+        self.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
+        self.denom = torch.zeros(n, 1, device=dev)
+        self.max_radii2D = torch.zeros(n, device=dev)
+
+    @torch.no_grad()
+    def densify_and_clone(self, grads, grad_threshold, scene_extent):
+        sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
+              (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
+        self._append({k: self._p[k].data[sel] for k in PARAM_NAMES})
+
+    @torch.no_grad()
+    def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None):
+        n0 = self.num_points
+        padded = torch.zeros(n0, device=grads.device)
+        padded[:grads.shape[0]] = grads.squeeze(-1)
+        sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
+        stds = self.get_scaling[sel].repeat(N, 1)
+        samples = torch.randn(stds.shape, device=stds.device, generator=generator) * stds
+        rots = quat_to_rotmat(self._p["rotation"].data[sel]).repeat(N, 1, 1)
+        extra = {k: self._p[k].data[sel].repeat(N, *([1] * (self._p[k].dim() - 1))) for k in PARAM_NAMES}
+        extra["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._p["xyz"].data[sel].repeat(N, 1)
+        extra["scaling"] = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
+        self._append(extra)
+        prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device=sel.device, dtype=torch.bool)))
+        self.prune_points(prune)
+
+    @torch.no_grad()
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        self.densify_and_clone(grads, max_grad, extent)
+        self.densify_and_split(grads, max_grad, extent, generator=generator)
+        prune_mask = (self.get_opacity < min_opacity).squeeze(-1)
+        if max_screen_size:
+            prune_mask = prune_mask | (self.max_radii2D > max_screen_size) | \
+                (self.get_scaling.max(dim=1).values > 0.1 * extent)
+        self.prune_points(prune_mask)
+
+    @torch.no_grad()
+    def reset_opacity(self):
+        new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
+        group = next(g for g in self.optimizer.param_groups if g.get("name") == "opacity")
+        old = group["params"][0]
+        state = self.optimizer.state.pop(old, None)
+        p = nn.Parameter(new.contiguous().requires_grad_(True))
+        if state is not None:
+            state["exp_avg"] = torch.zeros_like(new)
+            state["exp_avg_sq"] = torch.zeros_like(new)
+            self.optimizer.state[p] = state
+        group["params"][0] = p
+        self._p["opacity"] = p
+
+    def per_gaussian_parameters(self):
+        return [self._p[k] for k in PARAM_NAMES]

@@ -1,0 +1,230 @@
+"""Audio-to-deformation motion networks of InsTaG, re-implemented for the MI355X path.
+
+Counterpart of /root/reference/scene/motion_net.py (same module / parameter names so reference
+``state_dict``s load unchanged):
+  AudioAttNet :29-64, AudioNet :67-99, MLP :152-173,
+  MotionNetwork (UMF) :176-345, PersonalizedMotionNetwork (PMF) :562-748.
+The tri-plane grid encoders are ``instag_amd.gridencoder.GridEncoder`` (HIP); ``encoder_cls`` lets
+the CPU tests inject the oracle encoder.  The per-Gaussian MLP chains are dense GEMMs with B = N
+rows (torch Linear -> hipBLASLt on the device).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_AUDIO_DIMS = (("esperanto", 44), ("deepspeech", 29), ("hubert", 1024), ("ave", 32))
+
+
+def audio_in_dim(extractor: str) -> int:
+    for key, dim in _AUDIO_DIMS:
+        if key in extractor:
+            return dim
+    raise NotImplementedError(extractor)
+
+
+class AudioAttNet(nn.Module):
+    """Attention over the 8-frame audio window -> one feature vector (motion_net.py:29-64)."""
+
+    def __init__(self, dim_aud=64, seq_len=8):
+        super().__init__()
+        self.seq_len, self.dim_aud = seq_len, dim_aud
+        chans = [dim_aud, 16, 8, 4, 2, 1]
+        layers = []
+        for cin, cout in zip(chans[:-1], chans[1:]):
+            layers += [nn.Conv1d(cin, cout, kernel_size=3, stride=1, padding=1, bias=True), nn.LeakyReLU(0.02, True)]
+        self.attentionConvNet = nn.Sequential(*layers)
+        self.attentionNet = nn.Sequential(nn.Linear(seq_len, seq_len, bias=True), nn.Softmax(dim=1))
+
+    def forward(self, x):                       # x: [1, seq_len, dim_aud]
+        y = self.attentionConvNet(x.permute(0, 2, 1))
+        y = self.attentionNet(y.view(1, self.seq_len)).view(1, self.seq_len, 1)
+        return torch.sum(y * x, dim=1)
+
+
+class AudioNet(nn.Module):
+    """Per-frame audio feature encoder: 4 stride-2 conv1d + 2 FC (motion_net.py:67-99)."""
+
+    def __init__(self, dim_in=29, dim_aud=64, win_size=16):
+        super().__init__()
+        self.win_size, self.dim_aud = win_size, dim_aud
+        mid = 32 if dim_in < 128 else 128
+        chans = [dim_in, mid, mid, 64, 64]
+        layers = []
+        for cin, cout in zip(chans[:-1], chans[1:]):
+            layers += [nn.Conv1d(cin, cout, kernel_size=3, stride=2, padding=1, bias=True), nn.LeakyReLU(0.02, True)]
+        self.encoder_conv = nn.Sequential(*layers)
+        self.encoder_fc1 = nn.Sequential(nn.Linear(64, 64), nn.LeakyReLU(0.02, True), nn.Linear(64, dim_aud))
+
+    def forward(self, x):
+        half = self.win_size // 2
+        x = x[:, :, 8 - half:8 + half]
+        return self.encoder_fc1(self.encoder_conv(x).squeeze(-1))
+
+
+class MLP(nn.Module):
+    """Bias-free ReLU MLP (motion_net.py:152-173)."""
+
+    def __init__(self, dim_in, dim_out, dim_hidden, num_layers):
+        super().__init__()
+        self.dim_in, self.dim_out, self.dim_hidden, self.num_layers = dim_in, dim_out, dim_hidden, num_layers
+        self.net = nn.ModuleList([
+            nn.Linear(dim_in if l == 0 else dim_hidden, dim_out if l == num_layers - 1 else dim_hidden, bias=False)
+            for l in range(num_layers)])
+
+    def forward(self, x):
+        for l, layer in enumerate(self.net):
+            x = layer(x)
+            if l != self.num_layers - 1:
+                x = F.relu(x)
+        return x
+
+
+def _default_encoder_cls():
+    from .gridencoder import GridEncoder
+    return GridEncoder
+
+
+class _TriPlaneField(nn.Module):
+    """Shared part of UMF / PMF: audio branch, tri-plane encoders, attention MLPs, sigma_net."""
+
+    def __init__(self, audio_extractor, audio_dim, hidden_dim, exp_eye, out_dim, ind_dim=0, encoder_cls=None):
+        super().__init__()
+        encoder_cls = encoder_cls or _default_encoder_cls()
+        self.audio_in_dim = audio_in_dim(audio_extractor)
+        self.bound = 0.15
+        self.exp_eye = exp_eye
+        self.individual_dim = ind_dim
+        if ind_dim > 0:
+            self.individual_codes = nn.Parameter(torch.randn(10000, ind_dim) * 0.1)
+        self.audio_dim = audio_dim
+        if audio_extractor == "ave":
+            raise NotImplementedError("the 'ave' audio extractor is outside the accelerated path")
+        self.audio_net = AudioNet(self.audio_in_dim, audio_dim)
+        self.audio_att_net = AudioAttNet(audio_dim)
+        self.num_levels, self.level_dim = 12, 1
+        enc = dict(input_dim=2, num_levels=self.num_levels, level_dim=self.level_dim, base_resolution=16,
+                   log2_hashmap_size=17, desired_resolution=256 * self.bound, gridtype="hash", align_corners=False)
+        self.encoder_xy, self.encoder_yz, self.encoder_xz = encoder_cls(**enc), encoder_cls(**enc), encoder_cls(**enc)
+        self.in_dim_xy = self.in_dim_yz = self.in_dim_xz = self.encoder_xy.output_dim
+        self.in_dim = 3 * self.encoder_xy.output_dim
+        self.num_layers = 3
+        self.hidden_dim = hidden_dim
+        self.exp_in_dim = 5
+        self.eye_dim = 6 if exp_eye else 0
+        if exp_eye:
+            self.exp_encode_net = MLP(self.exp_in_dim, self.eye_dim - 1, 16, 2)
+            self.eye_att_net = MLP(self.in_dim, self.eye_dim, 16, 2)
+        self.out_dim = out_dim
+        self.sigma_net = MLP(self.in_dim + audio_dim + self.eye_dim + ind_dim, out_dim, hidden_dim, self.num_layers)
+        self.aud_ch_att_net = MLP(self.in_dim, audio_dim, 32, 2)
+
+    def encode_x(self, xyz, bound):
+        xy, yz = xyz[:, :-1], xyz[:, 1:]
+        xz = torch.cat([xyz[:, :1], xyz[:, -1:]], dim=-1)
+        return torch.cat([self.encoder_xy(xy, bound=bound), self.encoder_yz(yz, bound=bound),
+                          self.encoder_xz(xz, bound=bound)], dim=-1)
+
+    def encode_audio(self, a):
+        if a is None:
+            return None
+        return self.audio_att_net(self.audio_net(a).unsqueeze(0))
+
+    def _trunk(self, x, a, e, c):
+        enc_x = self.encode_x(x, bound=self.bound)
+        enc_a = self.encode_audio(a).repeat(enc_x.shape[0], 1)
+        aud_ch_att = self.aud_ch_att_net(enc_x)
+        parts = [enc_x, enc_a * aud_ch_att]
+        eye_att = None
+        if self.exp_eye:
+            eye_att = torch.relu(self.eye_att_net(enc_x))
+            enc_e = torch.cat([self.exp_encode_net(e[:-1]), e[-1:]], dim=-1)
+            parts.append(enc_e * eye_att)
+        if c is not None:
+            parts.append(c.repeat(enc_x.shape[0], 1))
+        h = self.sigma_net(torch.cat(parts, dim=-1))
+        return enc_x, aud_ch_att, eye_att, h
+
+
+class MotionNetwork(_TriPlaneField):
+    """Universal motion field (UMF), hidden 64, 11 outputs (motion_net.py:176-345)."""
+
+    def __init__(self, audio_dim=32, ind_dim=0, args=None, encoder_cls=None):
+        super().__init__(args.audio_extractor, audio_dim, 64, True, 11, ind_dim, encoder_cls)
+        self.cache = None
+
+    def forward(self, x, a, e=None, c=None):
+        _, aud_ch_att, eye_att, h = self._trunk(x, a, e, c)
+        results = {
+            "d_xyz": h[..., :3] * 1e-2, "d_rot": h[..., 3:7], "d_opa": h[..., 7:8], "d_scale": h[..., 8:11],
+            "ambient_aud": aud_ch_att.norm(dim=-1, keepdim=True),
+            "ambient_eye": eye_att.norm(dim=-1, keepdim=True),
+        }
+        self.cache = results
+        return results
+
+    def get_params(self, lr, lr_net, wd=0):
+        params = [
+            {"params": self.audio_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.encoder_xy.parameters(), "lr": lr},
+            {"params": self.encoder_yz.parameters(), "lr": lr},
+            {"params": self.encoder_xz.parameters(), "lr": lr},
+            {"params": self.sigma_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.audio_att_net.parameters(), "lr": lr_net * 5, "weight_decay": 0.0001},
+        ]
+        if self.individual_dim > 0:
+            params.append({"params": self.individual_codes, "lr": lr_net, "weight_decay": wd})
+        params += [
+            {"params": self.aud_ch_att_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.eye_att_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.exp_encode_net.parameters(), "lr": lr_net, "weight_decay": wd},
+        ]
+        return params
+
+
+class PersonalizedMotionNetwork(_TriPlaneField):
+    """Personalised motion field (PMF) + alignment head (motion_net.py:562-748)."""
+
+    def __init__(self, audio_dim=32, ind_dim=0, args=None, encoder_cls=None):
+        face = args.type == "face"
+        super().__init__(args.audio_extractor, audio_dim, 32 if face else 16, face, 11 if face else 7, ind_dim,
+                         encoder_cls)
+        self.args = args
+        self.align_net = MLP(self.in_dim, 6, self.hidden_dim, 2)
+
+    def forward(self, x, a, e=None, c=None, va=None):
+        enc_x, aud_ch_att, eye_att, h = self._trunk(x, a, e, c)
+        face = self.args.type == "face"
+        p = self.align_net(enc_x)
+        return {
+            "d_xyz": h[..., :3] * 1e-2, "d_rot": h[..., 3:7],
+            "d_opa": h[..., 7:8] if face else None, "d_scale": h[..., 8:11] if face else None,
+            "ambient_aud": aud_ch_att.norm(dim=-1, keepdim=True),
+            "ambient_eye": eye_att.norm(dim=-1, keepdim=True) if self.exp_eye else None,
+            "p_xyz": p[..., :3] * 1e-2,
+            "p_scale": torch.tanh(p[..., 3:] / 5) * 0.25 + 1,
+        }
+
+    def get_params(self, lr, lr_net, wd=0):
+        params = [
+            {"params": self.audio_net.parameters(), "name": "neural_audio_net", "lr": lr_net, "weight_decay": wd},
+            {"params": self.encoder_xy.parameters(), "name": "neural_encoder_xy", "lr": lr},
+            {"params": self.encoder_yz.parameters(), "name": "neural_encoder_xy", "lr": lr},
+            {"params": self.encoder_xz.parameters(), "name": "neural_encoder_xy", "lr": lr},
+            {"params": self.sigma_net.parameters(), "name": "neural_sigma_net", "lr": lr_net, "weight_decay": wd},
+            {"params": self.align_net.parameters(), "name": "neural_align_net", "lr": lr_net / 2, "weight_decay": wd},
+            {"params": self.audio_att_net.parameters(), "name": "neural_audio_att_net", "lr": lr_net * 5,
+             "weight_decay": 0.0001},
+        ]
+        if self.individual_dim > 0:
+            params.append({"params": self.individual_codes, "name": "neural_individual_codes", "lr": lr_net,
+                           "weight_decay": wd})
+        params.append({"params": self.aud_ch_att_net.parameters(), "name": "neural_aud_ch_att_net", "lr": lr_net,
+                       "weight_decay": wd})
+        if self.exp_eye:
+            params.append({"params": self.eye_att_net.parameters(), "name": "neural_eye_att_net", "lr": lr_net,
+                           "weight_decay": wd})
+            params.append({"params": self.exp_encode_net.parameters(), "name": "neural_exp_encode_net",
+                           "lr": lr_net, "weight_decay": wd})
+        return params

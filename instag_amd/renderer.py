@@ -1,0 +1,101 @@
+"""Render composition on the MI355X operators: ``render`` and ``render_motion``.
+
+Counterpart of /root/reference/gaussian_renderer/__init__.py: render :37-133, render_motion :151-298
+(same argument meaning and returned dictionary keys).  ``viewpoint_camera`` needs the attributes the
+reference reads: FoVx, FoVy, image_height, image_width, world_view_transform, full_proj_transform,
+camera_center, and ``talking_dict`` with ``auds`` [8,29,16] and ``au_exp`` [6] for render_motion.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from .diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def _settings(cam, pc, bg_color, scaling_modifier, debug=False):
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width),
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug)
+
+
+def _screenspace_points(pc):
+    pts = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
+    try:
+        pts.retain_grad()
+    except Exception:
+        pass
+    return pts
+
+
+def render(viewpoint_camera, pc, pipe=None, bg_color=None, scaling_modifier=1.0, override_color=None):
+    """Static render (no motion fields)."""
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(_settings(viewpoint_camera, pc, bg_color, scaling_modifier,
+                                              getattr(pipe, "debug", False)))
+    opacity = pc.get_opacity
+    shs, colors = (pc.get_features, None) if override_color is None else (None, override_color)
+    image, depth, normal, alpha, radii, extra = rasterizer(
+        means3D=pc.get_xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors, opacities=opacity,
+        scales=pc.get_scaling, rotations=pc.get_rotation, cov3Ds_precomp=None,
+        extra_attrs=torch.ones_like(opacity))
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "depth": depth, "alpha": alpha, "normal": normal, "radii": radii}
+
+
+def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, scaling_modifier=1.0, frame_idx=None,
+                  return_attn=False, personalized=False, align=False, detach_motion=False):
+    """Render with the universal (motion_net) and personalised (pc.neural_motion_grid) motion fields."""
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(_settings(viewpoint_camera, pc, bg_color, scaling_modifier,
+                                              getattr(pipe, "debug", False)))
+    dev = pc.get_xyz.device
+    audio_feat = viewpoint_camera.talking_dict["auds"].to(dev, non_blocking=True)
+    exp_feat = viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True)
+
+    xyz = pc.get_xyz
+    p_motion_preds = None
+    if personalized or align:
+        p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat, exp_feat)
+    if align:
+        xyz = xyz + p_motion_preds["p_xyz"]
+    motion_preds = motion_net(xyz, audio_feat, exp_feat)
+    d_xyz, d_scale, d_rot = motion_preds["d_xyz"], motion_preds["d_scale"], motion_preds["d_rot"]
+    if personalized:
+        d_xyz = d_xyz + p_motion_preds["d_xyz"]
+        d_scale = d_scale + p_motion_preds["d_scale"]
+        d_rot = d_rot + p_motion_preds["d_rot"]
+    if align:
+        d_xyz = d_xyz * p_motion_preds["p_scale"]
+    if detach_motion:
+        d_xyz, d_scale, d_rot = d_xyz.detach(), d_scale.detach(), d_rot.detach()
+
+    means3D = pc.get_xyz + d_xyz
+    opacity = pc.get_opacity
+    scales = pc.scaling_activation(pc._scaling + d_scale)
+    rotations = pc.rotation_activation(pc._rotation + d_rot)
+    ones = torch.ones_like(opacity)
+    image, depth, normal, alpha, radii, extra = rasterizer(
+        means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
+        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=ones)
+
+    rendered_attn = p_rendered_attn = None
+    if return_attn:
+        def attn_pass(preds):
+            eye = preds["ambient_eye"]
+            attn_precomp = torch.cat([preds["ambient_aud"], eye, torch.zeros_like(eye)], dim=-1)
+            out = rasterizer(means3D=means3D.detach(), means2D=screenspace_points, shs=None,
+                             colors_precomp=attn_precomp, opacities=opacity.detach(), scales=scales.detach(),
+                             rotations=rotations.detach(), cov3Ds_precomp=None, extra_attrs=ones)
+            return out[0]
+        rendered_attn = attn_pass(motion_preds)
+        if personalized:
+            p_rendered_attn = attn_pass(p_motion_preds)
+
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "depth": depth, "alpha": alpha, "normal": normal, "radii": radii, "motion": motion_preds,
+            "p_motion": p_motion_preds if personalized or align else None, "attn": rendered_attn,
+            "p_attn": p_rendered_attn}

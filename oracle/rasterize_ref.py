@@ -80,12 +80,18 @@ def _f(x) -> float:
     return float(F32(x))
 
 
+def _sqrt(x: torch.Tensor) -> torch.Tensor:
+    """Correctly rounded fp32 sqrt (torch's vectorised CPU sqrtf is 1 ulp off for ~0.7% of inputs;
+    the HIP sqrtf is correctly rounded).  sqrt in fp64 then one rounding is exact for fp32 inputs."""
+    return torch.sqrt(x.double()).to(x.dtype)
+
+
 def eval_sh_rgb(deg: int, shs: torch.Tensor, means3D: torch.Tensor, campos: torch.Tensor):
     """SH -> RGB in the fixed evaluation order the HIP kernel uses.  shs: [N, M, 3]."""
     dx = means3D[:, 0] - campos[0]
     dy = means3D[:, 1] - campos[1]
     dz = means3D[:, 2] - campos[2]
-    ln = torch.sqrt((dx * dx + dy * dy) + dz * dz)
+    ln = _sqrt((dx * dx + dy * dy) + dz * dz)
     x = (dx / ln)[:, None]
     y = (dy / ln)[:, None]
     z = (dz / ln)[:, None]
@@ -208,9 +214,10 @@ def preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotatio
     oky = (tytz.detach() >= -limy) & (tytz.detach() <= limy)
     txc = torch.where(okx, txtz * tz, (torch.clamp(txtz, -limx, limx) * tz).detach())
     tyc = torch.where(oky, tytz * tz, (torch.clamp(tytz, -limy, limy) * tz).detach())
-    J00 = focal_x / tz
+    # NB: python_scalar / tensor is evaluated by torch as reciprocal * scalar (two roundings)
+    J00 = torch.full_like(tz, focal_x) / tz
     J02 = -(focal_x * txc) / (tz * tz)
-    J11 = focal_y / tz
+    J11 = torch.full_like(tz, focal_y) / tz
     J12 = -(focal_y * tyc) / (tz * tz)
     # T = J * W, W = world->view rotation = V[:3,:3]^T
     T00 = J00 * V[0, 0] + J02 * V[0, 2]
@@ -237,9 +244,9 @@ def preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotatio
     con_z = c00 * det_inv
     with torch.no_grad():
         mid = 0.5 * (c00 + c11)
-        sq = torch.sqrt(torch.clamp_min(mid * mid - det, _f(0.1)))
+        sq = _sqrt(torch.clamp_min(mid * mid - det, _f(0.1)))
         lam = torch.maximum(mid + sq, mid - sq)
-        radius_f = torch.ceil(3.0 * torch.sqrt(lam))
+        radius_f = torch.ceil(3.0 * _sqrt(lam))
         finite = torch.isfinite(radius_f) & (radius_f > 0) & torch.isfinite(pix_x.detach()) & torch.isfinite(pix_y.detach())
         radius_f = torch.where(finite, radius_f, torch.zeros_like(radius_f))
         radius = radius_f.to(torch.int32)
@@ -298,6 +305,7 @@ def bin_and_sort(depth: torch.Tensor, rect: torch.Tensor, tiles_touched: torch.T
     starts_t = np.searchsorted(tile_sorted, np.arange(n_tiles), side="left")
     ends_t = np.searchsorted(tile_sorted, np.arange(n_tiles), side="right")
     ranges = np.stack([starts_t, ends_t], axis=1).astype(np.int32)
+    ranges[starts_t == ends_t] = 0                 # tiles with no instance keep the zero-filled range
     return dict(R=R, offsets=offsets.astype(np.int64), keys_unsorted=keys, keys=keys_sorted,
                 point_list=point_list, ranges=ranges)
 
@@ -306,8 +314,12 @@ ALPHA_MIN = float(F32(1.0) / F32(255.0))
 T_MIN = _f(0.0001)
 
 
-def blend(pre: dict, binning: dict, s: RasterSettings):
-    """Front-to-back compositing, vectorised over the 256 pixels of each tile."""
+def blend(pre: dict, binning: dict, s: RasterSettings, chunk: int = 512):
+    """Front-to-back compositing, vectorised over the 256 pixels of each tile.
+
+    The tile's depth-sorted list is consumed in chunks; a tile stops as soon as every pixel has
+    terminated (T(1-alpha) < 1e-4), exactly like the per-batch early exit of the kernels.  Within and
+    across chunks T is the plain sequential product T <- T*(1-alpha) (cumprod seeded with the carry)."""
     H, W = int(s.image_height), int(s.image_width)
     grid_x, grid_y = pre["grid"]
     E = pre["extra"].shape[1]
@@ -327,34 +339,41 @@ def blend(pre: dict, binning: dict, s: RasterSettings):
         tx0, ty0 = (t % grid_x) * BLOCK_X, (t // grid_x) * BLOCK_Y
         w_ = min(BLOCK_X, W - tx0)
         h_ = min(BLOCK_Y, H - ty0)
-        ids = point_list[a:b]
         ys, xs = torch.meshgrid(torch.arange(ty0, ty0 + h_), torch.arange(tx0, tx0 + w_), indexing="ij")
         pxf = xs.reshape(-1).to(dtype)
         pyf = ys.reshape(-1).to(dtype)
-        xy = pre["xy"][ids]
-        con = pre["conic"][ids]
-        op = pre["opacity"][ids]
-        dx = xy[:, 0:1] - pxf[None, :]
-        dy = xy[:, 1:2] - pyf[None, :]
-        power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
-        G = torch.exp(power)
-        raw = op[:, None] * G
-        alpha = raw - (raw - raw.clamp_max(_f(0.99))).detach()      # straight-through min(.99, .)
-        contrib = (power.detach() <= 0) & (alpha.detach() >= ALPHA_MIN)
-        a_eff = torch.where(contrib, alpha, torch.zeros_like(alpha))
-        one_minus = 1.0 - a_eff
-        T_incl = torch.cumprod(one_minus, dim=0)
-        T_excl = torch.cat([torch.ones_like(T_incl[:1]), T_incl[:-1]], dim=0)
-        keep = T_incl.detach() >= T_MIN            # prefix mask: False from the terminating Gaussian on
-        wgt = a_eff * T_excl * keep
-        acc = wgt.t() @ feat[ids]                  # [pixels, CH]
-        n_keep = keep.sum(0)
-        Tf = torch.where(n_keep > 0, T_incl.gather(0, (n_keep - 1).clamp_min(0)[None, :])[0],
-                         torch.ones_like(T_incl[0]))
-        idx1 = torch.arange(1, len(ids) + 1, dtype=torch.int32)[:, None]
-        nc = (idx1 * (contrib & keep)).max(0).values
-        pieces.append((ty0, tx0, h_, w_, acc, Tf, nc))
-    # assemble without in-place writes on a leaf (keeps autograd simple)
+        npix = pxf.numel()
+        T_cur = torch.ones(npix, dtype=dtype)
+        alive = torch.ones(npix, dtype=torch.bool)
+        acc = torch.zeros(npix, CH, dtype=dtype)
+        nc = torch.zeros(npix, dtype=torch.int32)
+        for c0 in range(a, b, chunk):
+            ids = point_list[c0:min(b, c0 + chunk)]
+            xy = pre["xy"][ids]
+            con = pre["conic"][ids]
+            op = pre["opacity"][ids]
+            dx = xy[:, 0:1] - pxf[None, :]
+            dy = xy[:, 1:2] - pyf[None, :]
+            power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
+            G = torch.exp(power)
+            raw = op[:, None] * G
+            alpha = raw - (raw - raw.clamp_max(_f(0.99))).detach()      # straight-through min(.99, .)
+            contrib = (power.detach() <= 0) & (alpha.detach() >= ALPHA_MIN)
+            a_eff = torch.where(contrib, alpha, torch.zeros_like(alpha))
+            one_minus = 1.0 - a_eff
+            T_all = torch.cumprod(torch.cat([T_cur[None, :], one_minus], dim=0), dim=0)
+            T_excl, T_incl = T_all[:-1], T_all[1:]
+            keep = alive[None, :] & (T_incl.detach() >= T_MIN)   # prefix mask per pixel
+            wgt = a_eff * T_excl * keep
+            acc = acc + wgt.t() @ feat[ids]
+            n_keep = keep.sum(0)
+            T_cur = torch.where(n_keep > 0, T_incl.gather(0, (n_keep - 1).clamp_min(0)[None, :])[0], T_cur)
+            idx1 = torch.arange(c0 - a + 1, c0 - a + len(ids) + 1, dtype=torch.int32)[:, None]
+            nc = torch.maximum(nc, (idx1 * (contrib & keep)).max(0).values)
+            alive = keep[-1]
+            if not bool(alive.any()):
+                break
+        pieces.append((ty0, tx0, h_, w_, acc, T_cur, nc))
     for (ty0, tx0, h_, w_, acc, Tf, nc) in pieces:
         out[:, ty0:ty0 + h_, tx0:tx0 + w_] = acc.t().reshape(CH, h_, w_)
         final_T[ty0:ty0 + h_, tx0:tx0 + w_] = Tf.reshape(h_, w_)

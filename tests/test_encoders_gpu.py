@@ -43,7 +43,10 @@ def test_grid_forward_backward(cfg):
     out = enc(xh, bound=1)
     out_ref, dy_dx_ref = ref.forward(x.numpy(), bound=1, calc_grad_inputs=True)
     assert out.shape == (5000, enc.output_dim)
-    assert float((out.detach().cpu() - torch.from_numpy(out_ref)).abs().max()) <= 2e-5
+    # O(1) random embeddings: one fp32 ulp of pos = x*scale+0.5 (FMA vs two roundings, exp2f ulp) is
+    # ~6e-8*resolution and neighbouring vertices differ by O(1..4) -> tolerance grows with the finest level
+    finest = cfg["desired_resolution"] if cfg["desired_resolution"] > cfg["base_resolution"] else cfg["base_resolution"]
+    assert float((out.detach().cpu() - torch.from_numpy(out_ref)).abs().max()) <= 1.5e-6 * finest
     w = torch.randn(out.shape, generator=g)
     (out * w.cuda()).sum().backward()
     L, C = cfg["num_levels"], cfg["level_dim"]
@@ -55,19 +58,22 @@ def test_grid_forward_backward(cfg):
     ge_h = enc.embeddings.grad.cpu().numpy()
     assert np.abs(ge_h - ge).max() <= 2e-4 * max(1.0, np.abs(ge).max())
     gi_h = xh.grad.cpu().numpy() * 2.0        # d/dx of (x+1)/2
-    assert np.abs(gi_h - gi).max() <= 2e-4 * max(1.0, np.abs(gi).max())
+    # dy_dx is piecewise constant per cell (and unrelated across cells of a hashed level): a point whose
+    # pos = x*scale+0.5 lands within an ulp of a cell border may pick the other cell -> allow rare outliers
+    rel = np.abs(gi_h - gi) / max(1.0, np.abs(gi).max())
+    assert np.quantile(rel, 0.995) <= 2e-4 and (rel > 2e-4).mean() < 5e-3
 
 
 def test_grid_known_answers():
     """Vertex value = embedding, bilinear midpoint = mean of 4 corners, out-of-range -> 0 (gridencoder.cu:111-191)."""
     from instag_amd.gridencoder import GridEncoder
-    enc = GridEncoder(input_dim=2, num_levels=1, level_dim=1, base_resolution=16, log2_hashmap_size=17,
-                      desired_resolution=16, align_corners=True).cuda()
+    enc = GridEncoder(input_dim=2, num_levels=2, level_dim=1, base_resolution=16, log2_hashmap_size=17,
+                      desired_resolution=32, align_corners=True).cuda()
     with torch.no_grad():
         enc.embeddings.copy_(torch.arange(enc.embeddings.numel(), dtype=torch.float32).view(-1, 1))
     # align_corners: scale = 15, resolution 16, stride 16: vertex (i, j) -> index i + 16 j
     v = torch.tensor([[3 / 15, 7 / 15], [3.5 / 15, 7.5 / 15], [1.5, 0.2], [-0.1, 0.5]]) * 2 - 1
-    out = enc(v.cuda(), bound=1).cpu().flatten()
+    out = enc(v.cuda(), bound=1).cpu()[:, 0]          # level 0
     assert abs(out[0].item() - (3 + 16 * 7)) < 1e-3
     assert abs(out[1].item() - np.mean([3 + 16 * 7, 4 + 16 * 7, 3 + 16 * 8, 4 + 16 * 8])) < 1e-3
     assert out[2].item() == 0.0 and out[3].item() == 0.0

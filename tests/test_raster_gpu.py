@@ -48,11 +48,6 @@ def run_hip(a, settings, use_sh=True, use_cov=False):
     return outs, inp
 
 
-def state_of(outs):
-    from instag_amd.diff_gauss import debug_export
-    return debug_export(outs[0].grad_fn.state if hasattr(outs[0].grad_fn, "state") else None)
-
-
 CASES = [
     pytest.param(2000, 128, 1, id="C1-2k-128"),
     pytest.param(6000, 200, 3, id="6k-200-sh3-ragged"),
@@ -158,7 +153,7 @@ def test_edge_cases():
         rotations=inp["rotations"], extra_attrs=inp["extra"])
     assert int(radii.sum()) == 0
     assert torch.allclose(img, s.bg[:, None, None].expand_as(img))
-    assert float(alpha.abs().max()) == 0.0
+    assert float(alpha.detach().abs().max()) == 0.0
     img.sum().backward()
     assert float(inp["means3D"].grad.abs().max()) == 0.0
     # argument validation mirrors the published rasterizer
