@@ -11,6 +11,8 @@ CUDA extensions are never imported (SURVEY.md §0 hazard).  The SH-encoder
 vectors are obtained by reading shencoder/src/shencoder.cu as text and
 evaluating its polynomial table numerically (fp32) on seeded inputs.
 """
+import sys
+sys.dont_write_bytecode = True   # never write __pycache__ into the read-only reference tree
 import importlib.util
 import json
 import os
@@ -132,10 +134,45 @@ def sh_encoder_table():
     np.savez(f"{HERE}/g6_sh_encoder.npz", **res)
 
 
+def motion_nets():
+    """G5: the reference's UMF / PMF forward on CPU with the oracle grid encoder injected as `gridencoder`."""
+    import types
+    from argparse import Namespace
+    sys.path.insert(0, ROOT)
+    from oracle import grid_torch
+    fake = types.ModuleType("gridencoder")
+    fake.GridEncoder = grid_torch.GridEncoder
+    sys.modules["gridencoder"] = fake
+    sys.path.insert(0, REF)
+    mn = _load(f"{REF}/scene/motion_net.py", "ref_motion_net")
+    sys.path.remove(REF)
+    torch.manual_seed(21)
+    res = {}
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(256, 3, generator=g) * 0.2 - 0.1
+    a = torch.randn(8, 29, 16, generator=g)
+    e = torch.rand(6, generator=g)
+    res.update(x=x.numpy(), a=a.numpy(), e=e.numpy())
+    for tag, cls in (("umf", mn.MotionNetwork), ("pmf", mn.PersonalizedMotionNetwork)):
+        net = cls(args=Namespace(audio_extractor="deepspeech", type="face"))
+        with torch.no_grad():
+            for n_, p_ in net.named_parameters():
+                if n_.endswith("embeddings"):
+                    p_.copy_(torch.randn(p_.shape, generator=g) * 0.1)
+        out = net(x, a, e)
+        for k_, v_ in net.state_dict().items():
+            res[f"{tag}.sd.{k_}"] = v_.numpy()
+        for k_, v_ in out.items():
+            if v_ is not None:
+                res[f"{tag}.out.{k_}"] = v_.detach().numpy()
+    np.savez_compressed(f"{HERE}/g5_motion_nets.npz", **res)
+
+
 if __name__ == "__main__":
     cameras()
     eval_sh()
     losses()
     lr_schedule()
     sh_encoder_table()
+    motion_nets()
     print("golden fixtures written to", HERE)

@@ -1,0 +1,57 @@
+"""CPU: the C-ABI shared library builds / loads and exports every symbol include/instag_hip.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "instag_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(instag_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from instag_amd import _lib
+    lib = _lib.lib()                       # builds with hipcc if missing; raises loudly otherwise
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/instag_hip.h but not exported"
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
+    assert lib.instag_abi_version() == 1
+    assert lib.instag_last_error() is not None
+
+
+def test_struct_layout_matches_header():
+    from instag_amd._lib import RasterArgs
+    # 11 x 4-byte scalars (44 B) padded to 48, then 12 pointers
+    assert ctypes.sizeof(RasterArgs) == 48 + 12 * 8
+    assert RasterArgs.bg.offset == 48 and RasterArgs.extra_attrs.offset == 48 + 11 * 8
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    from instag_amd import _lib
+    lib = _lib.lib()
+    # NULL tensors / unsupported dimensions are rejected before any device work
+    rc = lib.instag_sh_encode_forward(None, None, 4, 3, 4, None, None)
+    assert rc != 0 and b"NULL" in lib.instag_last_error()
+    one = ctypes.c_void_p(16)
+    rc = lib.instag_sh_encode_forward(one, one, 4, 2, 4, None, None)
+    assert rc != 0 and b"input dim == 3" in lib.instag_last_error()
+    rc = lib.instag_grid_encode_forward(one, one, one, one, 4, 7, 1, 2, 0.5, 16, None, 0, 0, 0, None)
+    assert rc != 0 and b"D must be" in lib.instag_last_error()
+
+
+def test_drop_in_package_names_import():
+    import diff_gauss
+    import gridencoder
+    import shencoder
+    assert diff_gauss.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+    enc = gridencoder.GridEncoder(input_dim=2, num_levels=12, level_dim=1, base_resolution=16,
+                                  log2_hashmap_size=17, desired_resolution=38.4)
+    assert enc.output_dim == 12 and tuple(enc.embeddings.shape) == (9464, 1)
+    assert shencoder.SHEncoder(3, 4).output_dim == 16
