@@ -24,7 +24,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 KERNEL_IDS = {"preprocess": 0, "duplicate": 1, "sort": 2, "ranges": 3, "blend_fwd": 4, "blend_bwd": 5,
-              "preprocess_bwd": 6, "grid_fwd": 7, "grid_bwd": 8}
+              "preprocess_bwd": 6, "grid_fwd": 7, "grid_bwd": 8, "mlp_fwd": 11, "mlp_bwd": 12, "mlp_wgrad": 13}
+NON_RASTER = ("grid_fwd", "grid_bwd", "mlp_fwd", "mlp_bwd", "mlp_wgrad")
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -40,7 +41,7 @@ def algorithmic_bytes(kernel, N, M, R, P, grid_points=0):
         "preprocess_bwd": 64 * R + N * (128 + 24 * M),
         "grid_fwd": grid_points * 152,
         "grid_bwd": grid_points * 152,
-    }[kernel]
+    }.get(kernel, 0)
 
 
 def cpu_baseline(n_gaussians, size, sh_degree, budget_s=30.0):
@@ -158,7 +159,7 @@ def main():
         R = int(diff_gauss.LAST_STATS.get("num_rendered", 0))
         P = size * size
         M = (args.sh_degree + 1) ** 2
-        raster_kernels = [k for k in kern if k not in ("grid_fwd", "grid_bwd")]
+        raster_kernels = [k for k in kern if k not in NON_RASTER]
         dom = max(raster_kernels, key=lambda k: kern[k]["total_ms"]) if raster_kernels else None
         roofline = None
         if dom:
@@ -182,7 +183,7 @@ def main():
             "roofline": roofline,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "raster_fwd_bwd_ms_per_frame": round(sum(v["total_ms"] for k, v in kern.items()
-                                                     if k not in ("grid_fwd", "grid_bwd")) / args.steps, 4),
+                                                     if k not in NON_RASTER) / args.steps, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle baseline (bounded sample)")

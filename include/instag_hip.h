@@ -150,11 +150,36 @@ int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* 
                                instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Bias-free ReLU MLP over N rows on the f32 matrix cores (exact fp32).
+ * Replaces the per-Gaussian `MLP` modules of scene/motion_net.py:152-173 (sigma_net, aud_ch_att_net,
+ * eye_att_net, align_net; instantiated at :234-238 and :600-604), i.e. for NL layers
+ *     y = W_NL * relu(... relu(W_1 x))          W_l row-major [out_l, in_l] (torch.nn.Linear.weight)
+ * x [N,K0], hidden width H, y [N,O]; NL in {2,3}; K0 <= 96, H <= 64, O <= 32.
+ * forward optionally stores the post-ReLU hidden activations a1 [N,H] (and a2 [N,H] for NL==3) for
+ * backward (pass NULL for inference).  backward consumes dy [N,O] and writes the pre-activation
+ * gradients dz1 [N,H] (dz2 [N,H]) and, when dx != NULL, dx [N,K0]; the weight gradients are then
+ *     dW_1 = dz1^T x,  dW_2 = dz2^T a1 (NL==3) or dy^T a1 (NL==2),  dW_3 = dy^T a2
+ * each computed with instag_linear_weight_grad (dz [N,O], in [N,K] -> dw [O,K]; O <= 64, K <= 96;
+ * workspace of instag_linear_weight_grad_workspace_bytes; deterministic).
+ * ------------------------------------------------------------------------------------------ */
+int instag_mlp_forward(const float* x, const float* w1, const float* w2, const float* w3, float* y,
+                       float* a1, float* a2, int32_t N, int32_t K0, int32_t H, int32_t O, int32_t NL,
+                       instag_stream_t stream);
+int instag_mlp_backward(const float* dy, const float* a1, const float* a2, const float* w1,
+                        const float* w2, const float* w3, float* dz1, float* dz2, float* dx, int32_t N,
+                        int32_t K0, int32_t H, int32_t O, int32_t NL, instag_stream_t stream);
+size_t instag_linear_weight_grad_workspace_bytes(int32_t N, int32_t O, int32_t K);
+int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void* workspace,
+                              size_t workspace_bytes, int32_t N, int32_t O, int32_t K,
+                              instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing (bench.py roofline leg).  When enabled, the launcher brackets the named
  * kernel with hipEvents on the launch stream; instag_prof_read synchronises those events and
  * returns accumulated milliseconds and launch count since the last reset.
  * Kernel ids: 0 preprocess, 1 duplicate, 2 sort, 3 ranges, 4 blend_fwd, 5 blend_bwd,
- *             6 preprocess_bwd, 7 grid_fwd, 8 grid_bwd, 9 sh_fwd, 10 sh_bwd.
+ *             6 preprocess_bwd, 7 grid_fwd, 8 grid_bwd, 9 sh_fwd, 10 sh_bwd,
+ *             11 mlp_fwd, 12 mlp_bwd, 13 mlp_weight_grad.
  * ------------------------------------------------------------------------------------------ */
 #define INSTAG_PROF_KERNELS 16
 int instag_prof_enable(int kernel_mask_or_minus1);

@@ -58,6 +58,10 @@ _PROTOS = {
                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "instag_raster_debug_export": (C.c_int, [vp, sz, vp, sz, vp, sz, i32, i64, i32, i32,
                                              vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "instag_mlp_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "instag_linear_weight_grad_workspace_bytes": (sz, [i32, i32, i32]),
+    "instag_linear_weight_grad": (C.c_int, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "instag_prof_enable": (C.c_int, [C.c_int]),
     "instag_prof_reset": (C.c_int, []),
     "instag_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),

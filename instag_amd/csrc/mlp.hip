@@ -1,0 +1,458 @@
+// Bias-free ReLU MLP (2 or 3 layers) over N rows on the f32 matrix cores of gfx950.
+//
+// Replaces the per-Gaussian `MLP` chains of the reference's motion networks
+// (scene/motion_net.py:152-173, used at :234-238, :600-604: sigma_net 74->64->64->11 / 74->32->32->11,
+// aud_ch_att_net 36->32->32, eye_att_net 36->16->6, align_net 36->32->6), which the reference runs as
+// separate eager Linear/ReLU kernels with B = N Gaussians.
+//
+// MI355X design.  v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) computes the TRANSPOSED product
+// Z^T[o][row] = sum_k W[o][k] * X^T[k][row]: the 32 rows of a wave's tile sit on the lanes
+// (row = lane&31) and every lane keeps 16 features per 32-feature block in registers,
+//     block b, register r, half h = lane>>5   <->   feature 32b + (r&3) + 8(r>>2) + 4h.
+// The accumulator layout of one layer IS the B-operand layout of the next (register r of block b
+// feeds MFMA k-step (b, r) directly), so the whole chain -- forward and the backward-data chain
+// dX^T = W^T dZ^T -- runs in registers with no shuffles and no LDS round trip for activations.
+// Weights live in LDS row-major with an odd row stride: the forward A-operand read (lanes vary the
+// output row) and the backward A-operand read (lanes vary the input column) are both conflict-free.
+// Weight gradients dW[o][k] = sum_rows dZ[row][o] * In[row][k] reduce over rows = the MFMA k index,
+// with both operands read straight from global memory (one coalesced 128-B row segment per half
+// wave); per-wave partial tiles are combined in a fixed order (LDS, then a second pass), so the
+// result is bitwise reproducible.
+#include "common.hpp"
+
+namespace instag {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int MLP_BLOCK = 256;
+
+__device__ __forceinline__ constexpr int feat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- layout-L tile load / store (rows on lanes) -------------------------------------------------
+__device__ __forceinline__ void load_block(const float* __restrict__ X, size_t row, bool valid, int K, int b, int h,
+                                           f32x16& v) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f0 = 32 * b + 8 * q + 4 * h;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid && f0 < K) {
+      const float* p = X + row * (size_t)K + f0;
+      if ((K & 3) == 0) {
+        t = *reinterpret_cast<const float4*>(p);
+      } else if ((K & 1) == 0) {
+        const float2 a = *reinterpret_cast<const float2*>(p);
+        t.x = a.x; t.y = a.y;
+        if (f0 + 2 < K) { const float2 c = *reinterpret_cast<const float2*>(p + 2); t.z = c.x; t.w = c.y; }
+      } else {
+        t.x = p[0];
+        if (f0 + 1 < K) t.y = p[1];
+        if (f0 + 2 < K) t.z = p[2];
+        if (f0 + 3 < K) t.w = p[3];
+      }
+    }
+    v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+}
+
+__device__ __forceinline__ void store_block(float* __restrict__ Y, size_t row, bool valid, int K, int b, int h,
+                                            const f32x16& v) {
+  if (!valid) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int f0 = 32 * b + 8 * q + 4 * h;
+    if (f0 >= K) continue;
+    float* p = Y + row * (size_t)K + f0;
+    if ((K & 3) == 0) {
+      *reinterpret_cast<float4*>(p) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else if ((K & 1) == 0) {
+      *reinterpret_cast<float2*>(p) = make_float2(v[4 * q], v[4 * q + 1]);
+      if (f0 + 2 < K) *reinterpret_cast<float2*>(p + 2) = make_float2(v[4 * q + 2], v[4 * q + 3]);
+    } else {
+      p[0] = v[4 * q];
+      if (f0 + 1 < K) p[1] = v[4 * q + 1];
+      if (f0 + 2 < K) p[2] = v[4 * q + 2];
+      if (f0 + 3 < K) p[3] = v[4 * q + 3];
+    }
+  }
+}
+
+// ---- weights: global [O][K] row-major -> LDS [OP][KP+1], zero padded --------------------------------
+__device__ __forceinline__ void stage_weights(float* __restrict__ lds, const float* __restrict__ W, int O, int K,
+                                              int OP, int KP) {
+  const int KS = KP + 1;
+  for (int i = threadIdx.x; i < OP * KS; i += MLP_BLOCK) {
+    const int o = i / KS, k = i - o * KS;
+    lds[i] = (o < O && k < K) ? W[o * K + k] : 0.f;
+  }
+}
+
+// Z^T = W X^T for one layer: in[KB] (layout L) -> acc[OB] (layout L)
+template <int KB, int OB>
+__device__ __forceinline__ void layer_forward(const float* __restrict__ Wl, int K, const f32x16 (&in)[KB],
+                                              f32x16 (&acc)[OB], int l31, int h) {
+  constexpr int KS = KB * 32 + 1;
+#pragma unroll
+  for (int t = 0; t < OB; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+  for (int b = 0; b < KB; ++b) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (32 * b + feat(r, 0) < K) {   // wave-uniform: both halves' features are padding beyond K
+        const int k = 32 * b + feat(r, h);
+#pragma unroll
+        for (int t = 0; t < OB; ++t) {
+          const float a = Wl[(32 * t + l31) * KS + k];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[b][r], acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// dIn^T = W^T dZ^T for one layer: dz[OB] -> din[KB]
+template <int OB, int KB>
+__device__ __forceinline__ void layer_backward(const float* __restrict__ Wl, int O, const f32x16 (&dz)[OB],
+                                               f32x16 (&din)[KB], int l31, int h) {
+  constexpr int KS = KB * 32 + 1;
+#pragma unroll
+  for (int b = 0; b < KB; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) din[b][i] = 0.f;
+#pragma unroll
+  for (int t = 0; t < OB; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (32 * t + feat(r, 0) < O) {
+        const int o = 32 * t + feat(r, h);
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+          const float a = Wl[o * KS + 32 * b + l31];
+          din[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, dz[t][r], din[b], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void relu_blocks(f32x16 (&v)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[b][i] = fmaxf(v[b][i], 0.f);
+}
+
+template <int NB>
+__device__ __forceinline__ void mask_blocks(f32x16 (&g)[NB], const f32x16 (&act)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[b][i] = act[b][i] > 0.f ? g[b][i] : 0.f;
+}
+
+struct MlpDims { int N, K0, H, O; };
+
+template <int KB0, int HB, int NL>
+__global__ void __launch_bounds__(MLP_BLOCK)
+mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restrict__ W1,
+                   const float* __restrict__ W2, const float* __restrict__ W3, float* __restrict__ Y,
+                   float* __restrict__ A1, float* __restrict__ A2) {
+  extern __shared__ __align__(16) float s_w[];
+  constexpr int KP0 = KB0 * 32, HP = HB * 32;
+  float* w1 = s_w;                                    // [HP][KP0+1]
+  float* w2 = w1 + HP * (KP0 + 1);                    // [NL==3 ? HP : 32][HP+1]
+  float* w3 = w2 + (NL == 3 ? HP : 32) * (HP + 1);    // [32][HP+1]  (NL==3 only)
+  stage_weights(w1, W1, d.H, d.K0, HP, KP0);
+  stage_weights(w2, W2, NL == 3 ? d.H : d.O, d.H, NL == 3 ? HP : 32, HP);
+  if (NL == 3) stage_weights(w3, W3, d.O, d.H, 32, HP);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int ntiles = (d.N + 31) / 32;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const size_t row = (size_t)tile * 32 + l31;
+    const bool valid = row < (size_t)d.N;
+    f32x16 in0[KB0];
+#pragma unroll
+    for (int b = 0; b < KB0; ++b) load_block(X, row, valid, d.K0, b, h, in0[b]);
+    f32x16 h1[HB];
+    layer_forward<KB0, HB>(w1, d.K0, in0, h1, l31, h);
+    relu_blocks<HB>(h1);
+    if (A1) {
+#pragma unroll
+      for (int b = 0; b < HB; ++b) store_block(A1, row, valid, d.H, b, h, h1[b]);
+    }
+    f32x16 out[1];
+    if (NL == 3) {
+      f32x16 h2[HB];
+      layer_forward<HB, HB>(w2, d.H, h1, h2, l31, h);
+      relu_blocks<HB>(h2);
+      if (A2) {
+#pragma unroll
+        for (int b = 0; b < HB; ++b) store_block(A2, row, valid, d.H, b, h, h2[b]);
+      }
+      layer_forward<HB, 1>(w3, d.H, h2, out, l31, h);
+    } else {
+      layer_forward<HB, 1>(w2, d.H, h1, out, l31, h);
+    }
+    store_block(Y, row, valid, d.O, 0, h, out[0]);
+  }
+}
+
+template <int KB0, int HB, int NL>
+__global__ void __launch_bounds__(MLP_BLOCK)
+mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __restrict__ A1,
+                    const float* __restrict__ A2, const float* __restrict__ W1, const float* __restrict__ W2,
+                    const float* __restrict__ W3, float* __restrict__ dZ1, float* __restrict__ dZ2,
+                    float* __restrict__ dX) {
+  extern __shared__ __align__(16) float s_w[];
+  constexpr int KP0 = KB0 * 32, HP = HB * 32;
+  float* w1 = s_w;
+  float* w2 = w1 + HP * (KP0 + 1);
+  float* w3 = w2 + (NL == 3 ? HP : 32) * (HP + 1);
+  if (dX) stage_weights(w1, W1, d.H, d.K0, HP, KP0);
+  stage_weights(w2, W2, NL == 3 ? d.H : d.O, d.H, NL == 3 ? HP : 32, HP);
+  if (NL == 3) stage_weights(w3, W3, d.O, d.H, 32, HP);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int ntiles = (d.N + 31) / 32;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const size_t row = (size_t)tile * 32 + l31;
+    const bool valid = row < (size_t)d.N;
+    f32x16 dy[1];
+    load_block(dY, row, valid, d.O, 0, h, dy[0]);
+    f32x16 g1[HB];
+    if (NL == 3) {
+      f32x16 g2[HB], act[HB];
+      layer_backward<1, HB>(w3, d.O, dy, g2, l31, h);
+#pragma unroll
+      for (int b = 0; b < HB; ++b) load_block(A2, row, valid, d.H, b, h, act[b]);
+      mask_blocks<HB>(g2, act);
+#pragma unroll
+      for (int b = 0; b < HB; ++b) store_block(dZ2, row, valid, d.H, b, h, g2[b]);
+      layer_backward<HB, HB>(w2, d.H, g2, g1, l31, h);
+    } else {
+      layer_backward<1, HB>(w2, d.O, dy, g1, l31, h);
+    }
+    {
+      f32x16 act[HB];
+#pragma unroll
+      for (int b = 0; b < HB; ++b) load_block(A1, row, valid, d.H, b, h, act[b]);
+      mask_blocks<HB>(g1, act);
+    }
+#pragma unroll
+    for (int b = 0; b < HB; ++b) store_block(dZ1, row, valid, d.H, b, h, g1[b]);
+    if (dX) {
+      f32x16 gx[KB0];
+      layer_backward<HB, KB0>(w1, d.H, g1, gx, l31, h);
+#pragma unroll
+      for (int b = 0; b < KB0; ++b) store_block(dX, row, valid, d.K0, b, h, gx[b]);
+    }
+  }
+}
+
+// ---- dW[o][k] = sum_rows dZ[row][o] * In[row][k] ---------------------------------------------------
+template <int OB, int KB>
+__global__ void __launch_bounds__(MLP_BLOCK)
+weight_grad_kernel(const float* __restrict__ dZ, const float* __restrict__ In, int N, int O, int K,
+                   float* __restrict__ partial) {
+  __shared__ float s_acc[OB * KB * 1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int nwaves = gridDim.x * 4;
+  const int per_wave = (((N + nwaves - 1) / nwaves) + 1) & ~1;       // even number of rows per wave
+  const int gw = blockIdx.x * 4 + wave;
+  const long w0 = (long)gw * per_wave;
+  const long w1 = min((long)N, w0 + per_wave);
+  f32x16 acc[OB][KB];
+#pragma unroll
+  for (int t = 0; t < OB; ++t)
+#pragma unroll
+    for (int b = 0; b < KB; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][b][i] = 0.f;
+  bool oin[OB], kin[KB];
+#pragma unroll
+  for (int t = 0; t < OB; ++t) oin[t] = 32 * t + l31 < O;
+#pragma unroll
+  for (int b = 0; b < KB; ++b) kin[b] = 32 * b + l31 < K;
+  constexpr int UNROLL = 4;
+  for (long r0 = w0; r0 < w1; r0 += 2 * UNROLL) {
+    float a[UNROLL][OB], bb[UNROLL][KB];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long row = r0 + 2 * u + h;
+      const bool ok = row < w1;
+#pragma unroll
+      for (int t = 0; t < OB; ++t) a[u][t] = (ok && oin[t]) ? dZ[row * O + 32 * t + l31] : 0.f;
+#pragma unroll
+      for (int b = 0; b < KB; ++b) bb[u][b] = (ok && kin[b]) ? In[row * K + 32 * b + l31] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int t = 0; t < OB; ++t)
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+          acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], bb[u][b], acc[t][b], 0, 0, 0);
+  }
+  // combine the 4 waves in a fixed order
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < OB; ++t)
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float* p = &s_acc[((t * KB + b) * 16 + i) * 64 + lane];
+            *p = (w == 0) ? acc[t][b][i] : (*p + acc[t][b][i]);
+          }
+    }
+    __syncthreads();
+  }
+  // partial[block][o][k] for o < O, k < K
+  float* dst = partial + (size_t)blockIdx.x * O * K;
+  for (int idx = threadIdx.x; idx < OB * KB * 1024; idx += MLP_BLOCK) {
+    const int ln = idx & 63, i = (idx >> 6) & 15, tb = idx >> 10;
+    const int t = tb / KB, b = tb - t * KB;
+    const int o = 32 * t + feat(i, ln >> 5), k = 32 * b + (ln & 31);
+    if (o < O && k < K) dst[o * K + k] = s_acc[idx];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+weight_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int count, float* __restrict__ dW) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * count + i];
+  dW[i] = s;
+}
+
+inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256)); }
+
+template <int KB0, int HB, int NL>
+size_t mlp_lds_bytes() {
+  constexpr int KP0 = KB0 * 32, HP = HB * 32;
+  return sizeof(float) * (HP * (KP0 + 1) + (NL == 3 ? HP : 32) * (HP + 1) + (NL == 3 ? 32 * (HP + 1) : 0));
+}
+
+template <int KB0, int HB, int NL>
+int run_fwd(const MlpDims& d, const float* x, const float* w1, const float* w2, const float* w3, float* y, float* a1,
+            float* a2, hipStream_t s) {
+  const int ntiles = (d.N + 31) / 32;
+  const int blocks = std::max(1, std::min(1024, (ntiles + 3) / 4));
+  ProfScope p(K_MLP_FWD, s);
+  mlp_forward_kernel<KB0, HB, NL><<<blocks, MLP_BLOCK, mlp_lds_bytes<KB0, HB, NL>(), s>>>(d, x, w1, w2, w3, y, a1, a2);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+template <int KB0, int HB, int NL>
+int run_bwd(const MlpDims& d, const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
+            const float* w3, float* dz1, float* dz2, float* dx, hipStream_t s) {
+  const int ntiles = (d.N + 31) / 32;
+  const int blocks = std::max(1, std::min(1024, (ntiles + 3) / 4));
+  ProfScope p(K_MLP_BWD, s);
+  mlp_backward_kernel<KB0, HB, NL><<<blocks, MLP_BLOCK, mlp_lds_bytes<KB0, HB, NL>(), s>>>(d, dy, a1, a2, w1, w2, w3,
+                                                                                        dz1, dz2, dx);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+template <int OB, int KB>
+int run_wg(const float* dz, const float* in, int N, int O, int K, float* partial, float* dw, hipStream_t s) {
+  const int blocks = wg_blocks(N);
+  ProfScope p(K_MLP_WGRAD, s);
+  weight_grad_kernel<OB, KB><<<blocks, MLP_BLOCK, 0, s>>>(dz, in, N, O, K, partial);
+  INSTAG_CHECK_LAUNCH();
+  weight_grad_reduce_kernel<<<(O * K + 255) / 256, 256, 0, s>>>(partial, blocks, O * K, dw);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+#define MLP_DISPATCH(FN, ...)                                                                      \
+  do {                                                                                             \
+    const int kb = (d.K0 + 31) / 32, hb = (d.H + 31) / 32;                                           \
+    if (NL == 2) {                                                                                 \
+      if (kb == 1 && hb == 1) return FN<1, 1, 2>(__VA_ARGS__);                                      \
+      if (kb == 2 && hb == 1) return FN<2, 1, 2>(__VA_ARGS__);                                      \
+      if (kb == 3 && hb == 1) return FN<3, 1, 2>(__VA_ARGS__);                                      \
+      if (kb == 1 && hb == 2) return FN<1, 2, 2>(__VA_ARGS__);                                      \
+      if (kb == 2 && hb == 2) return FN<2, 2, 2>(__VA_ARGS__);                                      \
+      if (kb == 3 && hb == 2) return FN<3, 2, 2>(__VA_ARGS__);                                      \
+    } else {                                                                                       \
+      if (kb == 1 && hb == 1) return FN<1, 1, 3>(__VA_ARGS__);                                      \
+      if (kb == 2 && hb == 1) return FN<2, 1, 3>(__VA_ARGS__);                                      \
+      if (kb == 3 && hb == 1) return FN<3, 1, 3>(__VA_ARGS__);                                      \
+      if (kb == 1 && hb == 2) return FN<1, 2, 3>(__VA_ARGS__);                                      \
+      if (kb == 2 && hb == 2) return FN<2, 2, 3>(__VA_ARGS__);                                      \
+      if (kb == 3 && hb == 2) return FN<3, 2, 3>(__VA_ARGS__);                                      \
+    }                                                                                              \
+  } while (0)
+
+int check_dims(int N, int K0, int H, int O, int NL) {
+  INSTAG_REQUIRE(N >= 0, "mlp: N must be >= 0");
+  INSTAG_REQUIRE(NL == 2 || NL == 3, "mlp: only 2- or 3-layer MLPs are supported");
+  INSTAG_REQUIRE(K0 >= 1 && K0 <= 96, "mlp: input width must be in [1,96]");
+  INSTAG_REQUIRE(H >= 1 && H <= 64, "mlp: hidden width must be in [1,64]");
+  INSTAG_REQUIRE(O >= 1 && O <= 32, "mlp: output width must be in [1,32]");
+  return INSTAG_OK;
+}
+
+}  // namespace
+}  // namespace instag
+
+using namespace instag;
+
+extern "C" {
+
+int instag_mlp_forward(const float* x, const float* w1, const float* w2, const float* w3, float* y, float* a1,
+                       float* a2, int32_t N, int32_t K0, int32_t H, int32_t O, int32_t NL, instag_stream_t stream) {
+  if (int e = check_dims(N, K0, H, O, NL)) return e;
+  INSTAG_REQUIRE(x && w1 && w2 && y && (NL == 2 || w3), "mlp_forward: NULL tensor");
+  if (N == 0) return INSTAG_OK;
+  const MlpDims d{N, K0, H, O};
+  hipStream_t s = (hipStream_t)stream;
+  MLP_DISPATCH(run_fwd, d, x, w1, w2, w3, y, a1, a2, s);
+  set_error("mlp_forward: unsupported shape");
+  return INSTAG_E_ARG;
+}
+
+int instag_mlp_backward(const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
+                        const float* w3, float* dz1, float* dz2, float* dx, int32_t N, int32_t K0, int32_t H,
+                        int32_t O, int32_t NL, instag_stream_t stream) {
+  if (int e = check_dims(N, K0, H, O, NL)) return e;
+  INSTAG_REQUIRE(dy && a1 && w1 && w2 && dz1 && (NL == 2 || (w3 && a2 && dz2)), "mlp_backward: NULL tensor");
+  if (N == 0) return INSTAG_OK;
+  const MlpDims d{N, K0, H, O};
+  hipStream_t s = (hipStream_t)stream;
+  MLP_DISPATCH(run_bwd, d, dy, a1, a2, w1, w2, w3, dz1, dz2, dx, s);
+  set_error("mlp_backward: unsupported shape");
+  return INSTAG_E_ARG;
+}
+
+size_t instag_linear_weight_grad_workspace_bytes(int32_t N, int32_t O, int32_t K) {
+  return (size_t)wg_blocks(N) * (size_t)O * (size_t)K * sizeof(float);
+}
+
+int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void* workspace, size_t workspace_bytes,
+                              int32_t N, int32_t O, int32_t K, instag_stream_t stream) {
+  INSTAG_REQUIRE(dz && in && dw, "linear_weight_grad: NULL tensor");
+  INSTAG_REQUIRE(O >= 1 && O <= 64 && K >= 1 && K <= 96, "linear_weight_grad: need O <= 64 and K <= 96");
+  INSTAG_REQUIRE(N >= 1, "linear_weight_grad: N must be >= 1");
+  if (workspace == nullptr || workspace_bytes < instag_linear_weight_grad_workspace_bytes(N, O, K)) {
+    set_error("linear_weight_grad: workspace too small");
+    return INSTAG_E_SPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  const int ob = (O + 31) / 32, kb = (K + 31) / 32;
+  if (ob == 1 && kb == 1) return run_wg<1, 1>(dz, in, N, O, K, part, dw, s);
+  if (ob == 1 && kb == 2) return run_wg<1, 2>(dz, in, N, O, K, part, dw, s);
+  if (ob == 1 && kb == 3) return run_wg<1, 3>(dz, in, N, O, K, part, dw, s);
+  if (ob == 2 && kb == 1) return run_wg<2, 1>(dz, in, N, O, K, part, dw, s);
+  if (ob == 2 && kb == 2) return run_wg<2, 2>(dz, in, N, O, K, part, dw, s);
+  return run_wg<2, 3>(dz, in, N, O, K, part, dw, s);
+}
+
+}  // extern "C"

@@ -5,8 +5,8 @@ Counterpart of /root/reference/scene/motion_net.py (same module / parameter name
   AudioAttNet :29-64, AudioNet :67-99, MLP :152-173,
   MotionNetwork (UMF) :176-345, PersonalizedMotionNetwork (PMF) :562-748.
 The tri-plane grid encoders are ``instag_amd.gridencoder.GridEncoder`` (HIP); ``encoder_cls`` lets
-the CPU tests inject the oracle encoder.  The per-Gaussian MLP chains are dense GEMMs with B = N
-rows (torch Linear -> hipBLASLt on the device).
+the CPU tests inject the oracle encoder.  The per-Gaussian MLP chains (B = N rows) run as fused
+f32-MFMA HIP kernels through ``instag_amd.mlp``.
 """
 from __future__ import annotations
 
@@ -74,6 +74,12 @@ class MLP(nn.Module):
             for l in range(num_layers)])
 
     def forward(self, x):
+        if x.is_cuda and x.dim() == 2:
+            # per-Gaussian matrix on the device: one fused f32-MFMA HIP kernel per pass (instag_amd/mlp.py)
+            from . import mlp as _mlp
+            if _mlp.supported(self.dim_in, self.dim_hidden, self.dim_out, self.num_layers):
+                return _mlp.fused_mlp(x, [layer.weight for layer in self.net])
+        # per-frame vectors (e.g. the 5-element expression code) and host-side tests: plain torch ops
         for l, layer in enumerate(self.net):
             x = layer(x)
             if l != self.num_layers - 1:

@@ -1,0 +1,98 @@
+"""GPU parity: fused f32-MFMA MLP operator vs a plain PyTorch fp64 reference, and the full motion
+networks (HIP grid encoders + HIP MLPs) vs the golden outputs of the reference's own modules (G5)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # (dim_in, hidden, dim_out, layers)  -- the MLPs of scene/motion_net.py:234-238,600-604
+    pytest.param(74, 64, 11, 3, id="umf-sigma"),
+    pytest.param(74, 32, 11, 3, id="pmf-sigma"),
+    pytest.param(36, 32, 32, 2, id="aud_ch_att"),
+    pytest.param(36, 16, 6, 2, id="eye_att"),
+    pytest.param(36, 32, 6, 2, id="align"),
+    pytest.param(96, 64, 32, 3, id="max-shape"),
+    pytest.param(5, 7, 3, 2, id="odd-shape"),
+]
+
+
+def _ref(x, ws):
+    h = x
+    for i, w in enumerate(ws):
+        h = h @ w.t()
+        if i != len(ws) - 1:
+            h = torch.relu(h)
+    return h
+
+
+@pytest.mark.parametrize("K0,H,O,NL", SHAPES)
+@pytest.mark.parametrize("N", [1, 4999, 65536])
+def test_fused_mlp_forward_backward(K0, H, O, NL, N):
+    from instag_amd.mlp import fused_mlp
+    g = torch.Generator().manual_seed(N + K0)
+    dims = [K0] + [H] * (NL - 1) + [O]
+    ws = [torch.randn(dims[i + 1], dims[i], generator=g) / np.sqrt(dims[i]) for i in range(NL)]
+    x = torch.randn(N, K0, generator=g)
+    gy = torch.randn(N, O, generator=g)
+    xd = x.double().requires_grad_(True)
+    wd = [w.double().requires_grad_(True) for w in ws]
+    yd = _ref(xd, wd)
+    (yd * gy.double()).sum().backward()
+    xh = x.cuda().requires_grad_(True)
+    wh = [w.cuda().requires_grad_(True) for w in ws]
+    yh = fused_mlp(xh, wh)
+    assert yh.shape == (N, O)
+    (yh * gy.cuda()).sum().backward()
+
+    def close(a, b, name, tol=2e-5, outliers=0.0):
+        a, b = a.detach().cpu().double(), b.detach()
+        err = (a - b).abs()
+        bad = err > tol * max(1.0, float(b.abs().max()))
+        assert float(bad.double().mean()) <= outliers, \
+            f"{name}: max err {float(err.max())} scale {float(b.abs().max())} bad {int(bad.sum())}"
+    close(yh, yd, "y")
+    # a hidden unit whose pre-activation is within fp32 rounding of 0 may take the other ReLU branch than the
+    # fp64 reference; that changes dx of its row by O(|w|): tolerate a few rows in a million
+    close(xh.grad, xd.grad, "dx", outliers=2e-5)
+    for i in range(NL):
+        close(wh[i].grad, wd[i].grad, f"dW{i + 1}", tol=2e-5 * max(1.0, np.sqrt(N) / 16))
+
+
+def test_fused_mlp_deterministic_and_no_input_grad():
+    from instag_amd.mlp import fused_mlp
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.randn(64, 74, generator=g).cuda().requires_grad_(True),
+          torch.randn(64, 64, generator=g).cuda().requires_grad_(True),
+          torch.randn(11, 64, generator=g).cuda().requires_grad_(True)]
+    x = torch.randn(30000, 74, generator=g).cuda()          # no grad for x -> dx is skipped
+    outs = []
+    for _ in range(2):
+        for w in ws:
+            w.grad = None
+        fused_mlp(x, ws).square().sum().backward()
+        outs.append([w.grad.clone() for w in ws])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_motion_networks_on_gpu_match_reference_golden(golden_dir):
+    """UMF / PMF with HIP grid encoders + HIP MLPs == outputs of the reference's modules (CPU, fixture G5)."""
+    from argparse import Namespace
+    from instag_amd.motion_net import MotionNetwork, PersonalizedMotionNetwork
+    g = np.load(f"{golden_dir}/g5_motion_nets.npz")
+    x, a, e = (torch.from_numpy(g[k]).cuda() for k in ("x", "a", "e"))
+    args = Namespace(audio_extractor="deepspeech", type="face")
+    for tag, cls in (("umf", MotionNetwork), ("pmf", PersonalizedMotionNetwork)):
+        net = cls(args=args).cuda()
+        sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}.sd.")}
+        net.load_state_dict(sd, strict=True)
+        out = net(x.clone().requires_grad_(True), a, e)
+        for k in [k[len(tag) + 5:] for k in g.files if k.startswith(f"{tag}.out.")]:
+            ref = torch.from_numpy(g[f"{tag}.out.{k}"])
+            err = float((out[k].detach().cpu() - ref).abs().max())
+            assert err <= 2e-6 + 2e-5 * float(ref.abs().max()), (tag, k, err)
+        loss = sum(v.square().sum() for v in out.values() if v is not None)
+        loss.backward()
+        assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+        assert net.encoder_xy.embeddings.grad is not None and net.sigma_net.net[0].weight.grad is not None
