@@ -174,12 +174,27 @@ int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void*
                               instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused L1 + SSIM image loss.  Replaces utils/loss_utils.py l1_loss :26-27 and ssim :42-72 (11x11
+ * Gaussian window sigma 1.5, zero padding, C1=0.01^2, C2=0.03^2, mean over C*H*W) as used at
+ * train_face.py:450-456.  img1/img2 [C,H,W].  forward writes per-workgroup partial sums
+ * (instag_l1_ssim_num_partials of them each; l1 = sum(partial_l1)/(C*H*W), ssim likewise) and the
+ * derivative maps [3,C,H,W]; backward writes d(loss)/d(img1) given the upstream gradients of the two
+ * scalar means (device scalars, NULL = 0).
+ * ------------------------------------------------------------------------------------------ */
+int instag_l1_ssim_num_partials(int32_t C, int32_t H, int32_t W);
+int instag_l1_ssim_forward(const float* img1, const float* img2, int32_t C, int32_t H, int32_t W,
+                           float* maps, float* partial_ssim, float* partial_l1, instag_stream_t stream);
+int instag_l1_ssim_backward(const float* img1, const float* img2, const float* maps, const float* g_ssim,
+                            const float* g_l1, int32_t C, int32_t H, int32_t W, float* dimg1,
+                            instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing (bench.py roofline leg).  When enabled, the launcher brackets the named
  * kernel with hipEvents on the launch stream; instag_prof_read synchronises those events and
  * returns accumulated milliseconds and launch count since the last reset.
  * Kernel ids: 0 preprocess, 1 duplicate, 2 sort, 3 ranges, 4 blend_fwd, 5 blend_bwd,
  *             6 preprocess_bwd, 7 grid_fwd, 8 grid_bwd, 9 sh_fwd, 10 sh_bwd,
- *             11 mlp_fwd, 12 mlp_bwd, 13 mlp_weight_grad.
+ *             11 mlp_fwd, 12 mlp_bwd, 13 mlp_weight_grad, 14 loss_fwd, 15 loss_bwd.
  * ------------------------------------------------------------------------------------------ */
 #define INSTAG_PROF_KERNELS 16
 int instag_prof_enable(int kernel_mask_or_minus1);

@@ -62,6 +62,9 @@ _PROTOS = {
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_linear_weight_grad_workspace_bytes": (sz, [i32, i32, i32]),
     "instag_linear_weight_grad": (C.c_int, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "instag_l1_ssim_num_partials": (C.c_int, [i32, i32, i32]),
+    "instag_l1_ssim_forward": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "instag_l1_ssim_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "instag_prof_enable": (C.c_int, [C.c_int]),
     "instag_prof_reset": (C.c_int, []),
     "instag_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -36,6 +36,7 @@ SOURCES = {
     "grid.hip": [],
     "sh.hip": [],
     "mlp.hip": [],
+    "ssim.hip": [],
 }
 
 

@@ -321,16 +321,25 @@ weight_grad_kernel(const float* __restrict__ dZ, const float* __restrict__ In, i
   }
 }
 
+// dW[i] = sum_p partial[p][i]: 64 elements x 4 partial-groups per workgroup, fixed summation order
 __global__ void __launch_bounds__(256)
 weight_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int count, float* __restrict__ dW) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
+  __shared__ float s_part[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * count + i];
-  dW[i] = s;
+  if (i < count) {
+    const int per = (nparts + 3) / 4;
+    const int p0 = g * per, p1 = min(nparts, p0 + per);
+#pragma unroll 8
+    for (int p = p0; p < p1; ++p) s += partial[(size_t)p * count + i];
+  }
+  s_part[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < count) dW[i] = ((s_part[0][e] + s_part[1][e]) + s_part[2][e]) + s_part[3][e];
 }
 
-inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256)); }
+inline int wg_blocks(int N) { return std::max(1, std::min(128, (N + 511) / 512)); }
 
 template <int KB0, int HB, int NL>
 size_t mlp_lds_bytes() {
@@ -365,7 +374,7 @@ int run_wg(const float* dz, const float* in, int N, int O, int K, float* partial
   ProfScope p(K_MLP_WGRAD, s);
   weight_grad_kernel<OB, KB><<<blocks, MLP_BLOCK, 0, s>>>(dz, in, N, O, K, partial);
   INSTAG_CHECK_LAUNCH();
-  weight_grad_reduce_kernel<<<(O * K + 255) / 256, 256, 0, s>>>(partial, blocks, O * K, dw);
+  weight_grad_reduce_kernel<<<(O * K + 63) / 64, 256, 0, s>>>(partial, blocks, O * K, dw);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -1,0 +1,188 @@
+// Fused L1 + SSIM image loss (forward and backward) for gfx950.
+//
+// Replaces the eager chain of the reference's loss block: utils/loss_utils.py l1_loss :26-27 and
+// ssim :42-72 (five 11x11 depthwise Gaussian convolutions, sigma 1.5, zero padding, C1=0.01^2,
+// C2=0.03^2, mean over all pixels), used at train_face.py:450-456.  One workgroup filters one 16x16
+// tile of one channel: the 26x26 halo of both images is staged in LDS once, the separable filter runs
+// as a horizontal pass into LDS and a vertical pass in registers, the SSIM map is reduced per
+// workgroup (fixed order -> deterministic partial sums, final sum by the caller).  Forward also stores
+// the three derivative maps dS/dmu1, dS/dE[x^2], dS/dE[xy]; backward filters them with the same
+// (symmetric) window and adds the L1 sign term, so the whole loss gradient is ONE kernel.
+#include "common.hpp"
+
+namespace instag {
+namespace {
+
+constexpr int TS = 16;            // tile side
+constexpr int RAD = 5;            // 11 taps
+constexpr int HS = TS + 2 * RAD;  // 26
+constexpr float C1 = 0.01f * 0.01f;
+constexpr float C2 = 0.03f * 0.03f;
+
+// normalised 1-D Gaussian window, size 11, sigma 1.5 (loss_utils.py:33-35)
+__device__ constexpr float GW[11] = {0.0010283801f, 0.0075987581f, 0.0360007721f, 0.1093606895f, 0.2130055377f,
+                                     0.2660117249f, 0.2130055377f, 0.1093606895f, 0.0360007721f, 0.0075987581f,
+                                     0.0010283801f};
+
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_red[wave] = v;
+  __syncthreads();
+  return ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+}
+
+__global__ void __launch_bounds__(256)
+l1_ssim_forward_kernel(const float* __restrict__ img1, const float* __restrict__ img2, int H, int W,
+                       float* __restrict__ maps, float* __restrict__ part_ssim, float* __restrict__ part_l1) {
+  __shared__ float s_x[HS][HS + 1], s_y[HS][HS + 1];
+  __shared__ float s_h[5][HS][TS + 1];
+  __shared__ float s_red[4];
+  const int c = blockIdx.z;
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+  const size_t plane = (size_t)H * W;
+  const float* p1 = img1 + c * plane;
+  const float* p2 = img2 + c * plane;
+  for (int i = threadIdx.x; i < HS * HS; i += 256) {
+    const int ly = i / HS, lx = i - ly * HS;
+    const int gy = y0 + ly - RAD, gx = x0 + lx - RAD;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    s_x[ly][lx] = in ? p1[(size_t)gy * W + gx] : 0.f;
+    s_y[ly][lx] = in ? p2[(size_t)gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  // horizontal pass: HS rows x TS columns x 5 quantities
+  for (int i = threadIdx.x; i < HS * TS; i += 256) {
+    const int ly = i / TS, lx = i - ly * TS;
+    float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float xv = s_x[ly][lx + k], yv = s_y[ly][lx + k], w = GW[k];
+      a += w * xv; b += w * yv; aa += w * xv * xv; bb += w * yv * yv; ab += w * xv * yv;
+    }
+    s_h[0][ly][lx] = a; s_h[1][ly][lx] = b; s_h[2][ly][lx] = aa; s_h[3][ly][lx] = bb; s_h[4][ly][lx] = ab;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int gx = x0 + tx, gy = y0 + ty;
+  const bool inside = gx < W && gy < H;
+  float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = GW[k];
+    mu1 += w * s_h[0][ty + k][tx]; mu2 += w * s_h[1][ty + k][tx];
+    e11 += w * s_h[2][ty + k][tx]; e22 += w * s_h[3][ty + k][tx]; e12 += w * s_h[4][ty + k][tx];
+  }
+  float ssim_v = 0.f, l1_v = 0.f;
+  if (inside) {
+    const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s11 = e11 - mu1s, s22 = e22 - mu2s, s12 = e12 - mu12;
+    const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1s + mu2s + C1, B2 = s11 + s22 + C2;
+    const float inv = 1.f / (B1 * B2);
+    ssim_v = A1 * A2 * inv;
+    // derivatives w.r.t. (mu1 | E[x^2] | E[xy]) with s11 = E11 - mu1^2, s12 = E12 - mu1 mu2
+    const float dS_ds11 = -ssim_v / B2;
+    const float dS_ds12 = 2.f * A1 * inv;
+    const float dS_dmu1 = 2.f * mu2 * A2 * inv - 2.f * mu1 * ssim_v / B1 + dS_ds11 * (-2.f * mu1) + dS_ds12 * (-mu2);
+    const size_t pix = (size_t)gy * W + gx;
+    const size_t C3 = (size_t)gridDim.z * plane;
+    maps[c * plane + pix] = dS_dmu1;
+    maps[C3 + c * plane + pix] = dS_ds11;
+    maps[2 * C3 + c * plane + pix] = dS_ds12;
+    l1_v = fabsf(s_x[ty + RAD][tx + RAD] - s_y[ty + RAD][tx + RAD]);
+  }
+  const float bs = block_sum_256(ssim_v, s_red);
+  __syncthreads();
+  const float bl = block_sum_256(l1_v, s_red);
+  if (threadIdx.x == 0) {
+    const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    part_ssim[bid] = bs;
+    part_l1[bid] = bl;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+l1_ssim_backward_kernel(const float* __restrict__ img1, const float* __restrict__ img2,
+                        const float* __restrict__ maps, const float* __restrict__ g_ssim,
+                        const float* __restrict__ g_l1, int C, int H, int W, float* __restrict__ dimg1) {
+  __shared__ float s_m[3][HS][HS + 1];
+  __shared__ float s_h[3][HS][TS + 1];
+  const int c = blockIdx.z;
+  const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+  const size_t plane = (size_t)H * W;
+  const size_t C3 = (size_t)C * plane;
+  for (int i = threadIdx.x; i < HS * HS; i += 256) {
+    const int ly = i / HS, lx = i - ly * HS;
+    const int gy = y0 + ly - RAD, gx = x0 + lx - RAD;
+    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const size_t o = c * plane + (size_t)gy * W + gx;
+    s_m[0][ly][lx] = in ? maps[o] : 0.f;
+    s_m[1][ly][lx] = in ? maps[C3 + o] : 0.f;
+    s_m[2][ly][lx] = in ? maps[2 * C3 + o] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < HS * TS; i += 256) {
+    const int ly = i / TS, lx = i - ly * TS;
+    float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = GW[k];
+      a += w * s_m[0][ly][lx + k]; b += w * s_m[1][ly][lx + k]; d += w * s_m[2][ly][lx + k];
+    }
+    s_h[0][ly][lx] = a; s_h[1][ly][lx] = b; s_h[2][ly][lx] = d;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int gx = x0 + tx, gy = y0 + ty;
+  if (gx >= W || gy >= H) return;
+  float fm = 0.f, f11 = 0.f, f12 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = GW[k];
+    fm += w * s_h[0][ty + k][tx]; f11 += w * s_h[1][ty + k][tx]; f12 += w * s_h[2][ty + k][tx];
+  }
+  const size_t pix = c * plane + (size_t)gy * W + gx;
+  const float x = img1[pix], y = img2[pix];
+  const float inv_n = 1.f / (float)C3;
+  const float gs = g_ssim ? g_ssim[0] : 0.f, gl = g_l1 ? g_l1[0] : 0.f;
+  const float diff = x - y;
+  const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+  dimg1[pix] = inv_n * (gs * (fm + 2.f * x * f11 + y * f12) + gl * sgn);
+}
+
+}  // namespace
+}  // namespace instag
+
+using namespace instag;
+
+extern "C" {
+
+int instag_l1_ssim_num_partials(int32_t C, int32_t H, int32_t W) {
+  return C * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
+}
+
+int instag_l1_ssim_forward(const float* img1, const float* img2, int32_t C, int32_t H, int32_t W, float* maps,
+                           float* partial_ssim, float* partial_l1, instag_stream_t stream) {
+  INSTAG_REQUIRE(img1 && img2 && maps && partial_ssim && partial_l1, "l1_ssim_forward: NULL tensor");
+  INSTAG_REQUIRE(C >= 1 && C <= 65535 && H >= 1 && W >= 1, "l1_ssim_forward: bad shape");
+  dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
+  ProfScope p(K_LOSS_FWD, (hipStream_t)stream);
+  l1_ssim_forward_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(img1, img2, H, W, maps, partial_ssim, partial_l1);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_l1_ssim_backward(const float* img1, const float* img2, const float* maps, const float* g_ssim,
+                            const float* g_l1, int32_t C, int32_t H, int32_t W, float* dimg1,
+                            instag_stream_t stream) {
+  INSTAG_REQUIRE(img1 && img2 && maps && dimg1, "l1_ssim_backward: NULL tensor");
+  INSTAG_REQUIRE(C >= 1 && C <= 65535 && H >= 1 && W >= 1, "l1_ssim_backward: bad shape");
+  dim3 grid((W + TS - 1) / TS, (H + TS - 1) / TS, C);
+  ProfScope p(K_LOSS_BWD, (hipStream_t)stream);
+  l1_ssim_backward_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(img1, img2, maps, g_ssim, g_l1, C, H, W, dimg1);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+}  // extern "C"

@@ -55,3 +55,44 @@ def ssim(img1, img2, window_size=11, size_average=True):
 def psnr(img1, img2):
     mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
     return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+class _FusedL1SSIM(torch.autograd.Function):
+    """(l1_mean, ssim_mean) of two [C,H,W] images in one HIP kernel each way (csrc/ssim.hip)."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        from . import _lib
+        from ._lib import check, ptr
+        L = _lib.lib()
+        a, b = img1.contiguous().float(), img2.contiguous().float()
+        C, H, W = a.shape
+        nb = L.instag_l1_ssim_num_partials(C, H, W)
+        maps = torch.empty(3, C, H, W, dtype=torch.float32, device=a.device)
+        parts = torch.empty(2, nb, dtype=torch.float32, device=a.device)
+        check(L.instag_l1_ssim_forward(ptr(a), ptr(b), C, H, W, ptr(maps), ptr(parts[0]), ptr(parts[1]),
+                                       _lib.current_stream()), "l1_ssim_forward")
+        sums = parts.sum(dim=1) / float(C * H * W)
+        ctx.save_for_backward(a, b, maps)
+        return sums[1], sums[0]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        from . import _lib
+        from ._lib import check, ptr
+        a, b, maps = ctx.saved_tensors
+        C, H, W = a.shape
+        g_l1 = g_l1.contiguous().float()
+        g_ssim = g_ssim.contiguous().float()
+        d = torch.empty_like(a)
+        check(_lib.lib().instag_l1_ssim_backward(ptr(a), ptr(b), ptr(maps), ptr(g_ssim), ptr(g_l1), C, H, W, ptr(d),
+                                                 _lib.current_stream()), "l1_ssim_backward")
+        return d, None
+
+
+def l1_and_ssim(img1, img2):
+    """Returns (l1_loss(img1, img2), ssim(img1, img2)); fused HIP kernels for [3,H,W] device images, the
+    torch formulation otherwise (host-side tests).  ``img2`` is treated as a constant."""
+    if img1.is_cuda and img1.dim() == 3:
+        return _FusedL1SSIM.apply(img1, img2.detach())
+    return l1_loss(img1, img2), ssim(img1, img2)

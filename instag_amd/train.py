@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 from .gaussian_model import GaussianModel, OptimizationParams
-from .losses import l1_loss, ssim
+from .losses import l1_and_ssim
 
 
 @dataclass
@@ -122,8 +122,8 @@ class FaceTrainer:
         gt = frame.original_image.to(dev)
         gt_white = gt * head_mask + self.bg[:, None, None] * ~head_mask
         gt_white = torch.where(mouth_mask[None], self.bg[:, None, None].expand_as(gt_white), gt_white)
-        Ll1 = l1_loss(image, gt_white)
-        loss = Ll1 + self.opt.lambda_dssim * (1.0 - ssim(image, gt_white))
+        Ll1, ssim_val = l1_and_ssim(image, gt_white)
+        loss = Ll1 + self.opt.lambda_dssim * (1.0 - ssim_val)
         if warm:
             m, pm = pkg["motion"], pkg["p_motion"]
             loss = loss + 1e-5 * (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()

@@ -130,3 +130,30 @@ def test_sh_encoder_shapes_and_errors():
         SHEncoder(3, 9)
     with pytest.raises(AssertionError):
         SHEncoder(2, 4)
+
+
+def test_fused_l1_ssim_matches_torch_and_golden(golden_dir):
+    from instag_amd import losses
+    g = np.load(f"{golden_dir}/g3_losses.npz")
+    a = torch.from_numpy(g["a"]).cuda().requires_grad_(True)
+    b = torch.from_numpy(g["b"]).cuda()
+    l1, s = losses.l1_and_ssim(a, b)
+    assert abs(float(l1) - float(g["l1"])) < 1e-6 and abs(float(s) - float(g["ssim"])) < 2e-6
+    (l1 + 0.2 * (1.0 - s)).backward()
+    a2 = torch.from_numpy(g["a"]).double().requires_grad_(True)
+    b2 = torch.from_numpy(g["b"]).double()
+    (losses.l1_loss(a2, b2) + 0.2 * (1.0 - losses.ssim(a2, b2))).backward()
+    assert float((a.grad.cpu().double() - a2.grad).abs().max()) <= 2e-5 * float(a2.grad.abs().max())
+    # ragged size (not a multiple of the 16x16 tile) and full 512x512
+    for shape in ((3, 75, 131), (3, 512, 512)):
+        gen = torch.Generator().manual_seed(shape[1])
+        x = torch.rand(shape, generator=gen)
+        y = (x + 0.2 * torch.randn(shape, generator=gen)).clamp(0, 1)
+        xh = x.cuda().requires_grad_(True)
+        l1h, sh = losses.l1_and_ssim(xh, y.cuda())
+        (l1h - 3.0 * sh).backward()
+        xd = x.double().requires_grad_(True)
+        l1d, sd = losses.l1_loss(xd, y.double()), losses.ssim(xd, y.double())
+        (l1d - 3.0 * sd).backward()
+        assert abs(float(l1h) - float(l1d)) < 1e-6 and abs(float(sh) - float(sd)) < 5e-6
+        assert float((xh.grad.cpu().double() - xd.grad).abs().max()) <= 5e-5 * float(xd.grad.abs().max())
