@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--sh-degree", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every operator eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
 
@@ -122,11 +123,18 @@ def main():
             trainer.step(frames[i % len(frames)])
 
     log(f"built trainer: {N} Gaussians, {size}x{size}, world {world}")
+    L = _lib.lib()
+    use_graph = not args.no_graph
+    graph = None
+    if use_graph:
+        # whole step captured into a hipGraph (rasterizer in sync-free capacity mode); see instag_amd/train.py
+        graph = trainer.enable_graph(frames[0])
+        log(f"step captured into a hipGraph (instance capacity {graph.capacity})")
     run(args.warmup)
     log("warm-up done")
-    L = _lib.lib()
-    L.instag_prof_enable(-1)
-    L.instag_prof_reset()
+    if not use_graph:
+        L.instag_prof_enable(-1)      # eager mode: HIP events bracket every kernel of the timed region itself
+        L.instag_prof_reset()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -144,7 +152,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations from the HIP events recorded on the launch stream during the timed region
+    overflow = []
+    if use_graph:
+        overflow = graph.check_overflow()
+        if overflow:
+            raise SystemExit(f"instance capacity exceeded during the timed region: {overflow}")
+        # Events cannot bracket kernels inside a replayed graph, so the per-kernel durations are measured
+        # right after the timed region on the SAME trainer state: the same number of steps run eagerly with
+        # HIP events around every kernel of the C ABI (the kernels and their inputs are the same).
+        trainer._graph = None
+        diff_gauss.set_capacity_plan(None)
+        L.instag_prof_enable(-1)
+        L.instag_prof_reset()
+        run(args.steps)
+        torch.cuda.synchronize()
+        log("instrumented eager pass done")
+
+    # per-kernel durations from the HIP events recorded on the launch stream
     import ctypes as C
     kern = {}
     for name, kid in KERNEL_IDS.items():
@@ -179,7 +203,8 @@ def main():
                                    "(DeepSpeech feats), 512x512, SH degree 1, main + attention raster pass, "
                                    "L1+DSSIM, Adam",
                        "gaussians": N, "image": [size, size], "sh_degree": args.sh_degree,
-                       "frames_per_step_per_gpu": 1, "parallelism": f"dp{world}"},
+                       "frames_per_step_per_gpu": 1, "parallelism": f"dp{world}",
+                       "execution": "hipGraph replay" if use_graph else "eager"},
             "roofline": roofline,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "raster_fwd_bwd_ms_per_frame": round(sum(v["total_ms"] for k, v in kern.items()

@@ -123,6 +123,16 @@ int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t
                                  void* binning, size_t binning_bytes, void* image, size_t image_bytes,
                                  int64_t R, float* out_color, float* out_depth, float* out_normal,
                                  float* out_alpha, float* out_extra, instag_stream_t stream);
+/* Sync-free forward (hipGraph-capturable): stage1 + stage2 in one call with a caller-chosen instance
+ * capacity instead of the host round trip.  binning / backward workspace are sized for `capacity`
+ * (instag_raster_binning_bytes(capacity), instag_raster_backward_workspace_bytes(N, capacity)) and
+ * backward is called with R = capacity.  status (device int32[2]): [0] = instances needed R,
+ * [1] = 1 if R > capacity (instances beyond the capacity were dropped: re-run with a larger one). */
+int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size_t geom_bytes,
+                                   void* binning, size_t binning_bytes, void* image, size_t image_bytes,
+                                   int64_t capacity, int32_t* radii, int32_t* status, float* out_color,
+                                   float* out_depth, float* out_normal, float* out_alpha,
+                                   float* out_extra, instag_stream_t stream);
 /* backward.  dL_dout_* may be NULL (treated as zero).  Gradient outputs may be NULL when not
  * needed; non-NULL ones are fully written (not accumulated).  dL_dmeans2D is [N,3]
  * (x,y in NDC units = pixel gradient * 0.5*(W,H); z = 0), the quantity

@@ -148,12 +148,13 @@ int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t
   return INSTAG_OK;
 }
 
-int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
-                                 size_t binning_bytes, void* image, size_t image_bytes, int64_t R,
-                                 float* out_color, float* out_depth, float* out_normal, float* out_alpha,
-                                 float* out_extra, instag_stream_t stream_) {
-  hipStream_t s = (hipStream_t)stream_;
-  if (int e = validate(a)) return e;
+// duplicate -> sort -> ranges -> blend over `R` instance slots.  In capacity mode (pad=true) R is the
+// caller's capacity: the unsorted keys are pre-filled with all-ones so that unused slots sort last
+// and own no tile range.
+static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
+                        size_t binning_bytes, void* image, size_t image_bytes, int64_t R, bool pad,
+                        float* out_color, float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
+                        hipStream_t s) {
   INSTAG_REQUIRE(out_color && out_depth && out_normal && out_alpha, "output images must not be NULL");
   INSTAG_REQUIRE(R >= 0 && R < (int64_t)1 << 31, "instance count out of range");
   const GeomLayout GL = geom_layout(a->N);
@@ -171,9 +172,10 @@ int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t
   uint32_t* vals_u = (uint32_t*)(bb + BL.vals_unsorted);
   uint64_t* keys = (uint64_t*)(bb + BL.keys);
   uint32_t* vals = (uint32_t*)(bb + BL.vals);
-  if (R > 0) {
+  if (R > 0 && a->N > 0) {
+    if (pad) INSTAG_CHECK_HIP(hipMemsetAsync(keys_u, 0xFF, (size_t)R * sizeof(uint64_t), s));
     if (int e = launch_duplicate(c, (float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched),
-                                 (const uint32_t*)(gb + GL.point_offsets), keys_u, vals_u, s)) return e;
+                                 (const uint32_t*)(gb + GL.point_offsets), keys_u, vals_u, (uint32_t)R, s)) return e;
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;
     {
@@ -182,11 +184,47 @@ int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t
       INSTAG_CHECK_HIP(rocprim::radix_sort_pairs(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0,
                                                  32 + tile_bits, s));
     }
-    if (int e = launch_ranges(R, keys, ranges, s)) return e;
+    if (int e = launch_ranges(R, keys, ranges, (uint32_t)tiles, s)) return e;
   }
   return launch_blend_forward(c, ranges, vals, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
                               (float*)(ib + IL.final_T), out_color, out_depth, out_normal, out_alpha,
                               a->E > 0 ? out_extra : nullptr, s);
+}
+
+int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
+                                 size_t binning_bytes, void* image, size_t image_bytes, int64_t R,
+                                 float* out_color, float* out_depth, float* out_normal, float* out_alpha,
+                                 float* out_extra, instag_stream_t stream_) {
+  if (int e = validate(a)) return e;
+  return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, R, false, out_color,
+                      out_depth, out_normal, out_alpha, out_extra, (hipStream_t)stream_);
+}
+
+int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
+                                   size_t binning_bytes, void* image, size_t image_bytes, int64_t capacity,
+                                   int32_t* radii, int32_t* status, float* out_color, float* out_depth,
+                                   float* out_normal, float* out_alpha, float* out_extra,
+                                   instag_stream_t stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (int e = validate(a)) return e;
+  INSTAG_REQUIRE(status != nullptr && radii != nullptr, "status / radii is NULL");
+  INSTAG_REQUIRE(capacity >= 1, "capacity must be >= 1");
+  const GeomLayout L = geom_layout(a->N);
+  if (geom_bytes < L.total) { set_error("geom buffer too small"); return INSTAG_E_SPACE; }
+  char* gb = (char*)geom;
+  const Camera c = make_camera(a);
+  uint32_t* tiles_touched = (uint32_t*)(gb + L.tiles_touched);
+  uint32_t* point_offsets = (uint32_t*)(gb + L.point_offsets);
+  if (a->N > 0) {
+    if (int e = launch_preprocess(c, a, (float*)(gb + L.rec2d), (float*)(gb + L.cov3d), tiles_touched,
+                                  (uint32_t*)(gb + L.flags), radii, s)) return e;
+    size_t tmp = L.scan_temp_bytes;
+    INSTAG_CHECK_HIP(rocprim::inclusive_scan(gb + L.scan_temp, tmp, tiles_touched, point_offsets, (size_t)a->N,
+                                             rocprim::plus<uint32_t>(), s));
+  }
+  if (int e = launch_status(a->N, point_offsets, (uint32_t)capacity, status, s)) return e;
+  return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, capacity, true, out_color,
+                      out_depth, out_normal, out_alpha, out_extra, s);
 }
 
 int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes, const void* binning,
@@ -222,7 +260,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
   }
   return launch_preprocess_backward(c, a, (const float*)(gb + GL.rec2d), (const float*)(gb + GL.cov3d),
                                     (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
-                                    radii, inst_grad, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp,
+                                    radii, inst_grad, (uint32_t)R, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp,
                                     dL_dopacities, dL_dscales, dL_drotations, dL_dcov3Ds_precomp,
                                     a->E > 0 ? dL_dextra_attrs : nullptr, s);
 }

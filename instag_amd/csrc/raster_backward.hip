@@ -28,10 +28,14 @@ __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
                            const float* __restrict__ cov3d, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ flags_in, const int32_t* __restrict__ radii,
-                           const float* __restrict__ inst_grad) {
+                           const float* __restrict__ inst_grad, uint32_t capacity) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= c.N) return;
-  const bool visible = radii[g] > 0;
+  bool visible = radii[g] > 0;
+  if (visible) {   // capacity mode: a Gaussian whose instances were dropped has no gradient rows
+    const uint32_t off0 = __float_as_uint(rec2d[(size_t)g * REC_FLOATS + R_OFFSET]);
+    if ((uint64_t)off0 + tiles_touched[g] > (uint64_t)capacity) visible = false;
+  }
 
   float gs[14];
 #pragma unroll
@@ -279,8 +283,8 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
 
 int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, const float* rec2d,
                                const float* cov3d, const uint32_t* tiles_touched, const uint32_t* flags,
-                               const int32_t* radii, const float* inst_grad, float* dL_dmeans3D,
-                               float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
+                               const int32_t* radii, const float* inst_grad, uint32_t capacity,
+                               float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                                float* dL_dopacities, float* dL_dscales, float* dL_drotations,
                                float* dL_dcov3D, float* dL_dextra, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
@@ -289,7 +293,7 @@ int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, con
            dL_dcov3D, dL_dextra};
   ProfScope p(K_PREPROCESS_BWD, s);
   preprocess_backward_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, io, rec2d, cov3d, tiles_touched, flags,
-                                                               radii, inst_grad);
+                                                               radii, inst_grad, capacity);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -17,8 +17,10 @@ Camera make_camera(const instag_raster_args* a);
 int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
                       uint32_t* tiles_touched, uint32_t* flags, int32_t* radii, hipStream_t s);
 int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* tiles_touched,
-                     const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s);
-int launch_ranges(int64_t R, const uint64_t* keys_sorted, int32_t* ranges, hipStream_t s);
+                     const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, uint32_t capacity,
+                     hipStream_t s);
+int launch_ranges(int64_t R, const uint64_t* keys_sorted, int32_t* ranges, uint32_t ntiles, hipStream_t s);
+int launch_status(int N, const uint32_t* point_offsets, uint32_t capacity, int32_t* status, hipStream_t s);
 
 // raster_blend.hip
 int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
@@ -34,7 +36,8 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
 // raster_backward.hip
 int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, const float* rec2d,
                                const float* cov3d, const uint32_t* tiles_touched, const uint32_t* flags,
-                               const int32_t* radii, const float* inst_grad, float* dL_dmeans3D,
+                               const int32_t* radii, const float* inst_grad, uint32_t capacity,
+                               float* dL_dmeans3D,
                                float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                                float* dL_dopacities, float* dL_dscales, float* dL_drotations,
                                float* dL_dcov3D, float* dL_dextra, hipStream_t s);

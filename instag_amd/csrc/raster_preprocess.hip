@@ -201,11 +201,12 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
 __global__ void __launch_bounds__(256)
 duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ tiles_touched,
                  const uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
-                 uint32_t* __restrict__ vals) {
+                 uint32_t* __restrict__ vals, uint32_t capacity) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
   const uint32_t tt = tiles_touched[g];
   if (tt == 0) return;
+  if (point_offsets[g] > capacity) return;   // capacity mode: instances beyond the buffer are dropped (flagged)
   uint32_t off = point_offsets[g] - tt;
   float* rec = rec2d + (size_t)g * REC_FLOATS;
   const uint32_t rect = __float_as_uint(rec[R_RECT]);
@@ -224,20 +225,29 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
 }
 
 __global__ void __launch_bounds__(256)
-ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, int32_t* __restrict__ ranges) {
+ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, int32_t* __restrict__ ranges, uint32_t ntiles) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
+  // tile ids >= ntiles are the all-ones padding keys of capacity mode: they sort last and own no range
   const uint32_t tile = (uint32_t)(keys[i] >> 32);
   if (i == 0) {
-    ranges[2 * tile] = 0;
+    if (tile < ntiles) ranges[2 * tile] = 0;
   } else {
     const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
     if (prev != tile) {
-      ranges[2 * prev + 1] = (int32_t)i;
-      ranges[2 * tile] = (int32_t)i;
+      if (prev < ntiles) ranges[2 * prev + 1] = (int32_t)i;
+      if (tile < ntiles) ranges[2 * tile] = (int32_t)i;
     }
   }
-  if (i == R - 1) ranges[2 * tile + 1] = (int32_t)R;
+  if (i == R - 1 && tile < ntiles) ranges[2 * tile + 1] = (int32_t)R;
+}
+
+// capacity mode: publish the instance count and the overflow flag without a host round trip
+__global__ void status_kernel(int N, const uint32_t* __restrict__ point_offsets, uint32_t capacity,
+                              int32_t* __restrict__ status) {
+  const uint32_t R = N > 0 ? point_offsets[N - 1] : 0u;
+  status[0] = (int32_t)R;
+  status[1] = R > capacity ? 1 : 0;
 }
 
 }  // namespace
@@ -268,19 +278,26 @@ int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d
 }
 
 int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* tiles_touched,
-                     const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, hipStream_t s) {
+                     const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, uint32_t capacity,
+                     hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_DUPLICATE, s);
   duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, tiles_touched, point_offsets,
-                                                     keys, vals);
+                                                     keys, vals, capacity);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
-int launch_ranges(int64_t R, const uint64_t* keys_sorted, int32_t* ranges, hipStream_t s) {
+int launch_ranges(int64_t R, const uint64_t* keys_sorted, int32_t* ranges, uint32_t ntiles, hipStream_t s) {
   if (R == 0) return INSTAG_OK;
   ProfScope p(K_RANGES, s);
-  ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, keys_sorted, ranges);
+  ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, keys_sorted, ranges, ntiles);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int launch_status(int N, const uint32_t* point_offsets, uint32_t capacity, int32_t* status, hipStream_t s) {
+  status_kernel<<<1, 1, 0, s>>>(N, point_offsets, capacity, status);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

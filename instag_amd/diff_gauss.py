@@ -55,6 +55,46 @@ def _require_cuda(**tensors):
 LAST_STATS = {"num_rendered": 0, "num_gaussians": 0}
 
 
+class CapacityPlan:
+    """Sync-free (hipGraph-capturable) mode of the rasterizer.
+
+    The k-th rasterizer call of a step uses the fixed instance capacity ``capacities[k]`` instead of
+    reading the instance count back to the host, and reports (needed R, overflow flag) into the
+    static device tensor ``status[k]``.  Call ``begin_step()`` before every step (eager or capture)."""
+
+    def __init__(self, capacities, device):
+        self.capacities = [int(c) for c in capacities]
+        self.status = [torch.zeros(2, dtype=torch.int32, device=device) for _ in self.capacities]
+        self.index = 0
+
+    def begin_step(self):
+        self.index = 0
+
+    def next_slot(self):
+        if self.index >= len(self.capacities):
+            raise RuntimeError("CapacityPlan: more rasterizer calls in a step than planned capacities")
+        k = self.index
+        self.index += 1
+        return self.capacities[k], self.status[k]
+
+    def overflowed(self):
+        """Host check (synchronises): list of (slot, needed R) whose capacity was exceeded."""
+        st = torch.stack(self.status).cpu()
+        return [(k, int(st[k, 0])) for k in range(len(self.capacities)) if int(st[k, 1]) != 0]
+
+    def needed(self):
+        return [int(v) for v in torch.stack(self.status).cpu()[:, 0]]
+
+
+_CAPACITY_PLAN = None
+
+
+def set_capacity_plan(plan):
+    """Install (or clear with None) the capacity plan used by every subsequent rasterizer forward."""
+    global _CAPACITY_PLAN
+    _CAPACITY_PLAN = plan
+
+
 class _State:
     """Opaque device buffers kept between forward and backward (geom / binning / image)."""
     __slots__ = ("args", "keep", "geom", "binning", "image", "R", "radii", "N", "H", "W", "E", "M")
@@ -79,7 +119,8 @@ def _make_args(s: GaussianRasterizationSettings, means3D, shs, colors, opac, sca
 
 
 def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D, extra):
-    """Run the two-stage forward.  Returns (outputs, state)."""
+    """Run the forward (two-stage with one host round trip, or sync-free under a CapacityPlan).
+    Returns (outputs, state)."""
     L = _lib.lib()
     dev = means3D.device
     a, keep, N, M, E = _make_args(settings, means3D, shs, colors, opac, scales, rots, cov3D, extra)
@@ -87,22 +128,30 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
     stream = _lib.current_stream()
     geom = torch.empty(L.instag_raster_geom_bytes(N), dtype=torch.uint8, device=dev)
     radii = torch.empty(N, dtype=torch.int32, device=dev)
-    R = C.c_int64(0)
-    check(L.instag_raster_forward_stage1(C.byref(a), ptr(geom), geom.numel(), ptr(radii), C.byref(R), stream),
-          "rasterize_gaussians")
-    R = int(R.value)
-    LAST_STATS["num_rendered"], LAST_STATS["num_gaussians"] = R, N
-    binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
     image = torch.empty(L.instag_raster_image_bytes(H, W), dtype=torch.uint8, device=dev)
     color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     normal = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     extra_img = torch.empty(E, H, W, dtype=torch.float32, device=dev)
-    check(L.instag_raster_forward_stage2(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
-                                         ptr(image), image.numel(), R, ptr(color), ptr(depth), ptr(normal),
-                                         ptr(alpha), ptr(extra_img) if E > 0 else None, stream),
-          "rasterize_gaussians")
+    if _CAPACITY_PLAN is not None:
+        R, status = _CAPACITY_PLAN.next_slot()
+        binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
+        check(L.instag_raster_forward_capacity(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
+                                               ptr(image), image.numel(), R, ptr(radii), ptr(status), ptr(color),
+                                               ptr(depth), ptr(normal), ptr(alpha),
+                                               ptr(extra_img) if E > 0 else None, stream), "rasterize_gaussians")
+    else:
+        Rc = C.c_int64(0)
+        check(L.instag_raster_forward_stage1(C.byref(a), ptr(geom), geom.numel(), ptr(radii), C.byref(Rc), stream),
+              "rasterize_gaussians")
+        R = int(Rc.value)
+        LAST_STATS["num_rendered"], LAST_STATS["num_gaussians"] = R, N
+        binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
+        check(L.instag_raster_forward_stage2(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
+                                             ptr(image), image.numel(), R, ptr(color), ptr(depth), ptr(normal),
+                                             ptr(alpha), ptr(extra_img) if E > 0 else None, stream),
+              "rasterize_gaussians")
     st = _State()
     st.args, st.keep, st.geom, st.binning, st.image = a, keep, geom, binning, image
     st.R, st.radii, st.N, st.H, st.W, st.E, st.M = R, radii, N, H, W, E, M

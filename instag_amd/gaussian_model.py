@@ -157,7 +157,7 @@ class GaussianModel:
         return self.load_raw(raw, device)
 
     # ---- optimizer ---------------------------------------------------------------------------------
-    def training_setup(self, opt=OptimizationParams, fused: Optional[bool] = None):
+    def training_setup(self, opt=OptimizationParams, fused: Optional[bool] = None, capturable: bool = False):
         dev = self._p["xyz"].device
         n = self.num_points
         self.percent_dense = opt.percent_dense
@@ -174,6 +174,10 @@ class GaussianModel:
             fused = dev.type == "cuda"
         if fused:
             kw["fused"] = True
+        if capturable:
+            # the step may be captured into a hipGraph: the scheduled learning rate lives in a device scalar
+            kw["capturable"] = True
+            groups[0]["lr"] = torch.tensor(float(groups[0]["lr"]), device=dev)
         self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **kw)
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=opt.position_lr_init * self.spatial_lr_scale, lr_final=opt.position_lr_final * self.spatial_lr_scale,
@@ -182,8 +186,12 @@ class GaussianModel:
     def update_learning_rate(self, iteration):
         for group in self.optimizer.param_groups:
             if group.get("name") == "xyz":
-                group["lr"] = self.xyz_scheduler_args(iteration)
-                return group["lr"]
+                lr = float(self.xyz_scheduler_args(iteration))
+                if isinstance(group["lr"], torch.Tensor):
+                    group["lr"].fill_(lr)
+                else:
+                    group["lr"] = lr
+                return lr
 
     # ---- densification ---------------------------------------------------------------------------------
     @torch.no_grad()

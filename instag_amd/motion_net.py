@@ -167,7 +167,9 @@ class MotionNetwork(_TriPlaneField):
             "ambient_aud": aud_ch_att.norm(dim=-1, keepdim=True),
             "ambient_eye": eye_att.norm(dim=-1, keepdim=True),
         }
-        self.cache = results
+        # consumed without gradients by the mouth branch at inference (gaussian_renderer/__init__.py:362-363);
+        # detached so that a finished step does not keep its autograd graph (and grad accumulators) alive
+        self.cache = {k: v.detach() for k, v in results.items()}
         return results
 
     def get_params(self, lr, lr_net, wd=0):

@@ -5,6 +5,14 @@ Counterpart of /root/reference/train_face.py:110-788 restricted to the hot path:
 densification statistics (:675-686) -> AdamW / Adam steps (:781-788).  LPIPS, the few-shot
 normal/depth priors and logging are out of scope.
 
+Two execution modes with identical arithmetic:
+  * eager  -- every operator is launched from Python (one host round trip per rasterizer pass);
+  * graph  -- the whole step (forward, backward, statistics, optimizers) is captured ONCE into a
+    hipGraph (torch.cuda.CUDAGraph) and replayed; the rasterizer runs in its sync-free capacity mode
+    (diff_gauss.CapacityPlan), per-frame inputs are copied into static device buffers, learning rates
+    live in device scalars.  The step is launch-bound in eager mode (~590 kernels), so this is the
+    MI355X-native way to run it.
+
 Data parallelism over frames (an addition): identical replicas, rank r renders its
 own frame, gradients of [Gaussians | UMF | PMF] are flattened into ONE bucket and all-reduced
 (RCCL over xGMI; gloo in the CPU tests), densification statistics are all-reduced too, so every
@@ -35,6 +43,23 @@ class Frame:
     camera_center: torch.Tensor
     talking_dict: dict
     original_image: torch.Tensor      # [3,H,W] in [0,1]
+
+    TENSORS = ("world_view_transform", "full_proj_transform", "camera_center", "original_image")
+    DICT_TENSORS = ("auds", "au_exp", "face_mask", "hair_mask", "mouth_mask")
+
+    def clone_static(self):
+        td = {k: self.talking_dict[k].clone() for k in self.DICT_TENSORS}
+        return Frame(self.image_height, self.image_width, self.FoVx, self.FoVy, self.world_view_transform.clone(),
+                     self.full_proj_transform.clone(), self.camera_center.clone(), td, self.original_image.clone())
+
+    def copy_from(self, other: "Frame"):
+        assert (self.image_height, self.image_width) == (other.image_height, other.image_width)
+        assert abs(self.FoVx - other.FoVx) < 1e-12 and abs(self.FoVy - other.FoVy) < 1e-12, \
+            "graph mode bakes the field of view into the captured launches"
+        for k in self.TENSORS:
+            getattr(self, k).copy_(getattr(other, k), non_blocking=True)
+        for k in self.DICT_TENSORS:
+            self.talking_dict[k].copy_(other.talking_dict[k], non_blocking=True)
 
 
 def make_frame(cam, frame_data) -> Frame:
@@ -80,6 +105,11 @@ def allreduce_gradients(params: List[torch.Tensor], extras: Optional[List[torch.
         o += e.numel()
 
 
+def masked_mean(x, mask, count):
+    """mean of x over the True elements of mask == x[mask].mean(), without the host sync of boolean indexing."""
+    return (x * mask).sum() / count
+
+
 class FaceTrainer:
     """Holds the Gaussians, the UMF (motion_net) and the PMF (gaussians.neural_motion_grid) and steps them."""
 
@@ -93,16 +123,39 @@ class FaceTrainer:
         self.densify = densify
         self.iteration = 0
         dev = gaussians.get_xyz.device
+        self.device = dev
         self.gen = torch.Generator(device=dev).manual_seed(seed)     # identical on every rank
-        fused = dev.type == "cuda"
+        self.on_gpu = dev.type == "cuda"
         # train_face.py:59-60: AdamW(betas .9/.99, eps 1e-8, wd .01), lr x0.1 during warm-up then 0.5^(it/iters)
-        self.motion_optimizer = torch.optim.AdamW(motion_net.get_params(5e-3, 5e-4), betas=(0.9, 0.99), eps=1e-8,
-                                                  weight_decay=0.01, **({"fused": True} if fused else {}))
-        warm_step, iters = 3000, opt.iterations
-        self.scheduler = torch.optim.lr_scheduler.LambdaLR(
-            self.motion_optimizer, lambda it: 0.1 if it < warm_step else 0.5 ** (it / iters))
-        self.g.training_setup(opt)
+        self._setup_optimizers()
         self.last = {}
+        self._graph = None
+
+    # ---- optimizers: learning rates are device scalars on the GPU so a captured step can be replayed -------
+    def _setup_optimizers(self):
+        kw = {"fused": True, "capturable": True} if self.on_gpu else {}
+        groups = self.motion_net.get_params(5e-3, 5e-4)
+        self._motion_base_lr = [float(g["lr"]) for g in groups]
+        if self.on_gpu:
+            for g in groups:
+                g["lr"] = torch.tensor(float(g["lr"]), device=self.device)
+        self.motion_optimizer = torch.optim.AdamW(groups, lr=5e-3 if not self.on_gpu else torch.tensor(5e-3, device=self.device),
+                                                  betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, **kw)
+        self.g.training_setup(self.opt, fused=self.on_gpu, capturable=self.on_gpu)
+
+    def _motion_lr_factor(self, it):
+        warm_step, iters = 3000, self.opt.iterations
+        return 0.1 if it < warm_step else 0.5 ** (it / iters)
+
+    def _set_learning_rates(self, it):
+        """Per-step schedules (train_face.py:60, scene/gaussian_model.py:421-427) written into the lr slots."""
+        f = self._motion_lr_factor(it - 1)      # LambdaLR: step `it` runs with lambda(it - 1)
+        for grp, base in zip(self.motion_optimizer.param_groups, self._motion_base_lr):
+            if isinstance(grp["lr"], torch.Tensor):
+                grp["lr"].fill_(base * f)
+            else:
+                grp["lr"] = base * f
+        self.g.update_learning_rate(it)
 
     def _all_params(self):
         ps = self.g.per_gaussian_parameters()
@@ -111,6 +164,7 @@ class FaceTrainer:
             ps += [p for p in self.g.neural_motion_grid.parameters()]
         return ps
 
+    # ---- loss block (train_face.py:450-456, 508-540) --------------------------------------------------------
     def loss_fn(self, frame: Frame, pkg, warm: bool):
         dev = self.bg.device
         td = frame.talking_dict
@@ -120,60 +174,183 @@ class FaceTrainer:
         head_mask = face_mask | hair_mask
         image, alpha = pkg["render"], pkg["alpha"]
         gt = frame.original_image.to(dev)
-        gt_white = gt * head_mask + self.bg[:, None, None] * ~head_mask
-        gt_white = torch.where(mouth_mask[None], self.bg[:, None, None].expand_as(gt_white), gt_white)
+        bg3 = self.bg[:, None, None]
+        gt_white = torch.where(head_mask[None] & ~mouth_mask[None], gt, bg3.expand_as(gt))
         Ll1, ssim_val = l1_and_ssim(image, gt_white)
         loss = Ll1 + self.opt.lambda_dssim * (1.0 - ssim_val)
         if warm:
             m, pm = pkg["motion"], pkg["p_motion"]
             loss = loss + 1e-5 * (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()
                                   + m["d_scale"].abs().mean() + pm["p_xyz"].abs().mean())
-            loss = loss + 1e-3 * (((1 - alpha) * head_mask).mean() + (alpha * ~head_mask).mean())
+            hm = head_mask.to(alpha.dtype)
+            loss = loss + 1e-3 * (((1 - alpha) * hm).mean() + (alpha * (1 - hm)).mean())
             attn = pkg["attn"]
-            loss = loss + 1e-4 * (attn[1][hair_mask].mean() + attn[0][hair_mask].mean())
+            hair = hair_mask.to(alpha.dtype)
+            cnt = hair.sum().clamp_min(1.0)
+            loss = loss + 1e-4 * (masked_mean(attn[1], hair, cnt) + masked_mean(attn[0], hair, cnt))
         return loss, Ll1
 
-    def step(self, frame: Frame, sync_stats: bool = False):
+    # ---- one step ---------------------------------------------------------------------------------------------
+    def _forward_backward(self, frame: Frame):
         from .renderer import render_motion
-        self.iteration += 1
-        it = self.iteration
-        self.g.update_learning_rate(it)
         pkg = render_motion(frame, self.g, self.motion_net, None, self.bg, return_attn=True, personalized=False,
                             align=True)
         loss, Ll1 = self.loss_fn(frame, pkg, warm=True)
         loss.backward()
+        return pkg, loss, Ll1
 
-        with torch.no_grad():
-            vis = pkg["visibility_filter"]
-            radii = pkg["radii"].to(self.g.max_radii2D.dtype)
-            vs_grad = pkg["viewspace_points"].grad
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                # statistics become the sum over ranks; gradients the mean (== accumulation over the frames)
-                norm = torch.norm(vs_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
-                cnt = vis[:, None].to(norm.dtype)
-                allreduce_gradients(self._all_params(), extras=[norm, cnt])
-                rmax = torch.where(vis, radii, torch.zeros_like(radii))
-                dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
-                self.g.max_radii2D = torch.max(self.g.max_radii2D, rmax)
-                self.g.xyz_gradient_accum += norm
-                self.g.denom += cnt
-            else:
-                self.g.max_radii2D = torch.where(vis, torch.max(self.g.max_radii2D, radii), self.g.max_radii2D)
-                self.g.add_densification_stats(vs_grad, vis)
+    @torch.no_grad()
+    def _stats_and_optimizers(self, pkg, distributed: bool):
+        vis = pkg["visibility_filter"]
+        radii = pkg["radii"].to(self.g.max_radii2D.dtype)
+        vs_grad = pkg["viewspace_points"].grad
+        norm = torch.norm(vs_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
+        cnt = vis[:, None].to(norm.dtype)
+        rmax = torch.where(vis, radii, torch.zeros_like(radii))
+        if distributed:
+            # statistics become the sum over ranks; gradients the mean (== accumulation over the ranks' frames)
+            allreduce_gradients(self._all_params(), extras=[norm, cnt])
+            dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
+        self.g.max_radii2D.copy_(torch.max(self.g.max_radii2D, rmax))
+        self.g.xyz_gradient_accum.add_(norm)
+        self.g.denom.add_(cnt)
+        self.motion_optimizer.step()
+        self.g.optimizer.step()
 
-            self.motion_optimizer.step()
-            self.g.optimizer.step()
-            self.motion_optimizer.zero_grad(set_to_none=True)
-            self.g.optimizer.zero_grad(set_to_none=True)
-            self.scheduler.step()
+    def _zero_grad(self):
+        self.motion_optimizer.zero_grad(set_to_none=True)
+        self.g.optimizer.zero_grad(set_to_none=True)
 
-            if self.densify and it < self.opt.densify_until_iter and it > self.opt.densify_from_iter \
-                    and it % self.opt.densification_interval == 0:
-                size_threshold = 20 if it > self.opt.opacity_reset_interval else None
-                self.g.densify_and_prune(self.opt.densify_grad_threshold, 0.05 + 0.25 * it / self.opt.densify_until_iter,
-                                         self.extent, size_threshold, generator=self.gen)
+    def _maybe_densify(self, it):
+        if self.densify and it < self.opt.densify_until_iter and it > self.opt.densify_from_iter \
+                and it % self.opt.densification_interval == 0:
+            size_threshold = 20 if it > self.opt.opacity_reset_interval else None
+            self.g.densify_and_prune(self.opt.densify_grad_threshold, 0.05 + 0.25 * it / self.opt.densify_until_iter,
+                                     self.extent, size_threshold, generator=self.gen)
+            self._graph = None        # N changed: the captured graph is stale
+            return True
+        return False
+
+    def step(self, frame: Frame):
+        self.iteration += 1
+        it = self.iteration
+        self._set_learning_rates(it)
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self._graph is not None:
+            self._graph.replay(frame)
+            loss, Ll1 = self._graph.loss, self._graph.l1
+        else:
+            from . import diff_gauss
+            if diff_gauss._CAPACITY_PLAN is not None:
+                diff_gauss._CAPACITY_PLAN.begin_step()
+            pkg, loss, Ll1 = self._forward_backward(frame)
+            self._stats_and_optimizers(pkg, distributed)
+            self._zero_grad()
+        self._maybe_densify(it)
         self.last = dict(loss=loss.detach(), l1=Ll1.detach(), num_points=self.g.num_points)
         return self.last
+
+    # ---- graph mode --------------------------------------------------------------------------------------------
+    def enable_graph(self, example_frame: Frame, headroom: float = 1.4, warmup_steps: int = 3):
+        """Capture the whole step into a hipGraph.  Runs `warmup_steps` eager steps plus two capacity-mode steps
+        first (they advance the iteration counter like any other step) to measure the instance counts and warm
+        every library."""
+        self._graph = None
+        self._graph = GraphedStep(self, example_frame, headroom, warmup_steps)
+        return self._graph
+
+
+class GraphedStep:
+    def __init__(self, trainer: FaceTrainer, example: Frame, headroom: float, warmup_steps: int):
+        from . import diff_gauss
+        t = self.trainer = trainer
+        dev = t.device
+        assert dev.type == "cuda", "graph mode needs the GPU"
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.static = example.clone_static()
+        # 1. eager warm-up in the normal (host round trip) mode: measures R of both raster passes
+        diff_gauss.set_capacity_plan(None)
+        needed = 0
+        for _ in range(max(1, warmup_steps)):
+            t.iteration += 1
+            t._set_learning_rates(t.iteration)
+            pkg, _, _ = t._forward_backward(self.static)
+            t._stats_and_optimizers(pkg, self.distributed)
+            t._zero_grad()
+            del pkg        # a live autograd graph keeps grad accumulators bound to this (non-capture) stream
+            needed = max(needed, diff_gauss.LAST_STATS["num_rendered"])
+        cap = int(needed * headroom) + 4096
+        self.plan = diff_gauss.CapacityPlan([cap, cap], dev)
+        diff_gauss.set_capacity_plan(self.plan)
+        # 2. one eager step in capacity mode on a side stream (allocator / library warm-up for capture)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                t.iteration += 1
+                t._set_learning_rates(t.iteration)
+                self.plan.begin_step()
+                pkg, _, _ = t._forward_backward(self.static)
+                t._stats_and_optimizers(pkg, self.distributed)
+                t._zero_grad()
+                del pkg
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        # 3. capture.  With several ranks the gradient exchange stays outside the graphs:
+        #    graph A = forward + backward (+ bucket fill), eager all-reduce, graph B = statistics + optimizers.
+        self.graph_a = torch.cuda.CUDAGraph()
+        self.graph_b = None
+        self.plan.begin_step()
+        if not self.distributed:
+            with torch.cuda.graph(self.graph_a):
+                pkg, loss, l1 = t._forward_backward(self.static)
+                t._stats_and_optimizers(pkg, False)
+                t._zero_grad()
+            # nothing captured is released before the capture has ended (ROCm 7.2: frees inside the capture
+            # window intermittently crash hipStreamEndCapture)
+            del pkg
+        else:
+            with torch.cuda.graph(self.graph_a):
+                pkg, loss, l1 = t._forward_backward(self.static)
+                vis = pkg["visibility_filter"]
+                vs_grad = pkg["viewspace_points"].grad
+                self._norm = torch.norm(vs_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
+                self._cnt = vis[:, None].to(self._norm.dtype)
+                radii = pkg["radii"].to(t.g.max_radii2D.dtype)
+                self._rmax = torch.where(vis, radii, torch.zeros_like(radii))
+                self._params = t._all_params()
+                self._bucket = torch.cat([flat_grad_bucket(self._params), self._norm.reshape(-1),
+                                          self._cnt.reshape(-1)])
+            self._n_grad = sum(p.numel() for p in self._params)
+            self.graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_b):
+                with torch.no_grad():
+                    scatter_grad_bucket(self._params, self._bucket[:self._n_grad])
+                    n = self._norm.numel()
+                    norm = self._bucket[self._n_grad:self._n_grad + n].view_as(self._norm)
+                    cnt = self._bucket[self._n_grad + n:].view_as(self._cnt)
+                    t.g.max_radii2D.copy_(torch.max(t.g.max_radii2D, self._rmax))
+                    t.g.xyz_gradient_accum.add_(norm)
+                    t.g.denom.add_(cnt)
+                    t.motion_optimizer.step()
+                    t.g.optimizer.step()
+                    t._zero_grad()
+        self.loss, self.l1 = loss, l1
+        self.capacity = cap
+
+    def replay(self, frame: Frame):
+        self.static.copy_from(frame)
+        self.graph_a.replay()
+        if self.graph_b is not None:
+            world = dist.get_world_size()
+            dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
+            self._bucket[:self._n_grad] /= world
+            dist.all_reduce(self._rmax, op=dist.ReduceOp.MAX)
+            self.graph_b.replay()
+
+    def check_overflow(self):
+        """Host-side (synchronising) check that no replayed step exceeded the instance capacity."""
+        return self.plan.overflowed()
 
 
 def build_trainer(n_gaussians, device, sh_degree=1, seed=0, densify=False, encoder_cls=None, raw=None):
