@@ -30,7 +30,7 @@ COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-fno-gpu-rdc"
 # rectangles, sort keys) are checked bit-for-bit against the CPU oracle.
 SOURCES = {
     "raster_preprocess.hip": ["-ffp-contract=off"],
-    "raster_blend.hip": ["-ffp-contract=off"],
+    "raster_blend.hip": [],
     "raster_backward.hip": [],
     "raster_api.hip": [],
     "grid.hip": [],

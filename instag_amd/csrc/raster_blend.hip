@@ -10,10 +10,9 @@
 //
 // Backward is deterministic and atomic-free: every (tile, Gaussian) instance owns one 64-byte
 // gradient row in `inst_grad` (slot = Gaussian's exclusive instance offset + position of the tile
-// inside its rectangle).  Per Gaussian the 14 partial gradients are reduced across the 64 lanes of
-// each wave with DPP row shifts / row broadcasts, the four wave partials are combined through LDS
-// in a fixed order and the row is written once with plain 16-byte stores.  The per-Gaussian sum
-// over its rows happens in raster_backward.hip.
+// inside its rectangle).  The reduction of a Gaussian's gradient over the 256 pixels of the tile runs
+// as two small fp32 GEMMs on the matrix cores (see blend_backward_kernel) and the row is written once
+// with plain 16-byte stores.  The per-Gaussian sum over its rows happens in raster_backward.hip.
 #include "raster_internal.hpp"
 
 namespace instag {
@@ -43,39 +42,51 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
 
   bool done = !inside;
   float T = 1.0f;
-  uint32_t contributor = 0, last_contributor = 0;
+  uint32_t last_contributor = 0;
   float acc[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) acc[k] = 0.f;
 
+  // the records of batch i+1 are fetched while batch i is being blended
+  float4 nrec0 = make_float4(0.f, 0.f, 0.f, 0.f), nrec1 = nrec0, nrec2 = nrec0, nrec3 = nrec0;
+  if (start + tid < end) {
+    const uint32_t gid = point_list[start + tid];
+    const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
+    nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
+  }
   for (int i = 0; i < rounds; ++i, toDo -= BLOCK) {
     if (__syncthreads_count(done) == BLOCK) break;
-    const int progress = i * BLOCK + tid;
-    if (start + progress < end) {
-      const uint32_t gid = point_list[start + progress];
-      const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
-      s_rec[tid][0] = r[0]; s_rec[tid][1] = r[1]; s_rec[tid][2] = r[2]; s_rec[tid][3] = r[3];
-    }
+    s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
     __syncthreads();
+    {
+      const int nprog = (i + 1) * BLOCK + tid;
+      if (start + nprog < end) {
+        const uint32_t gid = point_list[start + nprog];
+        const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
+        nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
+      }
+    }
     const int cnt = min(BLOCK, toDo);
-    for (int j = 0; !done && j < cnt; ++j) {
-      ++contributor;
-      const float4 a = s_rec[j][0];  // x y conA conB
-      const float4 b = s_rec[j][1];  // conC op r g
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      if (power > 0.0f) continue;
-      const float alpha = fminf(0.99f, b.y * __expf(power));
-      if (alpha < ALPHA_MIN) continue;
-      const float test_T = T * (1.0f - alpha);
-      if (test_T < T_MIN) { done = true; continue; }
-      const float w = alpha * T;
+    // branch-free body (predicated) so that unrolled iterations overlap: only T / done form a serial chain
+#pragma unroll 4
+    for (int j = 0; j < cnt; ++j) {
+      const float4 a = s_rec[j][0];   // x y conA conB
+      const float4 b = s_rec[j][1];   // conC op r g
       const float4 cc = s_rec[j][2];  // b depth nx ny
       const float4 dd = s_rec[j][3];  // nz extra . .
+      const float dx = a.x - pxf, dy = a.y - pyf;
+      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+      const float alpha = fminf(0.99f, b.y * __expf(power));
+      const bool hit = !done && !(power > 0.0f) && !(alpha < ALPHA_MIN);
+      const float test_T = T * (1.0f - alpha);
+      const bool stop = hit && (test_T < T_MIN);
+      done = done || stop;
+      const bool take = hit && !stop;
+      const float w = take ? alpha * T : 0.f;
       acc[0] += b.z * w; acc[1] += b.w * w; acc[2] += cc.x * w; acc[3] += cc.y * w;
       acc[4] += cc.z * w; acc[5] += cc.w * w; acc[6] += dd.x * w; acc[7] += dd.y * w;
-      T = test_T;
-      last_contributor = contributor;
+      T = take ? test_T : T;
+      last_contributor = take ? (uint32_t)(i * BLOCK + j + 1) : last_contributor;
     }
   }
   if (inside) {
@@ -95,25 +106,22 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   }
 }
 
-// ---- wave64 sum, result valid in lane 63 ------------------------------------------------------
-template <int CTRL, int ROW_MASK, bool BOUND>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, BOUND);
-  return v + __int_as_float(moved);
-}
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = dpp_add<0x111, 0xf, true>(v);   // row_shr:1
-  v = dpp_add<0x112, 0xf, true>(v);   // row_shr:2
-  v = dpp_add<0x114, 0xf, true>(v);   // row_shr:4
-  v = dpp_add<0x118, 0xf, true>(v);   // row_shr:8  -> lane 15 of each row = row total
-  v = dpp_add<0x142, 0xa, false>(v);  // row_bcast:15 into rows 1,3
-  v = dpp_add<0x143, 0xc, false>(v);  // row_bcast:31 into rows 2,3 -> lane 63 = wave total
-  return v;
-}
+// ---- backward ------------------------------------------------------------------------------------------
+// Per tile the back-to-front recurrence over the depth-sorted list is inherently sequential per pixel,
+// and the kernel's duration is the critical path of the longest tile.  The per-Gaussian step is therefore
+// kept minimal: phase A (one pixel per lane) only advances the recurrence and emits two numbers per
+// (Gaussian, pixel) -- w = alpha*T and t = G*dL/dalpha -- into LDS; the 14 gradient components of a
+// Gaussian are sums over the tile's 256 pixels of w*dL/dpixel[ch] and of t times the pixel-coordinate
+// moments (1, x, y, x^2, xy, y^2), i.e. two small GEMMs [32 Gaussians x 256 pixels] x [256 pixels x 16],
+// which phase B runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) instead of 14 x 6
+// cross-lane DPP adds per Gaussian per wave.  One wave per (16-Gaussian group, matrix); the per-pixel
+// feature fragments (B operands) are fixed for the whole tile and live in 64 VGPRs.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BB = 128;   // Gaussians per backward batch
-constexpr int NG = 14;    // gradient components per instance: x y conA conB conC op r g b depth nx ny nz extra
+constexpr int BB = 32;          // Gaussians per backward batch
+constexpr int WROW = 68;        // floats per (pixel-quarter, Gaussian) row of the w / t matrices (64 + 4 pad)
 
+template <bool FULL>            // FULL: depth / normal / extra channels carry gradient too; else rgb only
 __global__ void __launch_bounds__(BLOCK)
 blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const float* __restrict__ rec2d, const uint32_t* __restrict__ n_contrib,
@@ -122,7 +130,9 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
                       const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
                       float* __restrict__ inst_grad) {
   __shared__ float4 s_rec[BB][4];
-  __shared__ float s_part[4][BB][16];
+  __shared__ __align__(16) float s_W[4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
+  __shared__ __align__(16) float s_T[4 * BB * WROW];
+  __shared__ float s_res[BB][2][16];
   __shared__ int s_max[4];
   const int tile = blockIdx.x;
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
@@ -151,100 +161,137 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   dpix[0] = (inside && dL_dcolor) ? dL_dcolor[pix] : 0.f;
   dpix[1] = (inside && dL_dcolor) ? dL_dcolor[P + pix] : 0.f;
   dpix[2] = (inside && dL_dcolor) ? dL_dcolor[2 * P + pix] : 0.f;
-  dpix[3] = (inside && dL_ddepth) ? dL_ddepth[pix] : 0.f;
-  dpix[4] = (inside && dL_dnormal) ? dL_dnormal[pix] : 0.f;
-  dpix[5] = (inside && dL_dnormal) ? dL_dnormal[P + pix] : 0.f;
-  dpix[6] = (inside && dL_dnormal) ? dL_dnormal[2 * P + pix] : 0.f;
-  dpix[7] = (inside && dL_dextra) ? dL_dextra[pix] : 0.f;
+  dpix[3] = (FULL && inside && dL_ddepth) ? dL_ddepth[pix] : 0.f;
+  dpix[4] = (FULL && inside && dL_dnormal) ? dL_dnormal[pix] : 0.f;
+  dpix[5] = (FULL && inside && dL_dnormal) ? dL_dnormal[P + pix] : 0.f;
+  dpix[6] = (FULL && inside && dL_dnormal) ? dL_dnormal[2 * P + pix] : 0.f;
+  dpix[7] = (FULL && inside && dL_dextra) ? dL_dextra[pix] : 0.f;
   const float dalpha_img = (inside && dL_dalpha_img) ? dL_dalpha_img[pix] : 0.f;
   // d(T_final)/d(alpha_i) = -T_final/(1-alpha_i); T_final enters image (+bg) and alpha image (-1)
   const float tail = (c.bg[0] * dpix[0] + c.bg[1] * dpix[1] + c.bg[2] * dpix[2]) - dalpha_img;
 
-  float accum[NCH], last_col[NCH];
+  // ---- B-operand fragments of phase B (fixed per tile).  MFMA step s of pixel quarter kk = lane>>4 covers
+  // pixel p = 64 kk + s; feature f = lane & 15.  Waves 0/2 multiply the w matrix with dL/dpixel[f] (f < 8),
+  // waves 1/3 the t matrix with the moments (1, lx, ly, lx^2, lx ly, ly^2) of the pixel's in-tile coordinates.
+  const int mat = wave & 1, grp = wave >> 1;
+  float bfrag[64];
+  {
+    float* s_F = s_W;                       // staging: dL/dpixel of all 256 pixels, [pixel][8]
 #pragma unroll
-  for (int k = 0; k < NCH; ++k) { accum[k] = 0.f; last_col[k] = 0.f; }
-  float last_alpha = 0.f;
-
-  const uint32_t tile_xy = (uint32_t)tx | ((uint32_t)ty << 16);
-  const int rounds = (n + BB - 1) / BB;
-  for (int i = 0; i < rounds; ++i) {
+    for (int k = 0; k < NCH; ++k) s_F[tid * NCH + k] = dpix[k];
     __syncthreads();
+    const int kk = lane >> 4, f = lane & 15;
+#pragma unroll
+    for (int s_ = 0; s_ < 64; ++s_) {
+      const int p = 64 * kk + s_;
+      float v;
+      if (mat == 0) {
+        v = f < NCH ? s_F[p * NCH + f] : 0.f;
+      } else {
+        const float lx = (float)(p & 15), ly = (float)(p >> 4);
+        v = f == 0 ? 1.f : f == 1 ? lx : f == 2 ? ly : f == 3 ? lx * lx : f == 4 ? lx * ly : f == 5 ? ly * ly : 0.f;
+      }
+      bfrag[s_] = v;
+    }
+  }
+
+  // Serial per-pixel state of the back-to-front recurrence, reduced to two scalars: T (transmittance in front
+  // of the current Gaussian) and Q = sum over the Gaussians behind of w_i * <c_i, dL/dpixel>.  With
+  // cd_j = <c_j, dL/dpixel>:   dL/dalpha_j = T_j cd_j - (Q_j + T_final*tail) / (1 - alpha_j)
+  // (the "colour accumulated behind" of the published kernel is Q / T_{j+1} contracted with dL/dpixel).
+  float Q = 0.f;
+  const float tf_tail = T_final * tail;
+
+  const float tile_x0 = (float)(tx * TILE_X), tile_y0 = (float)(ty * TILE_Y);
+  const int rounds = (n + BB - 1) / BB;
+  // the records of batch i+1 are fetched (two dependent global loads) while batch i is being processed
+  float4 nrec0 = make_float4(0.f, 0.f, 0.f, 0.f), nrec1 = nrec0, nrec2 = nrec0, nrec3 = nrec0;
+  if (tid < min(BB, n)) {
+    const uint32_t gid = point_list[start + (n - 1) - tid];
+    const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
+    nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
+  }
+  for (int i = 0; i < rounds; ++i) {
+    __syncthreads();                          // previous batch fully consumed (s_rec, s_W/s_T, s_res, s_F)
     const int base = n - 1 - i * BB;          // list index of batch element 0 (walks backwards)
     const int cnt = min(BB, n - i * BB);
     if (tid < cnt) {
-      const uint32_t gid = point_list[start + base - tid];
-      const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
-      s_rec[tid][0] = r[0]; s_rec[tid][1] = r[1]; s_rec[tid][2] = r[2]; s_rec[tid][3] = r[3];
+      s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
     }
     __syncthreads();
+    {
+      const int nbase = base - BB;
+      if (tid < min(BB, nbase + 1)) {
+        const uint32_t gid = point_list[start + nbase - tid];
+        const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
+        nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
+      }
+    }
+    // ---- phase A: advance the per-pixel recurrence, emit w and t (branch-free, unrolled) ------------------
+#pragma unroll 4
     for (int j = 0; j < cnt; ++j) {
       const int idx = base - j;
-      const float4 a = s_rec[j][0];
-      const float4 b = s_rec[j][1];
+      const float4 a = s_rec[j][0];   // x y conA conB
+      const float4 b = s_rec[j][1];   // conC op r g
+      const float4 cc = s_rec[j][2];  // b depth nx ny
       const float dx = a.x - pxf, dy = a.y - pyf;
       const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
       const float G = __expf(power);
       const float alpha = fminf(0.99f, b.y * G);
       const bool valid = (idx < last_contributor) && !(power > 0.0f) && !(alpha < ALPHA_MIN);
-      if (__ballot(valid) == 0ull) {
-        if (lane < 16) s_part[wave][j][lane] = 0.f;
-        continue;
+      float cd = b.z * dpix[0] + b.w * dpix[1] + cc.x * dpix[2];
+      if (FULL) {
+        const float4 dd = s_rec[j][3];  // nz extra . .
+        cd += cc.y * dpix[3] + cc.z * dpix[4] + cc.w * dpix[5] + dd.x * dpix[6] + dd.y * dpix[7];
       }
-      float g[NG];
-#pragma unroll
-      for (int k = 0; k < NG; ++k) g[k] = 0.f;
-      if (valid) {
-        const float4 cc = s_rec[j][2];
-        const float4 dd = s_rec[j][3];
-        const float col[NCH] = {b.z, b.w, cc.x, cc.y, cc.z, cc.w, dd.x, dd.y};
-        T = T / (1.0f - alpha);
-        const float w = alpha * T;
-        float dL_dalpha = 0.f;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-          accum[k] = last_alpha * last_col[k] + (1.0f - last_alpha) * accum[k];
-          last_col[k] = col[k];
-          dL_dalpha += (col[k] - accum[k]) * dpix[k];
-          g[6 + k] = w * dpix[k];
-        }
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final / (1.0f - alpha)) * tail;
-        const float dL_dG = b.y * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        g[0] = dL_dG * (-gdx * a.z - gdy * a.w);
-        g[1] = dL_dG * (-gdy * b.x - gdx * a.w);
-        g[2] = -0.5f * gdx * dx * dL_dG;
-        g[3] = -gdx * dy * dL_dG;
-        g[4] = -0.5f * gdy * dy * dL_dG;
-        g[5] = G * dL_dalpha;
-      }
-#pragma unroll
-      for (int k = 0; k < NG; ++k) g[k] = wave_sum_to_lane63(g[k]);
-      if (lane == 63) {
-        float4* dst = reinterpret_cast<float4*>(&s_part[wave][j][0]);
-        dst[0] = make_float4(g[0], g[1], g[2], g[3]);
-        dst[1] = make_float4(g[4], g[5], g[6], g[7]);
-        dst[2] = make_float4(g[8], g[9], g[10], g[11]);
-        dst[3] = make_float4(g[12], g[13], 0.f, 0.f);
-      }
+      const float alpha_e = valid ? alpha : 0.f;
+      const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha_e);    // exactly 1 when not contributing
+      T = T * inv1ma;
+      const float w = alpha_e * T;
+      const float dL_dalpha = T * cd - inv1ma * (Q + tf_tail);
+      Q = Q + w * cd;
+      s_W[(wave * BB + j) * WROW + lane] = w;
+      s_T[(wave * BB + j) * WROW + lane] = valid ? G * dL_dalpha : 0.f;
     }
     __syncthreads();
-    if (tid < cnt) {
-      float4 r4[4];
+    // ---- phase B: [16 Gaussians x 256 pixels] x [256 pixels x 16 features] on the matrix cores ------------
+    {
+      const float* M = (mat == 0 ? s_W : s_T) + ((lane >> 4) * BB + 16 * grp + (lane & 15)) * WROW;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 p0 = reinterpret_cast<const float4*>(&s_part[0][tid][0])[q];
-        const float4 p1 = reinterpret_cast<const float4*>(&s_part[1][tid][0])[q];
-        const float4 p2 = reinterpret_cast<const float4*>(&s_part[2][tid][0])[q];
-        const float4 p3 = reinterpret_cast<const float4*>(&s_part[3][tid][0])[q];
-        r4[q] = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y,
-                            ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+      for (int s4 = 0; s4 < 16; ++s4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(M + 4 * s4);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bfrag[4 * s4 + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bfrag[4 * s4 + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bfrag[4 * s4 + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bfrag[4 * s4 + 3], acc, 0, 0, 0);
       }
+      // D[g = 4*(lane>>4) + r][f = lane&15]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_res[16 * grp + 4 * (lane >> 4) + r][mat][lane & 15] = acc[r];
+    }
+    __syncthreads();
+    // ---- one 64-byte gradient row per (tile, Gaussian) instance -------------------------------------------------
+    if (tid < cnt) {
+      const float4 ra = s_rec[tid][0], rb = s_rec[tid][1];
+      const float* Dw = s_res[tid][0];
+      const float* Dt = s_res[tid][1];
+      const float X = ra.x - tile_x0, Y = ra.y - tile_y0;
+      const float A = ra.z, B = ra.w, Cc = rb.x, op = rb.y;
+      const float S0 = Dt[0], Sx = Dt[1], Sy = Dt[2], Sxx = Dt[3], Sxy = Dt[4], Syy = Dt[5];
+      const float tdx = X * S0 - Sx, tdy = Y * S0 - Sy;
+      const float tdxx = X * X * S0 - 2.f * X * Sx + Sxx;
+      const float tdxy = X * Y * S0 - X * Sy - Y * Sx + Sxy;
+      const float tdyy = Y * Y * S0 - 2.f * Y * Sy + Syy;
+      float4 r4[4];
+      r4[0] = make_float4(-op * (A * tdx + B * tdy), -op * (Cc * tdy + B * tdx), -0.5f * op * tdxx, -op * tdxy);
+      r4[1] = make_float4(-0.5f * op * tdyy, S0, Dw[0], Dw[1]);
+      r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);
+      r4[3] = make_float4(Dw[6], Dw[7], 0.f, 0.f);
       const uint32_t off = __float_as_uint(s_rec[tid][3].z);
       const uint32_t rect = __float_as_uint(s_rec[tid][3].w);
       const uint32_t rminx = rect & 1023u, rminy = (rect >> 10) & 1023u, rw = rect >> 20;
-      const uint32_t slot = off + ((tile_xy >> 16) - rminy) * rw + ((tile_xy & 0xffffu) - rminx);
+      const uint32_t slot = off + ((uint32_t)ty - rminy) * rw + ((uint32_t)tx - rminx);
       float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)slot * REC_FLOATS);
       dst[0] = r4[0]; dst[1] = r4[1]; dst[2] = r4[2]; dst[3] = r4[3];
     }
@@ -274,8 +321,12 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
   ProfScope p(K_BLEND_BWD, s);
-  blend_backward_kernel<<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, dL_dcolor,
-                                                dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad);
+  if (dL_ddepth || dL_dnormal || dL_dextra)
+    blend_backward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, dL_dcolor,
+                                                        dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad);
+  else
+    blend_backward_kernel<false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, dL_dcolor,
+                                                         dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
