@@ -13,6 +13,20 @@ import torch
 
 from .diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
 
+CONCURRENT_PASSES = True      # fork the attention raster pass(es) onto a second stream
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """Second HIP stream per device: independent work (the attention raster pass) is forked onto it so that it
+    overlaps the main pass -- both blend kernels are bound by their longest tile and leave most CUs idle."""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
 
 def _settings(cam, pc, bg_color, scaling_modifier, debug=False):
     return GaussianRasterizationSettings(
@@ -78,19 +92,37 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     scales = pc.scaling_activation(pc._scaling + d_scale)
     rotations = pc.rotation_activation(pc._rotation + d_rot)
     ones = torch.ones_like(opacity)
+
+    def attn_pass(preds):
+        eye = preds["ambient_eye"]
+        attn_precomp = torch.cat([preds["ambient_aud"], eye, torch.zeros_like(eye)], dim=-1)
+        out = rasterizer(means3D=means3D.detach(), means2D=screenspace_points, shs=None,
+                         colors_precomp=attn_precomp, opacities=opacity.detach(), scales=scales.detach(),
+                         rotations=rotations.detach(), cov3Ds_precomp=None, extra_attrs=ones)
+        return out[0]
+
+    rendered_attn = p_rendered_attn = None
+    fork = return_attn and means3D.is_cuda and CONCURRENT_PASSES
+    if fork:
+        # the attention pass(es) only share inputs with the main pass: run them on a second stream
+        main_stream = torch.cuda.current_stream(dev)
+        side = _side_stream(dev)
+        side.wait_stream(main_stream)
+        with torch.cuda.stream(side):
+            rendered_attn = attn_pass(motion_preds)
+            if personalized:
+                p_rendered_attn = attn_pass(p_motion_preds)
+
     image, depth, normal, alpha, radii, extra = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=ones)
 
-    rendered_attn = p_rendered_attn = None
-    if return_attn:
-        def attn_pass(preds):
-            eye = preds["ambient_eye"]
-            attn_precomp = torch.cat([preds["ambient_aud"], eye, torch.zeros_like(eye)], dim=-1)
-            out = rasterizer(means3D=means3D.detach(), means2D=screenspace_points, shs=None,
-                             colors_precomp=attn_precomp, opacities=opacity.detach(), scales=scales.detach(),
-                             rotations=rotations.detach(), cov3Ds_precomp=None, extra_attrs=ones)
-            return out[0]
+    if fork:
+        main_stream.wait_stream(side)
+        for t in (rendered_attn, p_rendered_attn):
+            if t is not None:
+                t.record_stream(main_stream)
+    elif return_attn:
         rendered_attn = attn_pass(motion_preds)
         if personalized:
             p_rendered_attn = attn_pass(p_motion_preds)
