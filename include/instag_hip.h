@@ -62,6 +62,19 @@ int instag_grid_total_variation(const float* inputs, const float* embeddings, fl
                                 uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
                                 instag_stream_t stream);
 
+/* Tri-plane encoder: the three identically configured 2-D, C=1 grid encoders of a motion field (planes xy, yz, xz;
+ * scene/motion_net.py:214-216,244-258) in one pass: xyz [N,3] in [-bound,bound] -> out [N,3L] = cat(enc_xy, enc_yz,
+ * enc_xz), including the (x+bound)/(2 bound) mapping (gridencoder/grid.py:149).  Each plane's table ([total_params,1],
+ * shared `offsets` [L+1]) must fit 64 KB.  backward: grad [N,3L] -> dxyz [N,3] (zero-filled by the caller, may be
+ * NULL) and the three table gradients (zero-filled by the caller, accumulated into). */
+int instag_triplane_forward(const float* xyz, const float* table_xy, const float* table_yz,
+                            const float* table_xz, const int32_t* offsets, float* out, uint32_t N, uint32_t L,
+                            float S, uint32_t H, float bound, uint32_t total_params, instag_stream_t stream);
+int instag_triplane_backward(const float* grad, const float* xyz, const float* table_xy, const float* table_yz,
+                             const float* table_xz, const int32_t* offsets, float* dxyz, float* dtable_xy,
+                             float* dtable_yz, float* dtable_xz, uint32_t N, uint32_t L, float S, uint32_t H,
+                             float bound, uint32_t total_params, instag_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Spherical-harmonics encoder.  Replaces shencoder/src/shencoder.h:8-9:
  *   sh_encode_forward(inputs, outputs, B, D, C, dy_dx)

@@ -456,3 +456,171 @@ int instag_grid_total_variation(const float* inputs, const float* embeddings, fl
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// Tri-plane encoder: the three 2-D GridEncoders of a motion field (xy, yz, xz planes; identical
+// configuration: D=2, C=1, tables that fit LDS) evaluated in ONE pass over the points.
+//
+// Replaces, for one network, scene/motion_net.py:244-258 (split_xyz + three GridEncoder.forward calls +
+// torch.cat) including the input mapping (x+bound)/(2 bound) of gridencoder/grid.py:149 and the
+// [L,B,C]->[B,L*C] permute of :57: xyz [N,3] goes in, the concatenated feature row [N, 3L] comes out.
+// Backward recomputes the interpolation from the LDS-resident table instead of storing dy_dx
+// (96 B/point/plane), accumulates the table gradient in an LDS-private copy and returns d/dxyz.
+// =================================================================================================
+namespace instag {
+namespace {
+
+constexpr uint32_t TP_MAX_L = 16;
+
+struct TriPlaneArgs {
+  const float* xyz;           // [N,3]
+  const float* tables[3];     // each [T,1]
+  const int32_t* offsets;     // [L+1], shared by the three planes
+  uint32_t N, L, H;
+  float S, bound;
+};
+
+__device__ __forceinline__ void plane_coords(int plane, const float p[3], float x[2]) {
+  // xy = (x,y), yz = (y,z), xz = (x,z)   (motion_net.py:244-247)
+  x[0] = plane == 1 ? p[1] : p[0];
+  x[1] = plane == 0 ? p[1] : p[2];
+}
+
+__global__ void __launch_bounds__(GRID_BLOCK)
+triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
+  extern __shared__ __align__(16) float s_tab[];
+  const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;
+  const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
+  const uint32_t T = (uint32_t)a.offsets[a.L];
+  const float inv2b = 1.0f / (2.0f * a.bound);
+  for (int plane = 0; plane < 3; ++plane) {
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < T; i += GRID_BLOCK) s_tab[i] = a.tables[plane][i];
+    __syncthreads();
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
+      const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
+      float xw[2], x[2];
+      plane_coords(plane, p, xw);
+      x[0] = (xw[0] + a.bound) * inv2b;
+      x[1] = (xw[1] + a.bound) * inv2b;
+      const bool oob = x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f;
+      float* o = out + (size_t)b * 3 * a.L + plane * a.L;
+      for (uint32_t l = 0; l < a.L; ++l) {
+        const LevelGeom lg = level_geom(a.offsets, l, a.S, a.H);
+        float v;
+        encode_level<2, 1>(s_tab + (uint32_t)a.offsets[l], lg, x, oob, 0u, false, 0u, &v, nullptr);
+        o[l] = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(GRID_BLOCK)
+triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]*/, float* __restrict__ dxyz /*[N,3] or null*/,
+                         float* __restrict__ dtab0, float* __restrict__ dtab1, float* __restrict__ dtab2) {
+  extern __shared__ __align__(16) float s_mem[];
+  const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;
+  const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
+  const uint32_t T = (uint32_t)a.offsets[a.L];
+  float* s_tab = s_mem;
+  float* s_acc = s_mem + T;
+  const float inv2b = 1.0f / (2.0f * a.bound);
+  // this thread's points: at most ceil(per_block / GRID_BLOCK); d/dxyz is accumulated across the three planes in
+  // global memory (plain read-modify-write: each point is owned by exactly one thread of one block)
+  for (int plane = 0; plane < 3; ++plane) {
+    float* dtab = plane == 0 ? dtab0 : (plane == 1 ? dtab1 : dtab2);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < T; i += GRID_BLOCK) { s_tab[i] = a.tables[plane][i]; s_acc[i] = 0.f; }
+    __syncthreads();
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
+      const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
+      float xw[2], x[2];
+      plane_coords(plane, p, xw);
+      x[0] = (xw[0] + a.bound) * inv2b;
+      x[1] = (xw[1] + a.bound) * inv2b;
+      const bool oob = x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f;
+      if (oob) continue;
+      const float* g = grad + (size_t)b * 3 * a.L + plane * a.L;
+      float gx = 0.f, gy = 0.f;
+      for (uint32_t l = 0; l < a.L; ++l) {
+        const LevelGeom lg = level_geom(a.offsets, l, a.S, a.H);
+        const float gl = g[l];
+        const float* tab = s_tab + (uint32_t)a.offsets[l];
+        float* acc = s_acc + (uint32_t)a.offsets[l];
+        float pos[2], pos_deriv[2];
+        uint32_t pg[2];
+        locate<2>(x, lg.scale, false, 0u, pos, pos_deriv, pg);
+        uint32_t c00[2] = {pg[0], pg[1]}, c10[2] = {pg[0] + 1, pg[1]}, c01[2] = {pg[0], pg[1] + 1}, c11[2] = {pg[0] + 1, pg[1] + 1};
+        const uint32_t i00 = grid_index<2>(0u, false, lg.hashmap_size, lg.resolution, c00);
+        const uint32_t i10 = grid_index<2>(0u, false, lg.hashmap_size, lg.resolution, c10);
+        const uint32_t i01 = grid_index<2>(0u, false, lg.hashmap_size, lg.resolution, c01);
+        const uint32_t i11 = grid_index<2>(0u, false, lg.hashmap_size, lg.resolution, c11);
+        const float fx = pos[0], fy = pos[1];
+        __hip_atomic_fetch_add(&acc[i00], (1.f - fx) * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[i10], fx * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[i01], (1.f - fx) * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[i11], fx * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (dxyz) {
+          const float v00 = tab[i00], v10 = tab[i10], v01 = tab[i01], v11 = tab[i11];
+          // dy_dx of kernel_grid (gridencoder.cu:201-244) for D=2, linear interpolation
+          gx += gl * lg.scale * ((1.f - fy) * (v10 - v00) + fy * (v11 - v01));
+          gy += gl * lg.scale * ((1.f - fx) * (v01 - v00) + fx * (v11 - v10));
+        }
+      }
+      if (dxyz) {
+        gx *= inv2b; gy *= inv2b;
+        float* d = dxyz + (size_t)b * 3;
+        const int ia = plane == 1 ? 1 : 0, ib = plane == 0 ? 1 : 2;
+        d[ia] += gx;
+        d[ib] += gy;
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < T; i += GRID_BLOCK) {
+      const float v = s_acc[i];
+      if (v != 0.f) atomicAdd(&dtab[i], v);
+    }
+  }
+}
+
+}  // namespace
+}  // namespace instag
+
+extern "C" {
+
+int instag_triplane_forward(const float* xyz, const float* table_xy, const float* table_yz, const float* table_xz,
+                            const int32_t* offsets, float* out, uint32_t N, uint32_t L, float S, uint32_t H,
+                            float bound, uint32_t total_params, instag_stream_t stream) {
+  using namespace instag;
+  INSTAG_REQUIRE(xyz && table_xy && table_yz && table_xz && offsets && out, "triplane_forward: NULL tensor");
+  INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
+  INSTAG_REQUIRE(total_params * sizeof(float) <= 64 * 1024, "triplane: a plane's table must fit 64 KB of LDS");
+  if (N == 0) return INSTAG_OK;
+  TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_GRID_FWD, s);
+  triplane_forward_kernel<<<fwd_blocks(N), GRID_BLOCK, total_params * sizeof(float), s>>>(a, out);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_triplane_backward(const float* grad, const float* xyz, const float* table_xy, const float* table_yz,
+                             const float* table_xz, const int32_t* offsets, float* dxyz, float* dtable_xy,
+                             float* dtable_yz, float* dtable_xz, uint32_t N, uint32_t L, float S, uint32_t H,
+                             float bound, uint32_t total_params, instag_stream_t stream) {
+  using namespace instag;
+  INSTAG_REQUIRE(grad && xyz && table_xy && table_yz && table_xz && offsets && dtable_xy && dtable_yz && dtable_xz,
+                 "triplane_backward: NULL tensor");
+  INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
+  INSTAG_REQUIRE(total_params * sizeof(float) <= 64 * 1024, "triplane: a plane's table must fit 64 KB of LDS");
+  if (N == 0) return INSTAG_OK;
+  TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_GRID_BWD, s);
+  triplane_backward_kernel<<<bwd_blocks(N), GRID_BLOCK, 2 * total_params * sizeof(float), s>>>(
+      a, grad, dxyz, dtable_xy, dtable_yz, dtable_xz);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+}  // extern "C"

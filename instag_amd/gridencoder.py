@@ -146,3 +146,55 @@ class GridEncoder(nn.Module):
                                                      ptr(self.offsets), float(weight), B, D, C, L, S, H,
                                                      self.gridtype_id, int(self.align_corners),
                                                      _lib.current_stream()), "grad_total_variation")
+
+
+class _tri_plane_encode(Function):
+    """cat(enc_xy(xy), enc_yz(yz), enc_xz(xz)) of three identically configured 2-D, C=1 encoders in one kernel
+    (csrc/grid.hip: triplane_*).  Equivalent to scene/motion_net.py:244-258 of the reference."""
+
+    @staticmethod
+    def forward(ctx, xyz, emb_xy, emb_yz, emb_xz, offsets, S, H, bound):
+        xyz = xyz.contiguous().float()
+        tabs = [e.contiguous().float() for e in (emb_xy, emb_yz, emb_xz)]
+        _check_inputs(xyz=xyz, offsets=offsets, emb_xy=tabs[0], emb_yz=tabs[1], emb_xz=tabs[2])
+        N = xyz.shape[0]
+        L = offsets.shape[0] - 1
+        T = tabs[0].shape[0]
+        out = torch.empty(N, 3 * L, device=xyz.device, dtype=torch.float32)
+        check(_lib.lib().instag_triplane_forward(ptr(xyz), ptr(tabs[0]), ptr(tabs[1]), ptr(tabs[2]), ptr(offsets),
+                                                 ptr(out), N, L, S, H, float(bound), T, _lib.current_stream()),
+              "triplane_forward")
+        ctx.save_for_backward(xyz, tabs[0], tabs[1], tabs[2], offsets)
+        ctx.meta = (N, L, S, H, float(bound), T)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        xyz, t0, t1, t2, offsets = ctx.saved_tensors
+        N, L, S, H, bound, T = ctx.meta
+        grad = grad.contiguous().float()
+        dxyz = torch.zeros_like(xyz) if ctx.needs_input_grad[0] else None
+        dt = torch.zeros(3, T, 1, device=xyz.device, dtype=torch.float32)
+        check(_lib.lib().instag_triplane_backward(ptr(grad), ptr(xyz), ptr(t0), ptr(t1), ptr(t2), ptr(offsets),
+                                                  ptr(dxyz), ptr(dt[0]), ptr(dt[1]), ptr(dt[2]), N, L, S, H, bound, T,
+                                                  _lib.current_stream()), "triplane_backward")
+        return dxyz, dt[0], dt[1], dt[2], None, None, None, None
+
+
+def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
+    encs = (enc_xy, enc_yz, enc_xz)
+    if not all(isinstance(e, GridEncoder) for e in encs):
+        return False
+    e0 = encs[0]
+    same = all(e.input_dim == 2 and e.level_dim == 1 and e.num_levels == e0.num_levels
+               and e.base_resolution == e0.base_resolution and e.per_level_scale == e0.per_level_scale
+               and e.gridtype_id == 0 and not e.align_corners and e.interp_id == 0
+               and e.embeddings.shape == e0.embeddings.shape and e.embeddings.is_cuda for e in encs)
+    return same and e0.num_levels <= 16 and e0.embeddings.shape[0] * 4 <= 64 * 1024
+
+
+def tri_plane_encode(xyz, enc_xy, enc_yz, enc_xz, bound):
+    """xyz [N,3] -> [N, 3*L]; the three encoders must satisfy tri_plane_supported()."""
+    e0 = enc_xy
+    return _tri_plane_encode.apply(xyz, enc_xy.embeddings, enc_yz.embeddings, enc_xz.embeddings, e0.offsets,
+                                   float(np.log2(e0.per_level_scale)), int(e0.base_resolution), bound)

@@ -127,6 +127,11 @@ class _TriPlaneField(nn.Module):
         self.aud_ch_att_net = MLP(self.in_dim, audio_dim, 32, 2)
 
     def encode_x(self, xyz, bound):
+        if xyz.is_cuda:
+            from . import gridencoder as _ge
+            if _ge.tri_plane_supported(self.encoder_xy, self.encoder_yz, self.encoder_xz):
+                # the three planes in one HIP kernel, output already concatenated
+                return _ge.tri_plane_encode(xyz, self.encoder_xy, self.encoder_yz, self.encoder_xz, bound)
         xy, yz = xyz[:, :-1], xyz[:, 1:]
         xz = torch.cat([xyz[:, :1], xyz[:, -1:]], dim=-1)
         return torch.cat([self.encoder_xy(xy, bound=bound), self.encoder_yz(yz, bound=bound),

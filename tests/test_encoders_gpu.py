@@ -157,3 +157,31 @@ def test_fused_l1_ssim_matches_torch_and_golden(golden_dir):
         (l1d - 3.0 * sd).backward()
         assert abs(float(l1h) - float(l1d)) < 1e-6 and abs(float(sh) - float(sd)) < 5e-6
         assert float((xh.grad.cpu().double() - xd.grad).abs().max()) <= 5e-5 * float(xd.grad.abs().max())
+
+
+def test_tri_plane_encode_matches_three_encoders():
+    """Fused tri-plane kernel == cat of the three per-plane GridEncoder calls (forward, d/dxyz, table gradients)."""
+    from instag_amd.gridencoder import GridEncoder, tri_plane_encode, tri_plane_supported
+    torch.manual_seed(0)
+    encs = [GridEncoder(**FACE).cuda() for _ in range(3)]
+    with torch.no_grad():
+        for e in encs:
+            e.embeddings.copy_(torch.randn_like(e.embeddings))
+    assert tri_plane_supported(*encs)
+    x = (torch.rand(7001, 3) * 0.34 - 0.17)          # a few points outside bound 0.15 -> zeros
+    w = torch.randn(7001, 36)
+    xa = x.cuda().requires_grad_(True)
+    ya = tri_plane_encode(xa, *encs, 0.15)
+    (ya * w.cuda()).sum().backward()
+    ga = [e.embeddings.grad.clone() for e in encs]
+    for e in encs:
+        e.embeddings.grad = None
+    xb = x.cuda().requires_grad_(True)
+    xy, yz, xz = xb[:, :-1], xb[:, 1:], torch.cat([xb[:, :1], xb[:, -1:]], dim=-1)
+    yb = torch.cat([encs[0](xy, bound=0.15), encs[1](yz, bound=0.15), encs[2](xz, bound=0.15)], dim=-1)
+    (yb * w.cuda()).sum().backward()
+    assert ya.shape == (7001, 36)
+    assert float((ya - yb).abs().max()) <= 1e-5
+    assert float((xa.grad - xb.grad).abs().max()) <= 2e-4 * float(xb.grad.abs().max())
+    for g_, e in zip(ga, encs):
+        assert float((g_ - e.embeddings.grad).abs().max()) <= 2e-4 * float(e.embeddings.grad.abs().max())
