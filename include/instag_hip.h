@@ -197,6 +197,38 @@ int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void*
                               instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused per-Gaussian glue (csrc/glue.hip).
+ *  motion_glue  (scene/motion_net.py:291-306, :679-692): h_in [N,KX+KA+KE] = cat(enc_x, enc_a*aud, enc_e*relu(eye_pre)),
+ *               amb [N,2] = (||aud||, ||relu(eye_pre)||); backward returns d_enc_x, d_aud, d_eye_pre and accumulates
+ *               d_enc_a [KA], d_enc_e [KE] (zero-filled by the caller).  KA <= 32, KE <= 8.
+ *  deform_activate (gaussian_renderer/__init__.py:200-235, personalized=False, align=True): h [N,11] = UMF head output,
+ *               p [N,6] = PMF align head output -> means3D, scales, rotations, opacity.
+ *  motion_l1_reg (train_face.py:510-514): mean|h[:, :3]*1e-2| + mean|h[:,3:7]| + mean|h[:,7:8]| + mean|h[:,8:11]| +
+ *               mean|p[:, :3]*1e-2| as per-workgroup partial sums; backward takes the upstream scalar gradient g (device).
+ * ------------------------------------------------------------------------------------------ */
+int instag_motion_glue_forward(const float* enc_x, const float* aud, const float* eye_pre, const float* enc_a,
+                               const float* enc_e, float* h_in, float* amb, int32_t N, int32_t KX, int32_t KA,
+                               int32_t KE, instag_stream_t stream);
+int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const float* aud, const float* eye_pre,
+                                const float* enc_a, const float* enc_e, const float* amb, float* d_enc_x,
+                                float* d_aud, float* d_eye_pre, float* d_enc_a, float* d_enc_e, int32_t N,
+                                int32_t KX, int32_t KA, int32_t KE, instag_stream_t stream);
+int instag_deform_activate_forward(const float* xyz, const float* scaling, const float* rotation,
+                                   const float* opacity, const float* h, const float* p, float* means3D,
+                                   float* scales, float* rotations, float* opac, int32_t N,
+                                   instag_stream_t stream);
+int instag_deform_activate_backward(const float* scaling, const float* rotation, const float* opacity,
+                                    const float* h, const float* p, const float* g_means, const float* g_scales,
+                                    const float* g_rots, const float* g_opac, float* d_xyz, float* d_scaling,
+                                    float* d_rotation, float* d_opacity, float* d_h, float* d_p, int32_t N,
+                                    instag_stream_t stream);
+int instag_motion_l1_reg_num_partials(int32_t N);
+int instag_motion_l1_reg_forward(const float* h, const float* p, float* partial, int32_t N,
+                                 instag_stream_t stream);
+int instag_motion_l1_reg_backward(const float* h, const float* p, const float* g, float* d_h, float* d_p,
+                                  int32_t N, instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused L1 + SSIM image loss.  Replaces utils/loss_utils.py l1_loss :26-27 and ssim :42-72 (11x11
  * Gaussian window sigma 1.5, zero padding, C1=0.01^2, C2=0.03^2, mean over C*H*W) as used at
  * train_face.py:450-456.  img1/img2 [C,H,W].  forward writes per-workgroup partial sums

@@ -66,6 +66,13 @@ _PROTOS = {
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_linear_weight_grad_workspace_bytes": (sz, [i32, i32, i32]),
     "instag_linear_weight_grad": (C.c_int, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
+    "instag_motion_glue_forward": (C.c_int, [vp] * 7 + [i32] * 4 + [vp]),
+    "instag_motion_glue_backward": (C.c_int, [vp] * 12 + [i32] * 4 + [vp]),
+    "instag_deform_activate_forward": (C.c_int, [vp] * 10 + [i32, vp]),
+    "instag_deform_activate_backward": (C.c_int, [vp] * 15 + [i32, vp]),
+    "instag_motion_l1_reg_num_partials": (C.c_int, [i32]),
+    "instag_motion_l1_reg_forward": (C.c_int, [vp, vp, vp, i32, vp]),
+    "instag_motion_l1_reg_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
     "instag_l1_ssim_num_partials": (C.c_int, [i32, i32, i32]),
     "instag_l1_ssim_forward": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "instag_l1_ssim_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),

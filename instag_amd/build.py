@@ -37,6 +37,7 @@ SOURCES = {
     "sh.hip": [],
     "mlp.hip": [],
     "ssim.hip": [],
+    "glue.hip": [],
 }
 
 

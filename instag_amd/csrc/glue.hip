@@ -1,0 +1,320 @@
+// Fused per-Gaussian glue of the InsTaG render/train step: the elementwise chains that sit between the
+// encoders, the MLPs and the rasterizer, each as ONE forward and ONE backward kernel instead of dozens of
+// eager elementwise launches.
+//
+//  motion_glue      scene/motion_net.py:291-306 (UMF) / :679-692 (PMF):
+//                     h_in = cat(enc_x, enc_a * aud_ch_att, enc_e * relu(eye_pre)),
+//                     ambient_aud = ||aud_ch_att||, ambient_eye = ||relu(eye_pre)||
+//  deform_activate  gaussian_renderer/__init__.py:200-235 for render_motion(personalized=False, align=True):
+//                     means3D = xyz + (h[:, :3]*1e-2) * (tanh(p[:,3:]/5)*0.25+1), scales = softplus(scaling + h[:,8:11]),
+//                     rotations = normalize(rotation + h[:,3:7]), opacity = sigmoid(opacity_raw)
+//  motion_l1_reg    train_face.py:510-514: sum of the five mean-|.| regularisers of the motion outputs
+#include "common.hpp"
+
+namespace instag {
+namespace {
+
+constexpr int GB = 256;
+
+// ---- motion glue ----------------------------------------------------------------------------------------------
+struct GlueDims { int N, KX, KA, KE; };   // enc_x width, audio width, eye width; h_in width = KX+KA+KE
+
+__global__ void __launch_bounds__(GB)
+motion_glue_forward_kernel(GlueDims d, const float* __restrict__ enc_x, const float* __restrict__ aud,
+                           const float* __restrict__ eye_pre, const float* __restrict__ enc_a,
+                           const float* __restrict__ enc_e, float* __restrict__ h_in, float* __restrict__ amb) {
+  const int K = d.KX + d.KA + d.KE;
+  const size_t total = (size_t)d.N * K;
+  // element-parallel part: coalesced write of h_in
+  for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < total; i += (size_t)gridDim.x * GB) {
+    const int r = (int)(i / K), c = (int)(i - (size_t)r * K);
+    float v;
+    if (c < d.KX) v = enc_x[(size_t)r * d.KX + c];
+    else if (c < d.KX + d.KA) v = enc_a[c - d.KX] * aud[(size_t)r * d.KA + (c - d.KX)];
+    else v = enc_e[c - d.KX - d.KA] * fmaxf(eye_pre[(size_t)r * d.KE + (c - d.KX - d.KA)], 0.f);
+    h_in[i] = v;
+  }
+  // row-parallel part: the two norms
+  for (int r = blockIdx.x * GB + threadIdx.x; r < d.N; r += gridDim.x * GB) {
+    float sa = 0.f, se = 0.f;
+    for (int k = 0; k < d.KA; ++k) { const float v = aud[(size_t)r * d.KA + k]; sa += v * v; }
+    for (int k = 0; k < d.KE; ++k) { const float v = fmaxf(eye_pre[(size_t)r * d.KE + k], 0.f); se += v * v; }
+    amb[2 * r] = sqrtf(sa);
+    amb[2 * r + 1] = sqrtf(se);
+  }
+}
+
+__global__ void __launch_bounds__(GB)
+motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const float* __restrict__ d_amb,
+                            const float* __restrict__ aud, const float* __restrict__ eye_pre,
+                            const float* __restrict__ enc_a, const float* __restrict__ enc_e,
+                            const float* __restrict__ amb, float* __restrict__ d_enc_x, float* __restrict__ d_aud,
+                            float* __restrict__ d_eye_pre, float* __restrict__ d_enc_a, float* __restrict__ d_enc_e) {
+  __shared__ float s_acc[64];
+  const int K = d.KX + d.KA + d.KE;
+  for (int i = threadIdx.x; i < 64; i += GB) s_acc[i] = 0.f;
+  __syncthreads();
+  const size_t tx = (size_t)d.N * d.KX;
+  for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < tx; i += (size_t)gridDim.x * GB) {
+    const int r = (int)(i / d.KX), c = (int)(i - (size_t)r * d.KX);
+    d_enc_x[i] = d_h_in[(size_t)r * K + c];
+  }
+  float pa[32], pe[8];          // register partials of d_enc_a / d_enc_e (statically indexed: loops fully unrolled)
+#pragma unroll
+  for (int k = 0; k < 32; ++k) pa[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pe[k] = 0.f;
+  for (int r = blockIdx.x * GB + threadIdx.x; r < d.N; r += gridDim.x * GB) {
+    const float* g = d_h_in + (size_t)r * K;
+    const float na = amb[2 * r], ne = amb[2 * r + 1];
+    const float ga = (d_amb && na > 0.f) ? d_amb[2 * r] / na : 0.f;
+    const float ge = (d_amb && ne > 0.f) ? d_amb[2 * r + 1] / ne : 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      if (k < d.KA) {
+        const float a = aud[(size_t)r * d.KA + k], gw = g[d.KX + k];
+        d_aud[(size_t)r * d.KA + k] = enc_a[k] * gw + ga * a;
+        pa[k] += gw * a;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < d.KE) {
+        const float pre = eye_pre[(size_t)r * d.KE + k], gw = g[d.KX + d.KA + k];
+        const float act = fmaxf(pre, 0.f);
+        d_eye_pre[(size_t)r * d.KE + k] = pre > 0.f ? (enc_e[k] * gw + ge * act) : 0.f;
+        pe[k] += gw * act;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    float v = pa[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && k < d.KA) atomicAdd(&s_acc[k], v);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float v = pe[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && k < d.KE) atomicAdd(&s_acc[32 + k], v);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < d.KA) atomicAdd(&d_enc_a[threadIdx.x], s_acc[threadIdx.x]);
+  if ((int)threadIdx.x < d.KE) atomicAdd(&d_enc_e[threadIdx.x], s_acc[32 + threadIdx.x]);
+}
+
+// ---- deform + activations ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void __launch_bounds__(GB)
+deform_activate_forward_kernel(int N, const float* __restrict__ xyz, const float* __restrict__ scaling,
+                               const float* __restrict__ rotation, const float* __restrict__ opacity,
+                               const float* __restrict__ h /*[N,11]*/, const float* __restrict__ p /*[N,6]*/,
+                               float* __restrict__ means3D, float* __restrict__ scales, float* __restrict__ rots,
+                               float* __restrict__ opac) {
+  const int r = blockIdx.x * GB + threadIdx.x;
+  if (r >= N) return;
+  const float* hr = h + (size_t)r * 11;
+  const float* pr = p + (size_t)r * 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float ps = tanhf(pr[3 + k] * 0.2f) * 0.25f + 1.0f;
+    means3D[3 * r + k] = xyz[3 * r + k] + (hr[k] * 1e-2f) * ps;
+    scales[3 * r + k] = softplus_f(scaling[3 * r + k] + hr[8 + k]);
+  }
+  float q[4], n2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { q[k] = rotation[4 * r + k] + hr[3 + k]; n2 += q[k] * q[k]; }
+  const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rots[4 * r + k] = q[k] * inv;
+  opac[r] = sigmoid_f(opacity[r]);
+}
+
+__global__ void __launch_bounds__(GB)
+deform_activate_backward_kernel(int N, const float* __restrict__ scaling, const float* __restrict__ rotation,
+                                const float* __restrict__ opacity, const float* __restrict__ h,
+                                const float* __restrict__ p, const float* __restrict__ g_means,
+                                const float* __restrict__ g_scales, const float* __restrict__ g_rots,
+                                const float* __restrict__ g_opac, float* __restrict__ d_xyz,
+                                float* __restrict__ d_scaling, float* __restrict__ d_rotation,
+                                float* __restrict__ d_opacity, float* __restrict__ d_h, float* __restrict__ d_p) {
+  const int r = blockIdx.x * GB + threadIdx.x;
+  if (r >= N) return;
+  const float* hr = h + (size_t)r * 11;
+  const float* pr = p + (size_t)r * 6;
+  float dh[11], dp[6];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) dh[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dp[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float gm = g_means ? g_means[3 * r + k] : 0.f;
+    const float th = tanhf(pr[3 + k] * 0.2f);
+    const float ps = th * 0.25f + 1.0f;
+    d_xyz[3 * r + k] = gm;
+    dh[k] = gm * ps * 1e-2f;
+    dp[3 + k] = gm * (hr[k] * 1e-2f) * 0.25f * (1.f - th * th) * 0.2f;
+    const float gs = g_scales ? g_scales[3 * r + k] : 0.f;
+    const float sg = gs * sigmoid_f(scaling[3 * r + k] + hr[8 + k]);      // d softplus = sigmoid
+    d_scaling[3 * r + k] = sg;
+    dh[8 + k] = sg;
+  }
+  float q[4], n2 = 0.f, dot = 0.f, gr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    q[k] = rotation[4 * r + k] + hr[3 + k];
+    n2 += q[k] * q[k];
+    gr[k] = g_rots ? g_rots[4 * r + k] : 0.f;
+  }
+  const float nrm = sqrtf(n2);
+  const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dot += gr[k] * q[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // y = q / max(|q|, eps):  dq = (g - y <g, y>) / |q|   (for |q| > eps)
+    const float dq = nrm > 1e-12f ? (gr[k] - q[k] * inv * dot * inv) * inv : gr[k] * inv;
+    d_rotation[4 * r + k] = dq;
+    dh[3 + k] = dq;
+  }
+  const float so = sigmoid_f(opacity[r]);
+  d_opacity[r] = (g_opac ? g_opac[r] : 0.f) * so * (1.f - so);
+#pragma unroll
+  for (int k = 0; k < 11; ++k) d_h[(size_t)r * 11 + k] = dh[k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d_p[(size_t)r * 6 + k] = dp[k];
+}
+
+// ---- regulariser: mean|h[:, :3]*1e-2| + mean|h[:,3:7]| + mean|h[:,7:8]| + mean|h[:,8:11]| + mean|p[:, :3]*1e-2| ----------
+__global__ void __launch_bounds__(GB)
+motion_l1_reg_forward_kernel(int N, const float* __restrict__ h, const float* __restrict__ p,
+                             float* __restrict__ partial) {
+  __shared__ float s_red[4];
+  float acc = 0.f;
+  const float w_xyz = 1e-2f / (3.f * N), w_rot = 1.f / (4.f * N), w_opa = 1.f / (float)N, w_sc = 1.f / (3.f * N);
+  for (int r = blockIdx.x * GB + threadIdx.x; r < N; r += gridDim.x * GB) {
+    const float* hr = h + (size_t)r * 11;
+    const float* pr = p + (size_t)r * 6;
+    acc += w_xyz * (fabsf(hr[0]) + fabsf(hr[1]) + fabsf(hr[2]));
+    acc += w_rot * (fabsf(hr[3]) + fabsf(hr[4]) + fabsf(hr[5]) + fabsf(hr[6]));
+    acc += w_opa * fabsf(hr[7]);
+    acc += w_sc * (fabsf(hr[8]) + fabsf(hr[9]) + fabsf(hr[10]));
+    acc += w_xyz * (fabsf(pr[0]) + fabsf(pr[1]) + fabsf(pr[2]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void __launch_bounds__(GB)
+motion_l1_reg_backward_kernel(int N, const float* __restrict__ h, const float* __restrict__ p,
+                              const float* __restrict__ g, float* __restrict__ d_h, float* __restrict__ d_p) {
+  const int r = blockIdx.x * GB + threadIdx.x;
+  if (r >= N) return;
+  const float go = g[0];
+  const float w_xyz = go * 1e-2f / (3.f * N), w_rot = go / (4.f * N), w_opa = go / (float)N, w_sc = go / (3.f * N);
+  const float* hr = h + (size_t)r * 11;
+  const float* pr = p + (size_t)r * 6;
+  float* dh = d_h + (size_t)r * 11;
+  float* dp = d_p + (size_t)r * 6;
+  dh[0] = w_xyz * sgn(hr[0]); dh[1] = w_xyz * sgn(hr[1]); dh[2] = w_xyz * sgn(hr[2]);
+  dh[3] = w_rot * sgn(hr[3]); dh[4] = w_rot * sgn(hr[4]); dh[5] = w_rot * sgn(hr[5]); dh[6] = w_rot * sgn(hr[6]);
+  dh[7] = w_opa * sgn(hr[7]);
+  dh[8] = w_sc * sgn(hr[8]); dh[9] = w_sc * sgn(hr[9]); dh[10] = w_sc * sgn(hr[10]);
+  dp[0] = w_xyz * sgn(pr[0]); dp[1] = w_xyz * sgn(pr[1]); dp[2] = w_xyz * sgn(pr[2]);
+  dp[3] = 0.f; dp[4] = 0.f; dp[5] = 0.f;
+}
+
+inline int row_blocks(int N) { return std::max(1, std::min(2048, (N + GB - 1) / GB)); }
+
+}  // namespace
+}  // namespace instag
+
+using namespace instag;
+
+extern "C" {
+
+int instag_motion_glue_forward(const float* enc_x, const float* aud, const float* eye_pre, const float* enc_a,
+                               const float* enc_e, float* h_in, float* amb, int32_t N, int32_t KX, int32_t KA,
+                               int32_t KE, instag_stream_t stream) {
+  INSTAG_REQUIRE(enc_x && aud && eye_pre && enc_a && enc_e && h_in && amb, "motion_glue_forward: NULL tensor");
+  INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1, "motion_glue: widths out of range");
+  if (N == 0) return INSTAG_OK;
+  const GlueDims d{N, KX, KA, KE};
+  motion_glue_forward_kernel<<<row_blocks(N * 8), GB, 0, (hipStream_t)stream>>>(d, enc_x, aud, eye_pre, enc_a, enc_e,
+                                                                                h_in, amb);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const float* aud, const float* eye_pre,
+                                const float* enc_a, const float* enc_e, const float* amb, float* d_enc_x,
+                                float* d_aud, float* d_eye_pre, float* d_enc_a, float* d_enc_e, int32_t N,
+                                int32_t KX, int32_t KA, int32_t KE, instag_stream_t stream) {
+  INSTAG_REQUIRE(d_h_in && aud && eye_pre && enc_a && enc_e && amb && d_enc_x && d_aud && d_eye_pre && d_enc_a && d_enc_e,
+                 "motion_glue_backward: NULL tensor");
+  INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1, "motion_glue: widths out of range");
+  if (N == 0) return INSTAG_OK;
+  const GlueDims d{N, KX, KA, KE};
+  motion_glue_backward_kernel<<<row_blocks(N), GB, 0, (hipStream_t)stream>>>(
+      d, d_h_in, d_amb, aud, eye_pre, enc_a, enc_e, amb, d_enc_x, d_aud, d_eye_pre, d_enc_a, d_enc_e);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_deform_activate_forward(const float* xyz, const float* scaling, const float* rotation,
+                                   const float* opacity, const float* h, const float* p, float* means3D,
+                                   float* scales, float* rotations, float* opac, int32_t N, instag_stream_t stream) {
+  INSTAG_REQUIRE(xyz && scaling && rotation && opacity && h && p && means3D && scales && rotations && opac,
+                 "deform_activate_forward: NULL tensor");
+  if (N == 0) return INSTAG_OK;
+  deform_activate_forward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, xyz, scaling, rotation, opacity,
+                                                                                    h, p, means3D, scales, rotations, opac);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_deform_activate_backward(const float* scaling, const float* rotation, const float* opacity, const float* h,
+                                    const float* p, const float* g_means, const float* g_scales, const float* g_rots,
+                                    const float* g_opac, float* d_xyz, float* d_scaling, float* d_rotation,
+                                    float* d_opacity, float* d_h, float* d_p, int32_t N, instag_stream_t stream) {
+  INSTAG_REQUIRE(scaling && rotation && opacity && h && p && d_xyz && d_scaling && d_rotation && d_opacity && d_h && d_p,
+                 "deform_activate_backward: NULL tensor");
+  if (N == 0) return INSTAG_OK;
+  deform_activate_backward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(
+      N, scaling, rotation, opacity, h, p, g_means, g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity,
+      d_h, d_p);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_motion_l1_reg_num_partials(int32_t N) { return std::max(1, std::min(256, (N + GB - 1) / GB)); }
+
+int instag_motion_l1_reg_forward(const float* h, const float* p, float* partial, int32_t N, instag_stream_t stream) {
+  INSTAG_REQUIRE(h && p && partial, "motion_l1_reg_forward: NULL tensor");
+  INSTAG_REQUIRE(N >= 1, "motion_l1_reg: N must be >= 1");
+  motion_l1_reg_forward_kernel<<<instag_motion_l1_reg_num_partials(N), GB, 0, (hipStream_t)stream>>>(N, h, p, partial);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_motion_l1_reg_backward(const float* h, const float* p, const float* g, float* d_h, float* d_p, int32_t N,
+                                  instag_stream_t stream) {
+  INSTAG_REQUIRE(h && p && g && d_h && d_p, "motion_l1_reg_backward: NULL tensor");
+  INSTAG_REQUIRE(N >= 1, "motion_l1_reg: N must be >= 1");
+  motion_l1_reg_backward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, h, p, g, d_h, d_p);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""Fused per-Gaussian glue operators (HIP, csrc/glue.hip) used by the motion networks, the render
+composition and the loss block.  Each replaces a chain of eager elementwise ops of the reference:
+  motion_glue      scene/motion_net.py:291-306 / :679-692
+  deform_activate  gaussian_renderer/__init__.py:200-235 (render_motion, personalized=False, align=True)
+  motion_l1_reg    train_face.py:510-514
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _c(t):
+    return t.contiguous().float()
+
+
+class _MotionGlue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc_x, aud, eye_pre, enc_a, enc_e):
+        L = _lib.lib()
+        enc_x, aud, eye_pre, enc_a, enc_e = _c(enc_x), _c(aud), _c(eye_pre), _c(enc_a), _c(enc_e)
+        N, KX = enc_x.shape
+        KA, KE = aud.shape[1], eye_pre.shape[1]
+        h_in = torch.empty(N, KX + KA + KE, dtype=torch.float32, device=enc_x.device)
+        amb = torch.empty(N, 2, dtype=torch.float32, device=enc_x.device)
+        check(L.instag_motion_glue_forward(ptr(enc_x), ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e), ptr(h_in),
+                                           ptr(amb), N, KX, KA, KE, _lib.current_stream()), "motion_glue_forward")
+        ctx.save_for_backward(aud, eye_pre, enc_a, enc_e, amb)
+        ctx.dims = (N, KX, KA, KE)
+        ctx.mark_non_differentiable()
+        return h_in, amb
+
+    @staticmethod
+    def backward(ctx, d_h_in, d_amb):
+        L = _lib.lib()
+        aud, eye_pre, enc_a, enc_e, amb = ctx.saved_tensors
+        N, KX, KA, KE = ctx.dims
+        dev = aud.device
+        d_h_in = _c(d_h_in)
+        d_amb = None if d_amb is None else _c(d_amb)
+        d_enc_x = torch.empty(N, KX, dtype=torch.float32, device=dev)
+        d_aud = torch.empty(N, KA, dtype=torch.float32, device=dev)
+        d_eye = torch.empty(N, KE, dtype=torch.float32, device=dev)
+        d_vec = torch.zeros(KA + KE, dtype=torch.float32, device=dev)
+        check(L.instag_motion_glue_backward(ptr(d_h_in), ptr(d_amb), ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e),
+                                            ptr(amb), ptr(d_enc_x), ptr(d_aud), ptr(d_eye), ptr(d_vec[:KA]),
+                                            ptr(d_vec[KA:]), N, KX, KA, KE, _lib.current_stream()),
+              "motion_glue_backward")
+        return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:]
+
+
+def motion_glue(enc_x, aud, eye_pre, enc_a, enc_e):
+    """-> (h_in [N, KX+KA+KE], amb [N,2]); enc_a [KA], enc_e [KE] are per-frame vectors."""
+    return _MotionGlue.apply(enc_x, aud, eye_pre, enc_a.reshape(-1), enc_e.reshape(-1))
+
+
+def motion_glue_supported(enc_x, aud, eye_pre) -> bool:
+    return enc_x.is_cuda and aud.shape[1] <= 32 and eye_pre.shape[1] <= 8
+
+
+class _DeformActivate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, opacity, h, p):
+        L = _lib.lib()
+        xyz, scaling, rotation, opacity, h, p = (_c(t) for t in (xyz, scaling, rotation, opacity, h, p))
+        N = xyz.shape[0]
+        dev = xyz.device
+        means3D = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        rots = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        opac = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        check(L.instag_deform_activate_forward(ptr(xyz), ptr(scaling), ptr(rotation), ptr(opacity), ptr(h), ptr(p),
+                                               ptr(means3D), ptr(scales), ptr(rots), ptr(opac), N,
+                                               _lib.current_stream()), "deform_activate_forward")
+        ctx.save_for_backward(scaling, rotation, opacity, h, p)
+        return means3D, scales, rots, opac
+
+    @staticmethod
+    def backward(ctx, g_means, g_scales, g_rots, g_opac):
+        L = _lib.lib()
+        scaling, rotation, opacity, h, p = ctx.saved_tensors
+        N = scaling.shape[0]
+        dev = scaling.device
+        gs = [None if g is None else _c(g) for g in (g_means, g_scales, g_rots, g_opac)]
+        d_xyz = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        d_scaling = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        d_rot = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        d_op = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        d_h = torch.empty(N, 11, dtype=torch.float32, device=dev)
+        d_p = torch.empty(N, 6, dtype=torch.float32, device=dev)
+        check(L.instag_deform_activate_backward(ptr(scaling), ptr(rotation), ptr(opacity), ptr(h), ptr(p), ptr(gs[0]),
+                                                ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(d_xyz), ptr(d_scaling),
+                                                ptr(d_rot), ptr(d_op), ptr(d_h), ptr(d_p), N, _lib.current_stream()),
+              "deform_activate_backward")
+        return d_xyz, d_scaling, d_rot, d_op, d_h, d_p
+
+
+def deform_activate(xyz, scaling, rotation, opacity, h, p):
+    """means3D, scales, rotations, opacity for render_motion(personalized=False, align=True)."""
+    return _DeformActivate.apply(xyz, scaling, rotation, opacity, h, p)
+
+
+class _MotionL1Reg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, p):
+        L = _lib.lib()
+        h, p = _c(h), _c(p)
+        N = h.shape[0]
+        parts = torch.empty(L.instag_motion_l1_reg_num_partials(N), dtype=torch.float32, device=h.device)
+        check(L.instag_motion_l1_reg_forward(ptr(h), ptr(p), ptr(parts), N, _lib.current_stream()),
+              "motion_l1_reg_forward")
+        ctx.save_for_backward(h, p)
+        return parts.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        h, p = ctx.saved_tensors
+        N = h.shape[0]
+        g = _c(g)
+        d_h = torch.empty_like(h)
+        d_p = torch.empty_like(p)
+        check(_lib.lib().instag_motion_l1_reg_backward(ptr(h), ptr(p), ptr(g), ptr(d_h), ptr(d_p), N,
+                                                       _lib.current_stream()), "motion_l1_reg_backward")
+        return d_h, d_p
+
+
+def motion_l1_reg(h, p):
+    """mean|d_xyz| + mean|d_rot| + mean|d_opa| + mean|d_scale| + mean|p_xyz| from the raw head outputs."""
+    return _MotionL1Reg.apply(h, p)

@@ -143,10 +143,19 @@ class _TriPlaneField(nn.Module):
         return self.audio_att_net(self.audio_net(a).unsqueeze(0))
 
     def _trunk(self, x, a, e, c):
+        """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim])"""
         enc_x = self.encode_x(x, bound=self.bound)
-        enc_a = self.encode_audio(a).repeat(enc_x.shape[0], 1)
+        enc_a = self.encode_audio(a)
         aud_ch_att = self.aud_ch_att_net(enc_x)
-        parts = [enc_x, enc_a * aud_ch_att]
+        if self.exp_eye and c is None and enc_x.is_cuda:
+            from . import glue as _glue
+            eye_pre = self.eye_att_net(enc_x)
+            if _glue.motion_glue_supported(enc_x, aud_ch_att, eye_pre):
+                # repeat / mul / relu / cat / norm chain as one HIP kernel per pass (instag_amd/glue.py)
+                enc_e = torch.cat([self.exp_encode_net(e[:-1]), e[-1:]], dim=-1)
+                h_in, amb = _glue.motion_glue(enc_x, aud_ch_att, eye_pre, enc_a, enc_e)
+                return enc_x, amb[:, 0:1], amb[:, 1:2], self.sigma_net(h_in)
+        parts = [enc_x, enc_a.repeat(enc_x.shape[0], 1) * aud_ch_att]
         eye_att = None
         if self.exp_eye:
             eye_att = torch.relu(self.eye_att_net(enc_x))
@@ -155,7 +164,8 @@ class _TriPlaneField(nn.Module):
         if c is not None:
             parts.append(c.repeat(enc_x.shape[0], 1))
         h = self.sigma_net(torch.cat(parts, dim=-1))
-        return enc_x, aud_ch_att, eye_att, h
+        amb_eye = eye_att.norm(dim=-1, keepdim=True) if eye_att is not None else None
+        return enc_x, aud_ch_att.norm(dim=-1, keepdim=True), amb_eye, h
 
 
 class MotionNetwork(_TriPlaneField):
@@ -166,11 +176,11 @@ class MotionNetwork(_TriPlaneField):
         self.cache = None
 
     def forward(self, x, a, e=None, c=None):
-        _, aud_ch_att, eye_att, h = self._trunk(x, a, e, c)
+        _, amb_aud, amb_eye, h = self._trunk(x, a, e, c)
         results = {
             "d_xyz": h[..., :3] * 1e-2, "d_rot": h[..., 3:7], "d_opa": h[..., 7:8], "d_scale": h[..., 8:11],
-            "ambient_aud": aud_ch_att.norm(dim=-1, keepdim=True),
-            "ambient_eye": eye_att.norm(dim=-1, keepdim=True),
+            "ambient_aud": amb_aud, "ambient_eye": amb_eye,
+            "_h": h,          # raw head output, consumed by the fused deform / regulariser operators
         }
         # consumed without gradients by the mouth branch at inference (gaussian_renderer/__init__.py:362-363);
         # detached so that a finished step does not keep its autograd graph (and grad accumulators) alive
@@ -207,16 +217,16 @@ class PersonalizedMotionNetwork(_TriPlaneField):
         self.align_net = MLP(self.in_dim, 6, self.hidden_dim, 2)
 
     def forward(self, x, a, e=None, c=None, va=None):
-        enc_x, aud_ch_att, eye_att, h = self._trunk(x, a, e, c)
+        enc_x, amb_aud, amb_eye, h = self._trunk(x, a, e, c)
         face = self.args.type == "face"
         p = self.align_net(enc_x)
         return {
             "d_xyz": h[..., :3] * 1e-2, "d_rot": h[..., 3:7],
             "d_opa": h[..., 7:8] if face else None, "d_scale": h[..., 8:11] if face else None,
-            "ambient_aud": aud_ch_att.norm(dim=-1, keepdim=True),
-            "ambient_eye": eye_att.norm(dim=-1, keepdim=True) if self.exp_eye else None,
+            "ambient_aud": amb_aud, "ambient_eye": amb_eye if self.exp_eye else None,
             "p_xyz": p[..., :3] * 1e-2,
             "p_scale": torch.tanh(p[..., 3:] / 5) * 0.25 + 1,
+            "_h": h, "_p": p,
         }
 
     def get_params(self, lr, lr_net, wd=0):

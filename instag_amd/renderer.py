@@ -87,10 +87,19 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     if detach_motion:
         d_xyz, d_scale, d_rot = d_xyz.detach(), d_scale.detach(), d_rot.detach()
 
-    means3D = pc.get_xyz + d_xyz
-    opacity = pc.get_opacity
-    scales = pc.scaling_activation(pc._scaling + d_scale)
-    rotations = pc.rotation_activation(pc._rotation + d_rot)
+    fused = (align and not personalized and not detach_motion and pc.get_xyz.is_cuda
+             and motion_preds.get("_h") is not None and p_motion_preds.get("_p") is not None
+             and motion_preds["_h"].shape[-1] == 11)
+    if fused:
+        # deltas + softplus / normalize / sigmoid in one HIP kernel per pass (instag_amd/glue.py)
+        from .glue import deform_activate
+        means3D, scales, rotations, opacity = deform_activate(pc.get_xyz, pc._scaling, pc._rotation, pc._opacity,
+                                                              motion_preds["_h"], p_motion_preds["_p"])
+    else:
+        means3D = pc.get_xyz + d_xyz
+        opacity = pc.get_opacity
+        scales = pc.scaling_activation(pc._scaling + d_scale)
+        rotations = pc.rotation_activation(pc._rotation + d_rot)
     ones = torch.ones_like(opacity)
 
     def attn_pass(preds):

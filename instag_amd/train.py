@@ -180,8 +180,12 @@ class FaceTrainer:
         loss = Ll1 + self.opt.lambda_dssim * (1.0 - ssim_val)
         if warm:
             m, pm = pkg["motion"], pkg["p_motion"]
-            loss = loss + 1e-5 * (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()
-                                  + m["d_scale"].abs().mean() + pm["p_xyz"].abs().mean())
+            if image.is_cuda and m.get("_h") is not None and pm.get("_p") is not None:
+                from .glue import motion_l1_reg
+                loss = loss + 1e-5 * motion_l1_reg(m["_h"], pm["_p"])
+            else:
+                loss = loss + 1e-5 * (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()
+                                      + m["d_scale"].abs().mean() + pm["p_xyz"].abs().mean())
             hm = head_mask.to(alpha.dtype)
             loss = loss + 1e-3 * (((1 - alpha) * hm).mean() + (alpha * (1 - hm)).mean())
             attn = pkg["attn"]
