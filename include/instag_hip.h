@@ -244,6 +244,19 @@ int instag_l1_ssim_backward(const float* img1, const float* img2, const float* m
                             instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-tensor Adam / AdamW in one launch (csrc/adam.hip); replaces motion_optimizer.step() and
+ * gaussians.optimizer.step() of train_face.py:781-788.  tensors: device array of 48-byte records
+ * {float* p, const float* g (NULL = skip), float* m, float* v, int64 n, int32 group, int32 pad}; groups: device array
+ * of 24-byte records {beta1, beta2, eps, weight_decay, int32 decoupled (1 = AdamW), int32 pad}; lrs: device
+ * float[n_groups]; chunks: device int32[n_chunks][2] = (tensor index, chunk index), instag_adam_chunk_elems()
+ * elements per chunk; step: device float[n_tensors], per-tensor step counters, incremented by the call (for tensors with a
+ * gradient) before use.
+ * ------------------------------------------------------------------------------------------ */
+int instag_adam_chunk_elems(void);
+int instag_adam_step(const void* tensors, int32_t n_tensors, const void* groups, const float* lrs,
+                     const int32_t* chunks, int32_t n_chunks, float* step, instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-kernel timing (bench.py roofline leg).  When enabled, the launcher brackets the named
  * kernel with hipEvents on the launch stream; instag_prof_read synchronises those events and
  * returns accumulated milliseconds and launch count since the last reset.

@@ -76,6 +76,8 @@ _PROTOS = {
     "instag_l1_ssim_num_partials": (C.c_int, [i32, i32, i32]),
     "instag_l1_ssim_forward": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "instag_l1_ssim_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "instag_adam_chunk_elems": (C.c_int, []),
+    "instag_adam_step": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp]),
     "instag_prof_enable": (C.c_int, [C.c_int]),
     "instag_prof_reset": (C.c_int, []),
     "instag_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -38,6 +38,7 @@ SOURCES = {
     "mlp.hip": [],
     "ssim.hip": [],
     "glue.hip": [],
+    "adam.hip": [],
 }
 
 

@@ -1,0 +1,92 @@
+// Multi-tensor Adam / AdamW: every parameter tensor of every group of an optimizer in ONE launch.
+//
+// Replaces the optimizer steps of the reference's train loop (train_face.py:781-788:
+// motion_optimizer.step() = AdamW over the UMF groups, gaussians.optimizer.step() = Adam(eps 1e-15) over
+// the 7 per-Gaussian groups + the PMF groups, scene/gaussian_model.py:369-403), which eager PyTorch
+// runs as one fused-multi-tensor launch per group plus a step-counter update per group (~35 launches).
+// Arithmetic = torch.optim.Adam / AdamW (amsgrad=False, maximize=False):
+//   AdamW: p *= 1 - lr*wd;  Adam: g += wd*p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// Learning rates and the step counter live in device memory so that a captured hipGraph can be replayed.
+#include "common.hpp"
+
+namespace instag {
+namespace {
+
+struct AdamTensor {     // one parameter tensor (device pointers), 48 bytes
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+  int32_t group;
+  int32_t pad;
+};
+struct AdamGroup {      // hyper-parameters of one group, 24 bytes
+  float beta1, beta2, eps, weight_decay;
+  int32_t decoupled;    // 1 = AdamW
+  int32_t pad;
+};
+constexpr int ADAM_BLOCK = 256;
+constexpr int ADAM_CHUNK = 4096;       // elements per workgroup (16 per thread)
+
+// per-tensor step counters (torch keeps state['step'] per parameter; a parameter without gradient is not stepped)
+__global__ void adam_tick_kernel(const AdamTensor* __restrict__ tensors, int n, float* __restrict__ steps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && tensors[i].g != nullptr) steps[i] += 1.0f;
+}
+
+__global__ void __launch_bounds__(ADAM_BLOCK)
+adam_step_kernel(const AdamTensor* __restrict__ tensors, const AdamGroup* __restrict__ groups,
+                 const float* __restrict__ lrs, const int2* __restrict__ chunks, const float* __restrict__ step) {
+  const int2 ch = chunks[blockIdx.x];            // (tensor index, chunk index)
+  const AdamTensor t = tensors[ch.x];
+  if (t.g == nullptr) return;
+  const AdamGroup gr = groups[t.group];
+  const float lr = lrs[t.group];
+  const float tstep = step[ch.x];
+  const float bc1 = 1.0f - powf(gr.beta1, tstep);
+  const float bc2_sqrt = sqrtf(1.0f - powf(gr.beta2, tstep));
+  const float step_size = lr / bc1;
+  const int64_t base = (int64_t)ch.y * ADAM_CHUNK;
+  const int64_t end = min(t.n, base + ADAM_CHUNK);
+  for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) {
+    float p = t.p[i], g = t.g[i], m = t.m[i], v = t.v[i];
+    if (gr.decoupled) p *= 1.0f - lr * gr.weight_decay;
+    else if (gr.weight_decay != 0.f) g += gr.weight_decay * p;
+    m = gr.beta1 * m + (1.0f - gr.beta1) * g;
+    v = gr.beta2 * v + (1.0f - gr.beta2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + gr.eps;
+    p -= step_size * (m / denom);
+    t.p[i] = p; t.m[i] = m; t.v[i] = v;
+  }
+}
+
+}  // namespace
+}  // namespace instag
+
+using namespace instag;
+
+extern "C" {
+
+int instag_adam_chunk_elems(void) { return ADAM_CHUNK; }
+
+/* tensors: device array of 48-byte records {p, g, m, v, int64 n, int32 group, int32 pad}; groups: device array of
+ * 24-byte records {beta1, beta2, eps, weight_decay, int32 decoupled, int32 pad}; lrs: device float[n_groups];
+ * chunks: device int32[n_chunks][2] = (tensor index, chunk index within the tensor, instag_adam_chunk_elems()
+ * elements each); step: device float[n_tensors], the per-tensor step counters, incremented by this call (for tensors
+ * with a gradient) before they are used. */
+int instag_adam_step(const void* tensors, int32_t n_tensors, const void* groups, const float* lrs,
+                     const int32_t* chunks, int32_t n_chunks, float* step, instag_stream_t stream) {
+  INSTAG_REQUIRE(tensors && groups && lrs && chunks && step, "adam_step: NULL argument");
+  if (n_chunks <= 0 || n_tensors <= 0) return INSTAG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  adam_tick_kernel<<<(n_tensors + 63) / 64, 64, 0, s>>>((const AdamTensor*)tensors, n_tensors, step);
+  INSTAG_CHECK_LAUNCH();
+  adam_step_kernel<<<n_chunks, ADAM_BLOCK, 0, s>>>((const AdamTensor*)tensors, (const AdamGroup*)groups, lrs,
+                                                   (const int2*)chunks, step);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+}  // extern "C"

@@ -169,16 +169,14 @@ class GaussianModel:
         groups = [{"params": [self._p[k]], "lr": lrs[k], "name": k} for k in PARAM_NAMES]
         if self.neural_motion_grid is not None:
             groups += self.neural_motion_grid.get_params(lr=1e-3, lr_net=1e-4)
-        kw = {}
         if fused is None:
             fused = dev.type == "cuda"
         if fused:
-            kw["fused"] = True
-        if capturable:
-            # the step may be captured into a hipGraph: the scheduled learning rate lives in a device scalar
-            kw["capturable"] = True
-            groups[0]["lr"] = torch.tensor(float(groups[0]["lr"]), device=dev)
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, **kw)
+            # GPU: every group in one HIP launch, learning rates / step counter in device memory (instag_amd/optim.py)
+            from .optim import MultiTensorAdam
+            self.optimizer = MultiTensorAdam(groups, lr=0.0, betas=(0.9, 0.999), eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self.xyz_scheduler_args = get_expon_lr_func(
             lr_init=opt.position_lr_init * self.spatial_lr_scale, lr_final=opt.position_lr_final * self.spatial_lr_scale,
             lr_delay_mult=opt.position_lr_delay_mult, max_steps=opt.position_lr_max_steps)
@@ -219,12 +217,14 @@ class GaussianModel:
                     t = torch.cat((t, add), dim=0)
                 return t
             new = nn.Parameter(remap(old.data, False).contiguous().requires_grad_(True))
-            if state is not None:
+            if state is not None and "exp_avg" in state:
                 state["exp_avg"] = remap(state["exp_avg"], True).contiguous()
                 state["exp_avg_sq"] = remap(state["exp_avg_sq"], True).contiguous()
                 self.optimizer.state[new] = state
             group["params"][0] = new
             self._p[name] = new
+        if hasattr(self.optimizer, "invalidate"):
+            self.optimizer.invalidate()
 
     @torch.no_grad()
     def prune_points(self, mask):
@@ -283,12 +283,14 @@ class GaussianModel:
         old = group["params"][0]
         state = self.optimizer.state.pop(old, None)
         p = nn.Parameter(new.contiguous().requires_grad_(True))
-        if state is not None:
+        if state is not None and "exp_avg" in state:
             state["exp_avg"] = torch.zeros_like(new)
             state["exp_avg_sq"] = torch.zeros_like(new)
             self.optimizer.state[p] = state
         group["params"][0] = p
         self._p["opacity"] = p
+        if hasattr(self.optimizer, "invalidate"):
+            self.optimizer.invalidate()
 
     def per_gaussian_parameters(self):
         return [self._p[k] for k in PARAM_NAMES]

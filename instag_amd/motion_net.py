@@ -14,6 +14,17 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+CONCURRENT_AUDIO = True       # fork the audio branch onto a second stream (parallel hipGraph branch)
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 _AUDIO_DIMS = (("esperanto", 44), ("deepspeech", 29), ("hubert", 1024), ("ave", 32))
 
 
@@ -144,9 +155,23 @@ class _TriPlaneField(nn.Module):
 
     def _trunk(self, x, a, e, c):
         """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim])"""
+        fork = x.is_cuda and CONCURRENT_AUDIO
+        if fork:
+            # the per-frame audio branch (~40 tiny kernels) only meets the per-Gaussian branch at the glue:
+            # run it on a second stream so it overlaps the tri-plane encode and the attention MLPs
+            main_stream = torch.cuda.current_stream(x.device)
+            side = _side_stream(x.device)
+            side.wait_stream(main_stream)
+            with torch.cuda.stream(side):
+                enc_a = self.encode_audio(a)
         enc_x = self.encode_x(x, bound=self.bound)
-        enc_a = self.encode_audio(a)
-        aud_ch_att = self.aud_ch_att_net(enc_x)
+        if fork:
+            aud_ch_att = self.aud_ch_att_net(enc_x)
+            main_stream.wait_stream(side)
+            enc_a.record_stream(main_stream)
+        else:
+            enc_a = self.encode_audio(a)
+            aud_ch_att = self.aud_ch_att_net(enc_x)
         if self.exp_eye and c is None and enc_x.is_cuda:
             from . import glue as _glue
             eye_pre = self.eye_att_net(enc_x)

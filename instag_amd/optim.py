@@ -1,0 +1,122 @@
+"""Single-launch multi-tensor Adam / AdamW (HIP, csrc/adam.hip) with a torch.optim-like surface.
+
+Counterpart of the two optimizers of the reference's train loop (train_face.py:59, 781-788;
+scene/gaussian_model.py:369-403).  ``param_groups`` / ``state[param]['exp_avg'|'exp_avg_sq']`` behave like
+torch.optim.Adam's so that the densify / prune bookkeeping (scene/gaussian_model.py:563-621) works unchanged;
+``lr`` of a group may be changed between steps (python float); learning rates and the step counter are kept in
+device memory, so a captured hipGraph containing ``step()`` can be replayed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+_TENSOR_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("group", "<i4"),
+                       ("pad", "<i4")])
+_GROUP_DT = np.dtype([("beta1", "<f4"), ("beta2", "<f4"), ("eps", "<f4"), ("wd", "<f4"), ("decoupled", "<i4"),
+                      ("pad", "<i4")])
+
+
+class MultiTensorAdam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+        groups = list(params)
+        if groups and not isinstance(groups[0], dict):
+            groups = [{"params": groups}]
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled)
+        self.param_groups = []
+        for g in groups:
+            g = dict(g)
+            g["params"] = list(g["params"])
+            for k, v in self.defaults.items():
+                g.setdefault(k, v)
+            self.param_groups.append(g)
+        self.state = defaultdict(dict)
+        self._dev = None
+        self._step = None
+        self._layout_key = None
+
+    # ---- torch.optim surface ----------------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+
+    def _ensure_state(self, p):
+        st = self.state[p]
+        if "exp_avg" not in st:
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
+
+    def set_lrs(self):
+        """Push the groups' current python-float learning rates to the device (one small copy)."""
+        if self._dev is None:
+            return
+        host = self._lr_host
+        for i, g in enumerate(self.param_groups):
+            host[i] = float(g["lr"])
+        self._lr_dev.copy_(host, non_blocking=True)
+
+    @torch.no_grad()
+    def step(self):
+        L = _lib.lib()
+        tensors = []
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                if not p.is_cuda:
+                    raise RuntimeError("MultiTensorAdam runs on the GPU only")
+                st = self._ensure_state(p)
+                grad = p.grad
+                if grad is not None and not grad.is_contiguous():
+                    grad = grad.contiguous()
+                tensors.append((p, grad, st["exp_avg"], st["exp_avg_sq"], gi))
+        if not tensors:
+            return
+        dev = tensors[0][0].device
+        chunk = L.instag_adam_chunk_elems()
+        key = tuple((t[0].data_ptr(), t[0].numel(), t[2].data_ptr()) for t in tensors)
+        if self._dev != dev or key != self._layout_key:
+            # static part: chunk table, group table, pinned staging buffers
+            chunks = [(ti, c) for ti, t in enumerate(tensors) for c in range((t[0].numel() + chunk - 1) // chunk)]
+            self._chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
+            garr = np.zeros(len(self.param_groups), dtype=_GROUP_DT)
+            for i, g in enumerate(self.param_groups):
+                garr[i] = (g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], int(bool(g["decoupled"])), 0)
+            self._groups_dev = torch.from_numpy(garr.view(np.uint8).copy()).to(dev)
+            self._tensors_host = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8).pin_memory()
+            self._tensors_dev = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8, device=dev)
+            self._lr_host = torch.zeros(len(self.param_groups), dtype=torch.float32).pin_memory()
+            self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
+            # per-tensor step counters follow their parameter's state across re-layouts (densify / prune)
+            steps = torch.zeros(len(tensors), dtype=torch.float32, device=dev)
+            for i, t in enumerate(tensors):
+                prev = self.state[t[0]].get("step")
+                if prev is not None:
+                    steps[i:i + 1].copy_(prev.reshape(1))
+            self._step = steps
+            for i, t in enumerate(tensors):
+                self.state[t[0]]["step"] = steps[i:i + 1]
+            self._dev, self._layout_key = dev, key
+            self.set_lrs()
+        tarr = self._tensors_host.numpy().view(_TENSOR_DT)
+        for i, (p, grad, m, v, gi) in enumerate(tensors):
+            tarr[i] = (p.data_ptr(), 0 if grad is None else grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), gi, 0)
+        self._keep = [t[1] for t in tensors]          # keep contiguous grad copies alive until the launch ran
+        self._tensors_dev.copy_(self._tensors_host, non_blocking=True)
+        check(L.instag_adam_step(ptr(self._tensors_dev), len(tensors), ptr(self._groups_dev), ptr(self._lr_dev),
+                                 ptr(self._chunks), self._chunks.shape[0], ptr(self._step), _lib.current_stream()),
+              "adam_step")
+
+    def invalidate(self):
+        """Call after replacing parameters / state tensors (densify, prune)."""
+        self._layout_key = None

@@ -133,15 +133,15 @@ class FaceTrainer:
 
     # ---- optimizers: learning rates are device scalars on the GPU so a captured step can be replayed -------
     def _setup_optimizers(self):
-        kw = {"fused": True, "capturable": True} if self.on_gpu else {}
         groups = self.motion_net.get_params(5e-3, 5e-4)
         self._motion_base_lr = [float(g["lr"]) for g in groups]
         if self.on_gpu:
-            for g in groups:
-                g["lr"] = torch.tensor(float(g["lr"]), device=self.device)
-        self.motion_optimizer = torch.optim.AdamW(groups, lr=5e-3 if not self.on_gpu else torch.tensor(5e-3, device=self.device),
-                                                  betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01, **kw)
-        self.g.training_setup(self.opt, fused=self.on_gpu, capturable=self.on_gpu)
+            from .optim import MultiTensorAdam
+            self.motion_optimizer = MultiTensorAdam(groups, lr=5e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
+                                                    decoupled=True)
+        else:
+            self.motion_optimizer = torch.optim.AdamW(groups, lr=5e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+        self.g.training_setup(self.opt, fused=self.on_gpu)
 
     def _motion_lr_factor(self, it):
         warm_step, iters = 3000, self.opt.iterations
@@ -151,11 +151,11 @@ class FaceTrainer:
         """Per-step schedules (train_face.py:60, scene/gaussian_model.py:421-427) written into the lr slots."""
         f = self._motion_lr_factor(it - 1)      # LambdaLR: step `it` runs with lambda(it - 1)
         for grp, base in zip(self.motion_optimizer.param_groups, self._motion_base_lr):
-            if isinstance(grp["lr"], torch.Tensor):
-                grp["lr"].fill_(base * f)
-            else:
-                grp["lr"] = base * f
+            grp["lr"] = base * f
         self.g.update_learning_rate(it)
+        for opt_ in (self.motion_optimizer, self.g.optimizer):
+            if hasattr(opt_, "set_lrs"):
+                opt_.set_lrs()          # one small copy into the device-side learning-rate table
 
     def _all_params(self):
         ps = self.g.per_gaussian_parameters()

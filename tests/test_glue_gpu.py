@@ -80,3 +80,37 @@ def test_motion_l1_reg_matches_torch():
     assert abs(float(r) - float(ref(hd, pd))) < 1e-6
     _close(hh.grad, hd.grad, "dh", tol=1e-6)
     _close(ph.grad, pd.grad, "dp", tol=1e-6)
+
+
+def test_multi_tensor_adam_matches_torch():
+    """One-launch Adam/AdamW == torch.optim.Adam / AdamW over several steps, groups, learning-rate changes."""
+    from instag_amd.optim import MultiTensorAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(10000, 3), (10000, 1, 3), (10000, 3, 3), (64, 74), (11, 64), (9464, 1), (5,)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) * (0.1 if k % 2 else 3.0) for s in shapes] for k in range(6)]
+
+    def run(make, adamw):
+        ps = [torch.nn.Parameter(b.clone().cuda()) for b in base]
+        groups = [{"params": [ps[0]], "lr": 1.6e-4}, {"params": [ps[1], ps[2]], "lr": 2.5e-3},
+                  {"params": ps[3:5], "lr": 5e-4, "weight_decay": 0.01 if adamw else 0.0},
+                  {"params": ps[5:], "lr": 5e-3}]
+        opt = make(groups)
+        for k, gs in enumerate(grads):
+            for i, (p, gr) in enumerate(zip(ps, gs)):
+                p.grad = None if (i == 6 and k < 2) else gr.clone().cuda()     # a parameter that starts without grad
+            opt.param_groups[0]["lr"] = 1.6e-4 * (0.9 ** k)
+            if hasattr(opt, "set_lrs"):
+                opt.set_lrs()
+            opt.step()
+        return [p.detach().cpu() for p in ps]
+
+    for adamw in (False, True):
+        if adamw:
+            ref = run(lambda gr: torch.optim.AdamW(gr, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.0), True)
+            got = run(lambda gr: MultiTensorAdam(gr, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, decoupled=True), True)
+        else:
+            ref = run(lambda gr: torch.optim.Adam(gr, lr=0.0, eps=1e-15), False)
+            got = run(lambda gr: MultiTensorAdam(gr, lr=0.0, betas=(0.9, 0.999), eps=1e-15), False)
+        for a, b in zip(got, ref):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
