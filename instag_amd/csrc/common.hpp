@@ -63,7 +63,7 @@ enum RecSlot { R_X = 0, R_Y, R_CA, R_CB, R_CC, R_OP, R_R, R_G, R_B, R_DEPTH, R_N
 
 // flags[g]: bit0..2 rgb clamped, bit3..4 normal axis, bit5 normal flipped, bit6 tx clamped, bit7 ty clamped
 struct GeomLayout {
-  size_t rec2d, cov3d, tiles_touched, point_offsets, flags, scan_temp, scan_temp_bytes, total;
+  size_t rec2d, cov3d, tiles_touched, point_offsets, flags, cull_thr, scan_temp, scan_temp_bytes, total;
 };
 GeomLayout geom_layout(int32_t N);
 
@@ -73,7 +73,7 @@ struct ImageLayout {
 ImageLayout image_layout(int32_t H, int32_t W);
 
 struct BinningLayout {
-  size_t keys_unsorted, vals_unsorted, keys, vals, sort_temp, sort_temp_bytes, total;
+  size_t keys_unsorted, vals_unsorted, keys, vals, gid_unsorted, point_list, sort_temp, sort_temp_bytes, total;
 };
 BinningLayout binning_layout(int64_t R);
 

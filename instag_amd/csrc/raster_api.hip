@@ -53,6 +53,7 @@ GeomLayout geom_layout(int32_t N) {
   L.tiles_touched = o; o = align_up(o + n * sizeof(uint32_t), 256);
   L.point_offsets = o; o = align_up(o + n * sizeof(uint32_t), 256);
   L.flags = o; o = align_up(o + n * sizeof(uint32_t), 256);
+  L.cull_thr = o; o = align_up(o + n * sizeof(float), 256);
   size_t tmp = 0;
   (void)rocprim::inclusive_scan(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, n, rocprim::plus<uint32_t>());
   L.scan_temp = o; L.scan_temp_bytes = tmp; o = align_up(o + tmp, 256);
@@ -80,6 +81,8 @@ BinningLayout binning_layout(int64_t R) {
   L.vals_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.keys = o; o = align_up(o + r * sizeof(uint64_t), 256);
   L.vals = o; o = align_up(o + r * sizeof(uint32_t), 256);
+  L.gid_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
+  L.point_list = o; o = align_up(o + r * sizeof(uint32_t), 256);
   size_t tmp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
                                   (uint32_t*)nullptr, r, 0, 64);
@@ -137,7 +140,7 @@ int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t
   uint32_t* tiles_touched = (uint32_t*)(gb + L.tiles_touched);
   uint32_t* point_offsets = (uint32_t*)(gb + L.point_offsets);
   if (int e = launch_preprocess(c, a, (float*)(gb + L.rec2d), (float*)(gb + L.cov3d), tiles_touched,
-                                (uint32_t*)(gb + L.flags), radii, s)) return e;
+                                (uint32_t*)(gb + L.flags), (float*)(gb + L.cull_thr), radii, s)) return e;
   size_t tmp = L.scan_temp_bytes;
   INSTAG_CHECK_HIP(rocprim::inclusive_scan(gb + L.scan_temp, tmp, tiles_touched, point_offsets, (size_t)a->N,
                                            rocprim::plus<uint32_t>(), s));
@@ -172,10 +175,14 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   uint32_t* vals_u = (uint32_t*)(bb + BL.vals_unsorted);
   uint64_t* keys = (uint64_t*)(bb + BL.keys);
   uint32_t* vals = (uint32_t*)(bb + BL.vals);
+  uint32_t* gid_u = (uint32_t*)(bb + BL.gid_unsorted);
+  uint32_t* point_list = (uint32_t*)(bb + BL.point_list);
   if (R > 0 && a->N > 0) {
     if (pad) INSTAG_CHECK_HIP(hipMemsetAsync(keys_u, 0xFF, (size_t)R * sizeof(uint64_t), s));
     if (int e = launch_duplicate(c, (float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched),
-                                 (const uint32_t*)(gb + GL.point_offsets), keys_u, vals_u, (uint32_t)R, s)) return e;
+                                 (const uint32_t*)(gb + GL.point_offsets), (const uint32_t*)(gb + GL.flags),
+                                 (const float*)(gb + GL.cull_thr), keys_u,
+                                 vals_u, gid_u, (uint32_t)R, s)) return e;
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;
     {
@@ -184,9 +191,9 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
       INSTAG_CHECK_HIP(rocprim::radix_sort_pairs(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0,
                                                  32 + tile_bits, s));
     }
-    if (int e = launch_ranges(R, keys, ranges, (uint32_t)tiles, s)) return e;
+    if (int e = launch_ranges(R, keys, vals, gid_u, point_list, ranges, (uint32_t)tiles, s)) return e;
   }
-  return launch_blend_forward(c, ranges, vals, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
+  return launch_blend_forward(c, ranges, point_list, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
                               (float*)(ib + IL.final_T), out_color, out_depth, out_normal, out_alpha,
                               a->E > 0 ? out_extra : nullptr, s);
 }
@@ -217,7 +224,7 @@ int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size
   uint32_t* point_offsets = (uint32_t*)(gb + L.point_offsets);
   if (a->N > 0) {
     if (int e = launch_preprocess(c, a, (float*)(gb + L.rec2d), (float*)(gb + L.cov3d), tiles_touched,
-                                  (uint32_t*)(gb + L.flags), radii, s)) return e;
+                                  (uint32_t*)(gb + L.flags), (float*)(gb + L.cull_thr), radii, s)) return e;
     size_t tmp = L.scan_temp_bytes;
     INSTAG_CHECK_HIP(rocprim::inclusive_scan(gb + L.scan_temp, tmp, tiles_touched, point_offsets, (size_t)a->N,
                                              rocprim::plus<uint32_t>(), s));
@@ -252,8 +259,8 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
   float* inst_grad = (float*)workspace;
   INSTAG_CHECK_HIP(hipMemsetAsync(inst_grad, 0, need, s));
   if (R > 0) {
-    if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.vals),
-                                      (const float*)(gb + GL.rec2d), (const uint32_t*)(ib + IL.n_contrib),
+    if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
+                                      (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d), (const uint32_t*)(ib + IL.n_contrib),
                                       (const float*)(ib + IL.final_T), dL_dout_color, dL_dout_depth,
                                       dL_dout_normal, dL_dout_alpha, a->E > 0 ? dL_dout_extra : nullptr,
                                       inst_grad, s)) return e;
@@ -289,7 +296,7 @@ int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* 
   if (binning && R > 0) {
     if (binning_bytes < BL.total) { set_error("binning buffer too small"); return INSTAG_E_SPACE; }
     INSTAG_CHECK_HIP(cp(keys_sorted, bb + BL.keys, (size_t)R * 8));
-    INSTAG_CHECK_HIP(cp(point_list, bb + BL.vals, (size_t)R * 4));
+    INSTAG_CHECK_HIP(cp(point_list, bb + BL.point_list, (size_t)R * 4));
   }
   if (image) {
     if (image_bytes < IL.total) { set_error("image buffer too small"); return INSTAG_E_SPACE; }

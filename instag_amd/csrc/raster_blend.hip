@@ -10,7 +10,7 @@
 //
 // Backward is deterministic and atomic-free: every (tile, Gaussian) instance owns one 64-byte
 // gradient row in `inst_grad` (slot = Gaussian's exclusive instance offset + position of the tile
-// inside its rectangle).  The reduction of a Gaussian's gradient over the 256 pixels of the tile runs
+// among the Gaussian's kept tiles).  The reduction of a Gaussian's gradient over the 256 pixels of the tile runs
 // as two small fp32 GEMMs on the matrix cores (see blend_backward_kernel) and the row is written once
 // with plain 16-byte stores.  The per-Gaussian sum over its rows happens in raster_backward.hip.
 #include "raster_internal.hpp"
@@ -124,7 +124,7 @@ constexpr int WROW = 68;        // floats per (pixel-quarter, Gaussian) row of t
 template <bool FULL>            // FULL: depth / normal / extra channels carry gradient too; else rgb only
 __global__ void __launch_bounds__(BLOCK)
 blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
-                      const float* __restrict__ rec2d, const uint32_t* __restrict__ n_contrib,
+                      const uint32_t* __restrict__ slot_list, const float* __restrict__ rec2d, const uint32_t* __restrict__ n_contrib,
                       const float* __restrict__ final_T, const float* __restrict__ dL_dcolor,
                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dnormal,
                       const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
@@ -210,6 +210,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     const uint32_t gid = point_list[start + (n - 1) - tid];
     const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
     nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
+    nrec3.z = __uint_as_float(slot_list[start + (n - 1) - tid]);   // the instance's gradient row
   }
   for (int i = 0; i < rounds; ++i) {
     __syncthreads();                          // previous batch fully consumed (s_rec, s_W/s_T, s_res, s_F)
@@ -225,6 +226,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
         const uint32_t gid = point_list[start + nbase - tid];
         const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
         nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
+        nrec3.z = __uint_as_float(slot_list[start + nbase - tid]);
       }
     }
     // ---- phase A: advance the per-pixel recurrence, emit w and t (branch-free, unrolled) ------------------
@@ -288,10 +290,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       r4[1] = make_float4(-0.5f * op * tdyy, S0, Dw[0], Dw[1]);
       r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);
       r4[3] = make_float4(Dw[6], Dw[7], 0.f, 0.f);
-      const uint32_t off = __float_as_uint(s_rec[tid][3].z);
-      const uint32_t rect = __float_as_uint(s_rec[tid][3].w);
-      const uint32_t rminx = rect & 1023u, rminy = (rect >> 10) & 1023u, rw = rect >> 20;
-      const uint32_t slot = off + ((uint32_t)ty - rminy) * rw + ((uint32_t)tx - rminx);
+      const uint32_t slot = __float_as_uint(s_rec[tid][3].z);
       float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)slot * REC_FLOATS);
       dst[0] = r4[0]; dst[1] = r4[1]; dst[2] = r4[2]; dst[3] = r4[3];
     }
@@ -314,7 +313,7 @@ int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t*
 }
 
 int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
-                          const float* rec2d, const uint32_t* n_contrib, const float* final_T,
+                          const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
                           hipStream_t s) {
@@ -322,10 +321,10 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
   if (tiles == 0) return INSTAG_OK;
   ProfScope p(K_BLEND_BWD, s);
   if (dL_ddepth || dL_dnormal || dL_dextra)
-    blend_backward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, dL_dcolor,
+    blend_backward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T, dL_dcolor,
                                                         dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad);
   else
-    blend_backward_kernel<false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, dL_dcolor,
+    blend_backward_kernel<false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T, dL_dcolor,
                                                          dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;

@@ -15,11 +15,12 @@ Camera make_camera(const instag_raster_args* a);
 
 // raster_preprocess.hip (built with -ffp-contract=off: bit-exact against the oracle)
 int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
-                      uint32_t* tiles_touched, uint32_t* flags, int32_t* radii, hipStream_t s);
+                      uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, int32_t* radii, hipStream_t s);
 int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* tiles_touched,
-                     const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, uint32_t capacity,
-                     hipStream_t s);
-int launch_ranges(int64_t R, const uint64_t* keys_sorted, int32_t* ranges, uint32_t ntiles, hipStream_t s);
+                     const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint64_t* keys,
+                     uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, hipStream_t s);
+int launch_ranges(int64_t R, const uint64_t* keys_sorted, const uint32_t* slots_sorted, const uint32_t* gid_unsorted,
+                  uint32_t* point_list, int32_t* ranges, uint32_t ntiles, hipStream_t s);
 int launch_status(int N, const uint32_t* point_offsets, uint32_t capacity, int32_t* status, hipStream_t s);
 
 // raster_blend.hip
@@ -28,7 +29,7 @@ int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t*
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
                          hipStream_t s);
 int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
-                          const float* rec2d, const uint32_t* n_contrib, const float* final_T,
+                          const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
                           hipStream_t s);

@@ -21,6 +21,29 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
                                        0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
                                        -0.5900435899266435f};
 
+// Exact tile culling.  A Gaussian can only contribute to a pixel where alpha = o*exp(-q/2) >= 1/255, i.e. where
+// q(d) = A dx^2 + 2 B dx dy + C dy^2 <= 2 ln(255 o).  A tile of the bounding rectangle is kept iff the minimum of q
+// over the rectangle spanned by the tile's pixel centres is <= thr = 2 ln(255 o) * 1.001 + 0.001 (the margin keeps
+// the test conservative under fp32 rounding: no contributing (tile, Gaussian) pair is ever dropped, so images and
+// gradients are unchanged, only the instance lists get shorter).  Same fp32 operation order as
+// oracle/rasterize_ref.py::tile_keep_mask.
+__device__ __forceinline__ bool tile_kept(float px, float py, float A, float B, float C, float thr, int tx, int ty) {
+  const float x0 = (float)(tx * TILE_X), y0 = (float)(ty * TILE_Y);
+  const float dxl = x0 - px, dxr = (x0 + (float)(TILE_X - 1)) - px;
+  const float dyl = y0 - py, dyr = (y0 + (float)(TILE_Y - 1)) - py;
+  if (dxl <= 0.f && dxr >= 0.f && dyl <= 0.f && dyr >= 0.f) return true;   // centre inside the tile
+  const float B2 = 2.0f * B;
+  const float ya = fminf(fmaxf(-(B * dxl) / C, dyl), dyr);
+  const float yb = fminf(fmaxf(-(B * dxr) / C, dyl), dyr);
+  const float xa = fminf(fmaxf(-(B * dyl) / A, dxl), dxr);
+  const float xb = fminf(fmaxf(-(B * dyr) / A, dxl), dxr);
+  const float e1 = ((A * dxl) * dxl + (B2 * dxl) * ya) + (C * ya) * ya;
+  const float e2 = ((A * dxr) * dxr + (B2 * dxr) * yb) + (C * yb) * yb;
+  const float e3 = ((A * xa) * xa + (B2 * xa) * dyl) + (C * dyl) * dyl;
+  const float e4 = ((A * xb) * xb + (B2 * xb) * dyr) + (C * dyr) * dyr;
+  return fminf(fminf(e1, e2), fminf(e3, e4)) <= thr;
+}
+
 struct PreIn {
   const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *extra;
 };
@@ -28,7 +51,7 @@ struct PreIn {
 __global__ void __launch_bounds__(256)
 preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restrict__ cov3d,
                   uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ flags_out,
-                  int32_t* __restrict__ radii) {
+                  float* __restrict__ cull_thr, int32_t* __restrict__ radii) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= c.N) return;
   radii[g] = 0;
@@ -181,27 +204,37 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
     cr = in.colors[3 * g + 0]; cg = in.colors[3 * g + 1]; cb = in.colors[3 * g + 2];
   }
 
+  // instances = tiles of the rectangle that the alpha >= 1/255 ellipse can reach
+  const float op = in.opac[g];
+  const float thr = (float)(2.0 * log(255.0 * (double)op) * 1.001 + 0.001);
+  int kept = 0;
+  if (thr >= 0.0f) {
+    for (int ty_ = rminy; ty_ < rmaxy; ++ty_)
+      for (int tx_ = rminx; tx_ < rmaxx; ++tx_) kept += tile_kept(pix_x, pix_y, conA, conB, conC, thr, tx_, ty_) ? 1 : 0;
+  }
+  cull_thr[g] = thr;
   radii[g] = radius;
-  tiles_touched[g] = (uint32_t)tiles;
-  flags_out[g] = flags;
+  tiles_touched[g] = (uint32_t)kept;
+  flags_out[g] = flags | ((uint32_t)(rmaxy - rminy) << 16);   // bits 16..31: rectangle height in tiles
   float* c3 = cov3d + (size_t)g * 6;
   c3[0] = S00; c3[1] = S01; c3[2] = S02; c3[3] = S11; c3[4] = S12; c3[5] = S22;
 
   float4* rec = reinterpret_cast<float4*>(rec2d + (size_t)g * REC_FLOATS);
   const uint32_t rect = (uint32_t)rminx | ((uint32_t)rminy << 10) | ((uint32_t)(rmaxx - rminx) << 20);
   rec[0] = make_float4(pix_x, pix_y, conA, conB);
-  rec[1] = make_float4(conC, in.opac[g], cr, cg);
+  rec[1] = make_float4(conC, op, cr, cg);
   rec[2] = make_float4(cb, tz, nvx, nvy);
   rec[3] = make_float4(nvz, (c.E > 0 && in.extra) ? in.extra[g] : 0.0f, 0.0f, __uint_as_float(rect));
 }
 
-// One thread per Gaussian: emit (tile<<32 | depth bits, gaussian id) for every touched tile and
-// record the exclusive instance offset in the blend record (used by blend-backward to address the
-// per-instance gradient row without an index array).
+// One thread per Gaussian: emit (tile<<32 | depth bits) for every KEPT tile of its rectangle.  The sorted value
+// is the instance's own unsorted slot u (also the row of its gradient in blend-backward); gid_unsorted[u] maps
+// the slot back to the Gaussian.  The exclusive instance offset is recorded in the blend record.
 __global__ void __launch_bounds__(256)
 duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ tiles_touched,
-                 const uint32_t* __restrict__ point_offsets, uint64_t* __restrict__ keys,
-                 uint32_t* __restrict__ vals, uint32_t capacity) {
+                 const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ flags,
+                 const float* __restrict__ cull_thr, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                 uint32_t* __restrict__ gid_unsorted, uint32_t capacity) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= N) return;
   const uint32_t tt = tiles_touched[g];
@@ -212,22 +245,27 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
   const uint32_t rect = __float_as_uint(rec[R_RECT]);
   const uint32_t depth_bits = __float_as_uint(rec[R_DEPTH]);
   rec[R_OFFSET] = __uint_as_float(off);
-  const uint32_t rminx = rect & 1023u, rminy = (rect >> 10) & 1023u, rw = rect >> 20;
-  const uint32_t rh = tt / rw;
-  for (uint32_t y = rminy; y < rminy + rh; ++y) {
-    for (uint32_t x = rminx; x < rminx + rw; ++x) {
-      const uint64_t key = ((uint64_t)(y * (uint32_t)grid_x + x) << 32) | depth_bits;
-      keys[off] = key;
-      vals[off] = (uint32_t)g;
+  const int rminx = (int)(rect & 1023u), rminy = (int)((rect >> 10) & 1023u), rw = (int)(rect >> 20);
+  const int rh = (int)(flags[g] >> 16);
+  const float px = rec[R_X], py = rec[R_Y], A = rec[R_CA], B = rec[R_CB], C = rec[R_CC], thr = cull_thr[g];
+  for (int y = rminy; y < rminy + rh; ++y) {
+    for (int x = rminx; x < rminx + rw; ++x) {
+      if (!tile_kept(px, py, A, B, C, thr, x, y)) continue;
+      keys[off] = ((uint64_t)(uint32_t)(y * grid_x + x) << 32) | depth_bits;
+      vals[off] = off;
+      gid_unsorted[off] = (uint32_t)g;
       ++off;
     }
   }
 }
 
 __global__ void __launch_bounds__(256)
-ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, int32_t* __restrict__ ranges, uint32_t ntiles) {
+ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ slots_sorted,
+              const uint32_t* __restrict__ gid_unsorted, uint32_t* __restrict__ point_list,
+              int32_t* __restrict__ ranges, uint32_t ntiles) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
+  if ((uint32_t)(keys[i] >> 32) < ntiles) point_list[i] = gid_unsorted[slots_sorted[i]];
   // tile ids >= ntiles are the all-ones padding keys of capacity mode: they sort last and own no range
   const uint32_t tile = (uint32_t)(keys[i] >> 32);
   if (i == 0) {
@@ -267,31 +305,33 @@ Camera make_camera(const instag_raster_args* a) {
 }
 
 int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
-                      uint32_t* tiles_touched, uint32_t* flags, int32_t* radii, hipStream_t s) {
+                      uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, int32_t* radii, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   PreIn in{a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales, a->rotations,
            a->cov3Ds_precomp, a->extra_attrs};
   ProfScope p(K_PREPROCESS, s);
-  preprocess_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, in, rec2d, cov3d, tiles_touched, flags, radii);
+  preprocess_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, in, rec2d, cov3d, tiles_touched, flags, cull_thr, radii);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
 int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* tiles_touched,
-                     const uint32_t* point_offsets, uint64_t* keys, uint32_t* vals, uint32_t capacity,
-                     hipStream_t s) {
+                     const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint64_t* keys,
+                     uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_DUPLICATE, s);
-  duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, tiles_touched, point_offsets,
-                                                     keys, vals, capacity);
+  duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, tiles_touched, point_offsets, flags,
+                                                     cull_thr, keys, vals, gid_unsorted, capacity);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
-int launch_ranges(int64_t R, const uint64_t* keys_sorted, int32_t* ranges, uint32_t ntiles, hipStream_t s) {
+int launch_ranges(int64_t R, const uint64_t* keys_sorted, const uint32_t* slots_sorted, const uint32_t* gid_unsorted,
+                  uint32_t* point_list, int32_t* ranges, uint32_t ntiles, hipStream_t s) {
   if (R == 0) return INSTAG_OK;
   ProfScope p(K_RANGES, s);
-  ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, keys_sorted, ranges, ntiles);
+  ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, keys_sorted, slots_sorted, gid_unsorted,
+                                                                  point_list, ranges, ntiles);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -11,7 +11,8 @@ The operator the reference calls at
 with the semantics of the published 3DGS rasterizer (Kerbl et al. 2023):
 preprocess (frustum cull z<=0.2, cov3D=R S S^T R^T, EWA cov2D with 1.3*tanfov
 clamp and +0.3 low-pass, conic, radius=ceil(3 sqrt(lambda_max)), 16x16 tile
-rect, SH->RGB +0.5 clamp>=0) -> per-tile lists sorted by (tile, depth) with a
+rect, SH->RGB +0.5 clamp>=0) -> per-tile lists (tiles of the rect that the alpha>=1/255
+ellipse can reach: exact tile culling, results unchanged) sorted by (tile, depth) with a
 stable sort -> front-to-back alpha blending (skip power>0, alpha=min(.99,o*G),
 skip alpha<1/255, stop when T(1-alpha)<1e-4).  The fork's extra outputs are
 constrained by the reference's call sites:
@@ -281,21 +282,60 @@ def preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotatio
     )
 
 
-def bin_and_sort(depth: torch.Tensor, rect: torch.Tensor, tiles_touched: torch.Tensor, grid):
-    """Duplicate each visible Gaussian per touched tile, stable-sort by (tile<<32 | depth bits)."""
-    grid_x, grid_y = grid
-    tt = tiles_touched.numpy().astype(np.int64)
-    offsets = np.cumsum(tt)                       # inclusive scan, like the device scan
-    R = int(offsets[-1]) if len(offsets) else 0
+def tile_keep_mask(px, py, A, B, C, thr, tx, ty):
+    """Exact tile culling (numpy fp32, same operation order as csrc/raster_preprocess.hip::tile_kept).
+
+    A (tile, Gaussian) pair is kept iff the minimum of q(d) = A dx^2 + 2 B dx dy + C dy^2 over the rectangle of
+    the tile's pixel centres is <= thr = 2 ln(255 o) * 1.001 + 0.001, i.e. iff some pixel of the tile can reach
+    alpha >= 1/255 (conservatively): dropped pairs contribute nothing to any pixel."""
+    f = np.float32
+    x0 = (tx * BLOCK_X).astype(f)
+    y0 = (ty * BLOCK_Y).astype(f)
+    dxl, dxr = x0 - px, (x0 + f(BLOCK_X - 1)) - px
+    dyl, dyr = y0 - py, (y0 + f(BLOCK_Y - 1)) - py
+    inside = (dxl <= 0) & (dxr >= 0) & (dyl <= 0) & (dyr >= 0)
+    B2 = f(2.0) * B
+    with np.errstate(all="ignore"):
+        ya = np.minimum(np.maximum(-(B * dxl) / C, dyl), dyr)
+        yb = np.minimum(np.maximum(-(B * dxr) / C, dyl), dyr)
+        xa = np.minimum(np.maximum(-(B * dyl) / A, dxl), dxr)
+        xb = np.minimum(np.maximum(-(B * dyr) / A, dxl), dxr)
+        e1 = ((A * dxl) * dxl + (B2 * dxl) * ya) + (C * ya) * ya
+        e2 = ((A * dxr) * dxr + (B2 * dxr) * yb) + (C * yb) * yb
+        e3 = ((A * xa) * xa + (B2 * xa) * dyl) + (C * dyl) * dyl
+        e4 = ((A * xb) * xb + (B2 * xb) * dyr) + (C * dyr) * dyr
+        qmin = np.minimum(np.minimum(e1, e2), np.minimum(e3, e4))
+    return (thr >= 0) & (inside | (qmin <= thr))
+
+
+def bin_and_sort(pre: dict):
+    """Emit one instance per KEPT tile of each visible Gaussian's rectangle (row-major inside the rectangle),
+    stable-sort by (tile<<32 | depth bits)."""
+    grid_x, grid_y = pre["grid"]
+    depth, rect = pre["depth"], pre["rect"]
+    area = pre["tiles_touched"].numpy().astype(np.int64)            # rectangle area of visible Gaussians
     rect_np = rect.numpy()
+    n = len(area)
+    cand_g = np.repeat(np.arange(n, dtype=np.int64), area)
+    starts = np.repeat(np.cumsum(area) - area, area)
+    local = np.arange(len(cand_g), dtype=np.int64) - starts
+    rw = (rect_np[:, 2] - rect_np[:, 0]).astype(np.int64)[cand_g]
+    ty = rect_np[cand_g, 1].astype(np.int64) + local // np.maximum(rw, 1)
+    txx = rect_np[cand_g, 0].astype(np.int64) + local % np.maximum(rw, 1)
+    xy = pre["xy"].detach().numpy().astype(np.float32)
+    con = pre["conic"].detach().numpy().astype(np.float32)
+    op64 = pre["opacity"].detach().numpy().astype(np.float64)
+    with np.errstate(all="ignore"):
+        thr = (2.0 * np.log(255.0 * op64) * 1.001 + 0.001).astype(np.float32)
+    thr = np.where(np.isfinite(thr), thr, np.float32(-1.0))
+    keep = tile_keep_mask(xy[cand_g, 0], xy[cand_g, 1], con[cand_g, 0], con[cand_g, 1], con[cand_g, 2],
+                          thr[cand_g], txx, ty)
+    gids = cand_g[keep]
+    tt = np.bincount(gids, minlength=n).astype(np.int64)           # instances per Gaussian after culling
+    offsets = np.cumsum(tt)                                         # inclusive scan, like the device scan
+    R = int(offsets[-1]) if n else 0
     dbits = depth.detach().numpy().astype(np.float32).view(np.uint32).astype(np.uint64)
-    gids = np.repeat(np.arange(len(tt), dtype=np.int64), tt)
-    starts = np.repeat(offsets - tt, tt)
-    local = np.arange(R, dtype=np.int64) - starts
-    rw = (rect_np[:, 2] - rect_np[:, 0]).astype(np.int64)[gids]
-    ty = rect_np[gids, 1].astype(np.int64) + local // np.maximum(rw, 1)
-    txx = rect_np[gids, 0].astype(np.int64) + local % np.maximum(rw, 1)
-    tile = (ty * grid_x + txx).astype(np.uint64)
+    tile = (ty[keep] * grid_x + txx[keep]).astype(np.uint64)
     keys = (tile << np.uint64(32)) | dbits[gids]
     order = np.argsort(keys, kind="stable")
     keys_sorted = keys[order]
@@ -307,7 +347,7 @@ def bin_and_sort(depth: torch.Tensor, rect: torch.Tensor, tiles_touched: torch.T
     ranges = np.stack([starts_t, ends_t], axis=1).astype(np.int32)
     ranges[starts_t == ends_t] = 0                 # tiles with no instance keep the zero-filled range
     return dict(R=R, offsets=offsets.astype(np.int64), keys_unsorted=keys, keys=keys_sorted,
-                point_list=point_list, ranges=ranges)
+                point_list=point_list, ranges=ranges, tiles_touched=tt, candidates=int(len(cand_g)))
 
 
 ALPHA_MIN = float(F32(1.0) / F32(255.0))
@@ -396,7 +436,7 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
         raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
     pre = preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                      cov3Ds_precomp, extra_attrs, settings)
-    binning = bin_and_sort(pre["depth"], pre["rect"], pre["tiles_touched"], pre["grid"])
+    binning = bin_and_sort(pre)
     image, depth, normal, alpha, extra, final_T, n_contrib = blend(pre, binning, settings)
     outs = (image, depth, normal, alpha, pre["radii"], extra)
     if return_aux:
