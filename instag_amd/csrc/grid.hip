@@ -14,6 +14,8 @@
 //    flushes each non-zero cell with ONE global atomic per workgroup, instead of one contended
 //    global atomic per (point, corner) -- 100k points x 4 corners into <=1600 cells otherwise;
 //  * the input gradient (kernel_input_backward) is fused into the same pass.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace instag {
@@ -363,7 +365,10 @@ grid_tv_kernel(const float* __restrict__ inputs, const float* __restrict__ grid,
 }
 
 inline unsigned fwd_blocks(uint32_t B) { return (unsigned)std::min<uint32_t>(div_up<uint32_t>(B, GRID_BLOCK), 2048u); }
-inline unsigned bwd_blocks(uint32_t B) { return (unsigned)std::min<uint32_t>(div_up<uint32_t>(B, GRID_BLOCK), 512u); }
+inline unsigned bwd_blocks(uint32_t B) {
+  static const unsigned cap = getenv("INSTAG_GRID_BWD_BLOCKS") ? (unsigned)atoi(getenv("INSTAG_GRID_BWD_BLOCKS")) : 256u;
+  return (unsigned)std::min<uint32_t>(div_up<uint32_t>(B, GRID_BLOCK), cap);
+}
 
 template <uint32_t D, uint32_t C>
 int run_forward(const float* inputs, const float* emb, const int32_t* offsets, float* outputs, uint32_t B,
@@ -486,29 +491,47 @@ __device__ __forceinline__ void plane_coords(int plane, const float p[3], float 
   x[1] = plane == 0 ? p[1] : p[2];
 }
 
+// per-level constants, computed once per workgroup (every level of a tri-plane table is dense: index = x + y*(res+1))
+struct TpLevel { float scale; uint32_t stride, offset; };
+
+__device__ __forceinline__ void tp_levels(const TriPlaneArgs& a, TpLevel* s_lv) {
+  if (threadIdx.x < a.L) {
+    const LevelGeom lg = level_geom(a.offsets, threadIdx.x, a.S, a.H);
+    s_lv[threadIdx.x] = TpLevel{lg.scale, lg.resolution + 1, (uint32_t)a.offsets[threadIdx.x]};
+  }
+}
+
 __global__ void __launch_bounds__(GRID_BLOCK)
 triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
   extern __shared__ __align__(16) float s_tab[];
+  __shared__ TpLevel s_lv[TP_MAX_L];
   const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;
   const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
   const uint32_t T = (uint32_t)a.offsets[a.L];
   const float inv2b = 1.0f / (2.0f * a.bound);
+  tp_levels(a, s_lv);
   for (int plane = 0; plane < 3; ++plane) {
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < T; i += GRID_BLOCK) s_tab[i] = a.tables[plane][i];
     __syncthreads();
     for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
       const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
-      float xw[2], x[2];
+      float xw[2];
       plane_coords(plane, p, xw);
-      x[0] = (xw[0] + a.bound) * inv2b;
-      x[1] = (xw[1] + a.bound) * inv2b;
-      const bool oob = x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f;
+      const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
+      const bool oob = x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f;
       float* o = out + (size_t)b * 3 * a.L + plane * a.L;
       for (uint32_t l = 0; l < a.L; ++l) {
-        const LevelGeom lg = level_geom(a.offsets, l, a.S, a.H);
-        float v;
-        encode_level<2, 1>(s_tab + (uint32_t)a.offsets[l], lg, x, oob, 0u, false, 0u, &v, nullptr);
+        float v = 0.f;
+        if (!oob) {
+          const TpLevel lv = s_lv[l];
+          const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
+          const float flx = floorf(px), fly = floorf(py);
+          const float fx = px - flx, fy = py - fly;
+          const float* tab = s_tab + lv.offset + (uint32_t)flx + (uint32_t)fly * lv.stride;
+          const float v00 = tab[0], v10 = tab[1], v01 = tab[lv.stride], v11 = tab[lv.stride + 1];
+          v = ((1.f - fx) * (1.f - fy)) * v00 + (fx * (1.f - fy)) * v10 + ((1.f - fx) * fy) * v01 + (fx * fy) * v11;
+        }
         o[l] = v;
       }
     }
@@ -522,9 +545,11 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
   const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;
   const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
   const uint32_t T = (uint32_t)a.offsets[a.L];
+  __shared__ TpLevel s_lv[TP_MAX_L];
   float* s_tab = s_mem;
   float* s_acc = s_mem + T;
   const float inv2b = 1.0f / (2.0f * a.bound);
+  tp_levels(a, s_lv);
   // this thread's points: at most ceil(per_block / GRID_BLOCK); d/dxyz is accumulated across the three planes in
   // global memory (plain read-modify-write: each point is owned by exactly one thread of one block)
   for (int plane = 0; plane < 3; ++plane) {
@@ -543,28 +568,22 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
       const float* g = grad + (size_t)b * 3 * a.L + plane * a.L;
       float gx = 0.f, gy = 0.f;
       for (uint32_t l = 0; l < a.L; ++l) {
-        const LevelGeom lg = level_geom(a.offsets, l, a.S, a.H);
+        const TpLevel lv = s_lv[l];
         const float gl = g[l];
-        const float* tab = s_tab + (uint32_t)a.offsets[l];
-        float* acc = s_acc + (uint32_t)a.offsets[l];
-        float pos[2], pos_deriv[2];
-        uint32_t pg[2];
-        locate<2>(x, lg.scale, false, 0u, pos, pos_deriv, pg);
-        uint32_t c00[2] = {pg[0], pg[1]}, c10[2] = {pg[0] + 1, pg[1]}, c01[2] = {pg[0], pg[1] + 1}, c11[2] = {pg[0] + 1, pg[1] + 1};
-        const uint32_t i00 = grid_index<2>(0u, false, lg.hashmap_size, lg.resolution, c00);
-        const uint32_t i10 = grid_index<2>(0u, false, lg.hashmap_size, lg.resolution, c10);
-        const uint32_t i01 = grid_index<2>(0u, false, lg.hashmap_size, lg.resolution, c01);
-        const uint32_t i11 = grid_index<2>(0u, false, lg.hashmap_size, lg.resolution, c11);
-        const float fx = pos[0], fy = pos[1];
-        __hip_atomic_fetch_add(&acc[i00], (1.f - fx) * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[i10], fx * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[i01], (1.f - fx) * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[i11], fx * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const float px = x[0] * lv.scale + 0.5f, py = x[1] * lv.scale + 0.5f;
+        const float flx = floorf(px), fly = floorf(py);
+        const float fx = px - flx, fy = py - fly;
+        const uint32_t i00 = lv.offset + (uint32_t)flx + (uint32_t)fly * lv.stride;
+        const uint32_t i10 = i00 + 1, i01 = i00 + lv.stride, i11 = i01 + 1;
+        __hip_atomic_fetch_add(&s_acc[i00], (1.f - fx) * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_acc[i10], fx * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_acc[i01], (1.f - fx) * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&s_acc[i11], fx * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (dxyz) {
-          const float v00 = tab[i00], v10 = tab[i10], v01 = tab[i01], v11 = tab[i11];
+          const float v00 = s_tab[i00], v10 = s_tab[i10], v01 = s_tab[i01], v11 = s_tab[i11];
           // dy_dx of kernel_grid (gridencoder.cu:201-244) for D=2, linear interpolation
-          gx += gl * lg.scale * ((1.f - fy) * (v10 - v00) + fy * (v11 - v01));
-          gy += gl * lg.scale * ((1.f - fx) * (v01 - v00) + fx * (v11 - v10));
+          gx += gl * lv.scale * ((1.f - fy) * (v10 - v00) + fy * (v11 - v01));
+          gy += gl * lv.scale * ((1.f - fx) * (v01 - v00) + fx * (v11 - v10));
         }
       }
       if (dxyz) {

@@ -190,7 +190,14 @@ def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
                and e.base_resolution == e0.base_resolution and e.per_level_scale == e0.per_level_scale
                and e.gridtype_id == 0 and not e.align_corners and e.interp_id == 0
                and e.embeddings.shape == e0.embeddings.shape and e.embeddings.is_cuda for e in encs)
-    return same and e0.num_levels <= 16 and e0.embeddings.shape[0] * 4 <= 64 * 1024
+    if not (same and e0.num_levels <= 16 and e0.embeddings.shape[0] * 4 <= 64 * 1024):
+        return False
+    # the fused kernels index every level densely (x + y*(res+1)): no level may be hashed
+    for i in range(e0.num_levels):
+        res = int(np.ceil(e0.base_resolution * e0.per_level_scale ** i))
+        if (res + 1) ** 2 > e0.max_params:
+            return False
+    return True
 
 
 def tri_plane_encode(xyz, enc_xy, enc_yz, enc_xz, bound):
