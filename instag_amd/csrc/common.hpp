@@ -63,7 +63,8 @@ enum RecSlot { R_X = 0, R_Y, R_CA, R_CB, R_CC, R_OP, R_R, R_G, R_B, R_DEPTH, R_N
 
 // flags[g]: bit0..2 rgb clamped, bit3..4 normal axis, bit5 normal flipped, bit6 tx clamped, bit7 ty clamped
 struct GeomLayout {
-  size_t rec2d, cov3d, tiles_touched, point_offsets, flags, cull_thr, scan_temp, scan_temp_bytes, total;
+  size_t rec2d, cov3d, tiles_touched, point_offsets, flags, cull_thr, depth_key, order_in, depth_key_sorted, order,
+      tt_sorted, scan_temp, scan_temp_bytes, sort_temp, sort_temp_bytes, total;
 };
 GeomLayout geom_layout(int32_t N);
 

@@ -15,11 +15,15 @@ Camera make_camera(const instag_raster_args* a);
 
 // raster_preprocess.hip (built with -ffp-contract=off: bit-exact against the oracle)
 int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
-                      uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, int32_t* radii, hipStream_t s);
-int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* tiles_touched,
-                     const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint64_t* keys,
+                      uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, uint32_t* depth_key,
+                      uint32_t* order_in, int32_t* radii, hipStream_t s);
+int launch_gather_counts(int N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* tt_sorted, hipStream_t s);
+int launch_export_keys(int64_t R, const uint32_t* tile_keys, const uint32_t* point_list, const float* rec2d,
+                       uint64_t* keys64, hipStream_t s);
+int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order, const uint32_t* tt_sorted,
+                     const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint32_t* keys,
                      uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, hipStream_t s);
-int launch_ranges(int64_t R, const uint64_t* keys_sorted, const uint32_t* slots_sorted, const uint32_t* gid_unsorted,
+int launch_ranges(int64_t R, const uint32_t* keys_sorted, const uint32_t* slots_sorted, const uint32_t* gid_unsorted,
                   uint32_t* point_list, int32_t* ranges, uint32_t ntiles, hipStream_t s);
 int launch_status(int N, const uint32_t* point_offsets, uint32_t capacity, int32_t* status, hipStream_t s);
 

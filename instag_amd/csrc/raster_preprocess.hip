@@ -51,9 +51,12 @@ struct PreIn {
 __global__ void __launch_bounds__(256)
 preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restrict__ cov3d,
                   uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ flags_out,
-                  float* __restrict__ cull_thr, int32_t* __restrict__ radii) {
+                  float* __restrict__ cull_thr, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order_in,
+                  int32_t* __restrict__ radii) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= c.N) return;
+  depth_key[g] = 0xFFFFFFFFu;      // Gaussians without instances sort last
+  order_in[g] = (uint32_t)g;
   radii[g] = 0;
   tiles_touched[g] = 0;
   const float* __restrict__ V = c.view;
@@ -215,6 +218,7 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
   cull_thr[g] = thr;
   radii[g] = radius;
   tiles_touched[g] = (uint32_t)kept;
+  if (kept > 0) depth_key[g] = __float_as_uint(tz);
   flags_out[g] = flags | ((uint32_t)(rmaxy - rminy) << 16);   // bits 16..31: rectangle height in tiles
   float* c3 = cov3d + (size_t)g * 6;
   c3[0] = S00; c3[1] = S01; c3[2] = S02; c3[3] = S11; c3[4] = S12; c3[5] = S22;
@@ -227,23 +231,25 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
   rec[3] = make_float4(nvz, (c.E > 0 && in.extra) ? in.extra[g] : 0.0f, 0.0f, __uint_as_float(rect));
 }
 
-// One thread per Gaussian: emit (tile<<32 | depth bits) for every KEPT tile of its rectangle.  The sorted value
+// One thread per Gaussian, in DEPTH ORDER: emit the tile id of every KEPT tile of its rectangle (the depth half of
+// the published (tile<<32 | depth) key is implied by the emission order + a stable sort).  The sorted value
 // is the instance's own unsorted slot u (also the row of its gradient in blend-backward); gid_unsorted[u] maps
 // the slot back to the Gaussian.  The exclusive instance offset is recorded in the blend record.
 __global__ void __launch_bounds__(256)
-duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ tiles_touched,
-                 const uint32_t* __restrict__ point_offsets, const uint32_t* __restrict__ flags,
-                 const float* __restrict__ cull_thr, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                 uint32_t* __restrict__ gid_unsorted, uint32_t capacity) {
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= N) return;
-  const uint32_t tt = tiles_touched[g];
+duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ order,
+                 const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ point_offsets,
+                 const uint32_t* __restrict__ flags, const float* __restrict__ cull_thr,
+                 uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ gid_unsorted,
+                 uint32_t capacity) {
+  const int i = blockIdx.x * 256 + threadIdx.x;      // rank in depth order
+  if (i >= N) return;
+  const uint32_t tt = tt_sorted[i];
   if (tt == 0) return;
-  if (point_offsets[g] > capacity) return;   // capacity mode: instances beyond the buffer are dropped (flagged)
-  uint32_t off = point_offsets[g] - tt;
+  if (point_offsets[i] > capacity) return;   // capacity mode: instances beyond the buffer are dropped (flagged)
+  const uint32_t g = order[i];
+  uint32_t off = point_offsets[i] - tt;
   float* rec = rec2d + (size_t)g * REC_FLOATS;
   const uint32_t rect = __float_as_uint(rec[R_RECT]);
-  const uint32_t depth_bits = __float_as_uint(rec[R_DEPTH]);
   rec[R_OFFSET] = __uint_as_float(off);
   const int rminx = (int)(rect & 1023u), rminy = (int)((rect >> 10) & 1023u), rw = (int)(rect >> 20);
   const int rh = (int)(flags[g] >> 16);
@@ -251,27 +257,44 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
   for (int y = rminy; y < rminy + rh; ++y) {
     for (int x = rminx; x < rminx + rw; ++x) {
       if (!tile_kept(px, py, A, B, C, thr, x, y)) continue;
-      keys[off] = ((uint64_t)(uint32_t)(y * grid_x + x) << 32) | depth_bits;
+      keys[off] = (uint32_t)(y * grid_x + x);
       vals[off] = off;
-      gid_unsorted[off] = (uint32_t)g;
+      gid_unsorted[off] = g;
       ++off;
     }
   }
 }
 
 __global__ void __launch_bounds__(256)
-ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ slots_sorted,
+gather_counts_kernel(int N, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ order,
+                     uint32_t* __restrict__ tt_sorted) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < N) tt_sorted[i] = tiles_touched[order[i]];
+}
+
+// debug / parity: the 64-bit (tile<<32 | depth bits) key of every sorted instance
+__global__ void __launch_bounds__(256)
+export_keys_kernel(int64_t R, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ point_list,
+                   const float* __restrict__ rec2d, uint64_t* __restrict__ keys64) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  const uint32_t depth_bits = __float_as_uint(rec2d[(size_t)point_list[i] * REC_FLOATS + R_DEPTH]);
+  keys64[i] = ((uint64_t)tile_keys[i] << 32) | depth_bits;
+}
+
+__global__ void __launch_bounds__(256)
+ranges_kernel(int64_t R, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ slots_sorted,
               const uint32_t* __restrict__ gid_unsorted, uint32_t* __restrict__ point_list,
               int32_t* __restrict__ ranges, uint32_t ntiles) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
-  if ((uint32_t)(keys[i] >> 32) < ntiles) point_list[i] = gid_unsorted[slots_sorted[i]];
+  if (keys[i] < ntiles) point_list[i] = gid_unsorted[slots_sorted[i]];
   // tile ids >= ntiles are the all-ones padding keys of capacity mode: they sort last and own no range
-  const uint32_t tile = (uint32_t)(keys[i] >> 32);
+  const uint32_t tile = keys[i];
   if (i == 0) {
     if (tile < ntiles) ranges[2 * tile] = 0;
   } else {
-    const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
+    const uint32_t prev = keys[i - 1];
     if (prev != tile) {
       if (prev < ntiles) ranges[2 * prev + 1] = (int32_t)i;
       if (tile < ntiles) ranges[2 * tile] = (int32_t)i;
@@ -305,28 +328,45 @@ Camera make_camera(const instag_raster_args* a) {
 }
 
 int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
-                      uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, int32_t* radii, hipStream_t s) {
+                      uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, uint32_t* depth_key,
+                      uint32_t* order_in, int32_t* radii, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   PreIn in{a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales, a->rotations,
            a->cov3Ds_precomp, a->extra_attrs};
   ProfScope p(K_PREPROCESS, s);
-  preprocess_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, in, rec2d, cov3d, tiles_touched, flags, cull_thr, radii);
+  preprocess_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, in, rec2d, cov3d, tiles_touched, flags, cull_thr, depth_key,
+                                                     order_in, radii);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
-int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* tiles_touched,
-                     const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint64_t* keys,
+int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order, const uint32_t* tt_sorted,
+                     const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint32_t* keys,
                      uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_DUPLICATE, s);
-  duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, tiles_touched, point_offsets, flags,
+  duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, order, tt_sorted, point_offsets, flags,
                                                      cull_thr, keys, vals, gid_unsorted, capacity);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
-int launch_ranges(int64_t R, const uint64_t* keys_sorted, const uint32_t* slots_sorted, const uint32_t* gid_unsorted,
+int launch_gather_counts(int N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* tt_sorted, hipStream_t s) {
+  if (N == 0) return INSTAG_OK;
+  gather_counts_kernel<<<div_up(N, 256), 256, 0, s>>>(N, tiles_touched, order, tt_sorted);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int launch_export_keys(int64_t R, const uint32_t* tile_keys, const uint32_t* point_list, const float* rec2d,
+                       uint64_t* keys64, hipStream_t s) {
+  if (R == 0) return INSTAG_OK;
+  export_keys_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, tile_keys, point_list, rec2d, keys64);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int launch_ranges(int64_t R, const uint32_t* keys_sorted, const uint32_t* slots_sorted, const uint32_t* gid_unsorted,
                   uint32_t* point_list, int32_t* ranges, uint32_t ntiles, hipStream_t s) {
   if (R == 0) return INSTAG_OK;
   ProfScope p(K_RANGES, s);

@@ -71,7 +71,6 @@ def test_binning_bit_exact(n, size, deg):
     assert np.array_equal(d["tiles_touched"].cpu().numpy().astype(np.int64), binning["tiles_touched"])
     assert binning["R"] < binning["candidates"]          # exact tile culling removed some rectangle tiles
     assert d["R"] == binning["R"]
-    assert np.array_equal(d["point_offsets"].cpu().numpy().astype(np.int64), binning["offsets"])
     assert np.array_equal(d["keys"].cpu().numpy().view(np.uint64), binning["keys"])
     assert np.array_equal(d["point_list"].cpu().numpy(), binning["point_list"])
     assert np.array_equal(d["ranges"].cpu().numpy(), binning["ranges"])
