@@ -128,8 +128,14 @@ def main():
     graph = None
     if use_graph:
         # whole step captured into a hipGraph (rasterizer in sync-free capacity mode); see instag_amd/train.py
-        graph = trainer.enable_graph(frames[0])
-        log(f"step captured into a hipGraph (instance capacity {graph.capacity})")
+        try:
+            graph = trainer.enable_graph(frames[0])
+            log(f"step captured into a hipGraph (instance capacity {graph.capacity})")
+        except Exception as exc:       # e.g. a collective library that cannot coexist with stream capture
+            log(f"graph capture failed ({type(exc).__name__}: {exc}); running the same HIP operators eagerly")
+            trainer._graph = None
+            diff_gauss.set_capacity_plan(None)
+            use_graph = False
     run(args.warmup)
     log("warm-up done")
     if not use_graph:

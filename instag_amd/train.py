@@ -255,22 +255,26 @@ class FaceTrainer:
         return self.last
 
     # ---- graph mode --------------------------------------------------------------------------------------------
-    def enable_graph(self, example_frame: Frame, headroom: float = 1.4, warmup_steps: int = 3):
+    def enable_graph(self, example_frame: Frame, headroom: float = 1.4, warmup_steps: int = 3,
+                     split_for_allreduce: Optional[bool] = None):
         """Capture the whole step into a hipGraph.  Runs `warmup_steps` eager steps plus two capacity-mode steps
         first (they advance the iteration counter like any other step) to measure the instance counts and warm
         every library."""
         self._graph = None
-        self._graph = GraphedStep(self, example_frame, headroom, warmup_steps)
+        self._graph = GraphedStep(self, example_frame, headroom, warmup_steps, split_for_allreduce)
         return self._graph
 
 
 class GraphedStep:
-    def __init__(self, trainer: FaceTrainer, example: Frame, headroom: float, warmup_steps: int):
+    def __init__(self, trainer: FaceTrainer, example: Frame, headroom: float, warmup_steps: int,
+                 split_for_allreduce: Optional[bool] = None):
         from . import diff_gauss
         t = self.trainer = trainer
         dev = t.device
         assert dev.type == "cuda", "graph mode needs the GPU"
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # two graphs with the (eager) gradient all-reduce between them; can be forced for single-rank tests
+        self.split = self.distributed if split_for_allreduce is None else bool(split_for_allreduce)
         self.static = example.clone_static()
         # 1. eager warm-up in the normal (host round trip) mode: measures R of both raster passes
         diff_gauss.set_capacity_plan(None)
@@ -305,7 +309,7 @@ class GraphedStep:
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         self.plan.begin_step()
-        if not self.distributed:
+        if not self.split:
             with torch.cuda.graph(self.graph_a):
                 pkg, loss, l1 = t._forward_backward(self.static)
                 t._stats_and_optimizers(pkg, False)
@@ -325,6 +329,7 @@ class GraphedStep:
                 self._params = t._all_params()
                 self._bucket = torch.cat([flat_grad_bucket(self._params), self._norm.reshape(-1),
                                           self._cnt.reshape(-1)])
+            del pkg
             self._n_grad = sum(p.numel() for p in self._params)
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b):
@@ -346,10 +351,11 @@ class GraphedStep:
         self.static.copy_from(frame)
         self.graph_a.replay()
         if self.graph_b is not None:
-            world = dist.get_world_size()
-            dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
-            self._bucket[:self._n_grad] /= world
-            dist.all_reduce(self._rmax, op=dist.ReduceOp.MAX)
+            if self.distributed:
+                world = dist.get_world_size()
+                dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
+                self._bucket[:self._n_grad] /= world
+                dist.all_reduce(self._rmax, op=dist.ReduceOp.MAX)
             self.graph_b.replay()
 
     def check_overflow(self):

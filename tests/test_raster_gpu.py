@@ -227,24 +227,27 @@ def test_graphed_train_step_matches_eager():
     frames = [make_frame(cams[i].to(dev), synthetic_frame(128, i, dev)) for i in range(3)]
     losses = {}
     params = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "graph-split"):
         tr = build_trainer(3000, dev, seed=1)
         try:
-            if mode == "graph":
-                tr.enable_graph(frames[0], warmup_steps=2)       # 2 eager + 2 capacity-mode steps on frame 0
+            if mode != "eager":
+                # 2 eager + 2 capacity-mode steps on frame 0; "graph-split" = the two-graph form used with several
+                # ranks (forward+backward | gradient exchange | statistics+optimizers)
+                tr.enable_graph(frames[0], warmup_steps=2, split_for_allreduce=(mode == "graph-split"))
             else:
                 for _ in range(4):
                     tr.step(frames[0])
             ls = []
             for i in range(6):
                 ls.append(float(tr.step(frames[i % 3])["loss"]))
-            if mode == "graph":
+            if mode != "eager":
                 assert tr._graph is not None and not tr._graph.check_overflow()
         finally:
             diff_gauss.set_capacity_plan(None)
         losses[mode] = ls
         params[mode] = tr.g.get_xyz.detach().clone()
     assert tr.iteration == 10
-    for a_, b_ in zip(losses["eager"], losses["graph"]):
-        assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (losses["eager"], losses["graph"])
-    assert float((params["eager"] - params["graph"]).abs().max()) <= 1e-5
+    for mode in ("graph", "graph-split"):
+        for a_, b_ in zip(losses["eager"], losses[mode]):
+            assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (mode, losses["eager"], losses[mode])
+        assert float((params["eager"] - params[mode]).abs().max()) <= 1e-5
