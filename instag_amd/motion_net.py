@@ -18,8 +18,8 @@ CONCURRENT_AUDIO = True       # fork the audio branch onto a second stream (para
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device):
-    key = (device.type, device.index)
+def _side_stream(device, index=0):
+    key = (device.type, device.index, index)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
@@ -153,17 +153,33 @@ class _TriPlaneField(nn.Module):
             return None
         return self.audio_att_net(self.audio_net(a).unsqueeze(0))
 
+    def start_audio(self, a, stream_index=0):
+        """Launch the audio branch now, on a side stream; the next forward(x, a, ...) with the same `a` picks it
+        up.  Lets the caller overlap the audio branches of several networks with earlier per-Gaussian work."""
+        if not (a.is_cuda and CONCURRENT_AUDIO):
+            return
+        main_stream = torch.cuda.current_stream(a.device)
+        side = _side_stream(a.device, stream_index)
+        side.wait_stream(main_stream)
+        with torch.cuda.stream(side):
+            enc_a = self.encode_audio(a)
+        self._audio_pending = (a, enc_a, side)
+
     def _trunk(self, x, a, e, c):
         """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim])"""
         fork = x.is_cuda and CONCURRENT_AUDIO
+        pending = self.__dict__.pop("_audio_pending", None)
         if fork:
             # the per-frame audio branch (~40 tiny kernels) only meets the per-Gaussian branch at the glue:
-            # run it on a second stream so it overlaps the tri-plane encode and the attention MLPs
+            # it runs on a second stream so it overlaps the tri-plane encode and the attention MLPs
             main_stream = torch.cuda.current_stream(x.device)
-            side = _side_stream(x.device)
-            side.wait_stream(main_stream)
-            with torch.cuda.stream(side):
-                enc_a = self.encode_audio(a)
+            if pending is not None and pending[0] is a:
+                enc_a, side = pending[1], pending[2]          # started early by start_audio()
+            else:
+                side = _side_stream(x.device)
+                side.wait_stream(main_stream)
+                with torch.cuda.stream(side):
+                    enc_a = self.encode_audio(a)
         enc_x = self.encode_x(x, bound=self.bound)
         if fork:
             aud_ch_att = self.aud_ch_att_net(enc_x)
