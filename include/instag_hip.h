@@ -229,6 +229,28 @@ int instag_motion_l1_reg_backward(const float* h, const float* p, const float* g
                                   int32_t N, instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-frame conditioning codes of one motion network, one workgroup per pass (csrc/audio.hip):
+ *   enc_a [dim_aud] = AudioAttNet(AudioNet(a))             scene/motion_net.py:29-64, :67-99
+ *   enc_e [6]       = cat(exp_encode_net(e[:5]), e[5:6])   scene/motion_net.py:152-173 (MLP 5->16->5, bias-free)
+ * a [8, dim_in, 16] (8 audio windows of 16 samples), e [6] or NULL (then enc_e NULL: network without the
+ * expression branch).  `params` / `grads` are HOST arrays of 26 DEVICE pointers in state_dict order:
+ *   0-7   audio_net.encoder_conv.{0,2,4,6}.{weight,bias}   conv1d k3 s2 p1: dim_in->mid->mid->64->64
+ *   8-11  audio_net.encoder_fc1.{0,2}.{weight,bias}        64->64 (LeakyReLU 0.02) ->dim_aud
+ *   12-21 audio_att_net.attentionConvNet.{0,2,4,6,8}.{weight,bias}   conv1d k3 s1 p1: dim_aud->16->8->4->2->1
+ *   22-23 audio_att_net.attentionNet.0.{weight,bias}       linear 8->8 (+ softmax)
+ *   24-25 exp_encode_net.net.{0,1}.weight                  [16,5], [5,16] (may be NULL when e is NULL)
+ * forward keeps every activation in `saved` (instag_frame_code_saved_floats floats); backward OVERWRITES
+ * every grads[i] (same shapes as params[i]); no gradient flows to a or e.  Deterministic (no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int64_t instag_frame_code_saved_floats(int32_t dim_in, int32_t mid, int32_t dim_aud);
+int instag_frame_code_forward(const float* a, const float* e, const float* const* params, float* enc_a,
+                              float* enc_e, float* saved, int32_t dim_in, int32_t mid, int32_t dim_aud,
+                              instag_stream_t stream);
+int instag_frame_code_backward(const float* a, const float* e, const float* const* params, const float* saved,
+                               const float* d_enc_a, const float* d_enc_e, float* const* grads, int32_t dim_in,
+                               int32_t mid, int32_t dim_aud, instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused L1 + SSIM image loss.  Replaces utils/loss_utils.py l1_loss :26-27 and ssim :42-72 (11x11
  * Gaussian window sigma 1.5, zero padding, C1=0.01^2, C2=0.03^2, mean over C*H*W) as used at
  * train_face.py:450-456.  img1/img2 [C,H,W].  forward writes per-workgroup partial sums

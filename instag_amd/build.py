@@ -39,6 +39,7 @@ SOURCES = {
     "ssim.hip": [],
     "glue.hip": [],
     "adam.hip": [],
+    "audio.hip": [],
 }
 
 

@@ -1,0 +1,314 @@
+// Per-frame conditioning codes of a motion network as ONE workgroup per pass:
+//   enc_a = AudioAttNet(AudioNet(a))            scene/motion_net.py:29-64, :67-99 (used at :283-289 / :672-677)
+//   enc_e = cat(exp_encode_net(e[:-1]), e[-1:]) scene/motion_net.py:152-173, :297-299 / :684-686
+// The reference runs this as ~11 cuDNN conv1d / GEMM launches plus their activations (and three times that in
+// backward) on an 8-window batch: launch-latency bound.  Here every activation lives in LDS, weights stream
+// from L2, and the backward pass produces every parameter gradient without atomics (deterministic).
+//
+// Layer stack (B = 8 windows, W = 16 samples, D = dim_in, M = mid, A = dim_aud, LeakyReLU slope 0.02):
+//   conv k3 s2 p1: D->M (16->8), M->M (8->4), M->64 (4->2), 64->64 (2->1); fc 64->64 (leaky), fc 64->A
+//   attention (B=1, channels = A features, length = 8 windows): conv k3 s1 p1 A->16->8->4->2->1 (leaky each),
+//   linear 8->8, softmax, enc_a = sum_t y[t] * feat[t]
+//   expression: relu(W1[16x5] e[:5]), W2[5x16], enc_e = (.., e[5])
+#include "common.hpp"
+
+namespace instag {
+namespace {
+
+constexpr int FT = 1024;          // threads of the single workgroup
+constexpr int NB = 8;             // audio windows per frame (= attention sequence length)
+constexpr int WIN = 16;
+constexpr float SLOPE = 0.02f;
+constexpr int NPARAM = 26;
+
+struct FrameDims { int D, M, A, has_exp; };
+
+// float offsets of every activation inside one LDS / saved block
+struct FrameLayout {
+  int x0, a1, a2, a3, a4, f1, f2, xt, c1, c2, c3, c4, c5, z, y, eh, end;
+};
+
+__host__ __device__ inline FrameLayout frame_layout(int D, int M, int A) {
+  FrameLayout L;
+  int o = 0;
+  L.x0 = o; o += NB * D * WIN;
+  L.a1 = o; o += NB * M * 8;
+  L.a2 = o; o += NB * M * 4;
+  L.a3 = o; o += NB * 64 * 2;
+  L.a4 = o; o += NB * 64;
+  L.f1 = o; o += NB * 64;
+  L.f2 = o; o += NB * A;
+  L.xt = o; o += A * NB;
+  L.c1 = o; o += 16 * NB;
+  L.c2 = o; o += 8 * NB;
+  L.c3 = o; o += 4 * NB;
+  L.c4 = o; o += 2 * NB;
+  L.c5 = o; o += NB;
+  L.z = o; o += NB;
+  L.y = o; o += NB;
+  L.eh = o; o += 16;
+  L.end = o;
+  return L;
+}
+
+struct ParamPtrs { const float* p[NPARAM]; };
+struct GradPtrs { float* p[NPARAM]; };
+
+__device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : SLOPE * v; }
+__device__ __forceinline__ float dleaky(float post) { return post > 0.f ? 1.f : SLOPE; }
+
+// y[b][co][l] = act(bias[co] + sum_{ci,k} w[co][ci][k] * x[b][ci][stride*l + k - pad]); K = 1 is a linear layer
+__device__ void conv_forward(const float* x, const float* __restrict__ w, const float* __restrict__ bias, float* y,
+                             int B, int cin, int cout, int lin, int lout, int stride, int K, int pad, bool act) {
+  const int total = B * cout * lout;
+  for (int o = threadIdx.x; o < total; o += FT) {
+    const int l = o % lout, co = (o / lout) % cout, b = o / (lout * cout);
+    float acc = bias ? bias[co] : 0.f;
+    const float* wr = w + (size_t)co * cin * K;
+    const float* xb = x + (size_t)b * cin * lin;
+    for (int ci = 0; ci < cin; ++ci)
+      for (int k = 0; k < K; ++k) {
+        const int p = stride * l + k - pad;
+        if (p >= 0 && p < lin) acc += wr[ci * K + k] * xb[ci * lin + p];
+      }
+    y[o] = act ? leaky(acc) : acc;
+  }
+}
+
+// g_out holds d(pre-activation) of the layer's output.  Writes dW, dbias to global and, when g_in != nullptr,
+// d(pre-activation) of the layer's input (x is a leaky output when in_act) or the plain input gradient.
+__device__ void conv_backward(const float* x, const float* g_out, const float* __restrict__ w, float* __restrict__ dW,
+                              float* __restrict__ dbias, float* g_in, int B, int cin, int cout, int lin, int lout,
+                              int stride, int K, int pad, bool in_act, bool in_accumulate) {
+  const int nW = cout * cin * K;
+  const int nB = dbias ? cout : 0;
+  const int nI = g_in ? B * cin * lin : 0;
+  for (int idx = threadIdx.x; idx < nW + nB + nI; idx += FT) {
+    if (idx < nW) {
+      const int k = idx % K, ci = (idx / K) % cin, co = idx / (K * cin);
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float* gb = g_out + ((size_t)b * cout + co) * lout;
+        const float* xb = x + ((size_t)b * cin + ci) * lin;
+        for (int l = 0; l < lout; ++l) {
+          const int p = stride * l + k - pad;
+          if (p >= 0 && p < lin) acc += gb[l] * xb[p];
+        }
+      }
+      dW[idx] = acc;
+    } else if (idx < nW + nB) {
+      const int co = idx - nW;
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b)
+        for (int l = 0; l < lout; ++l) acc += g_out[((size_t)b * cout + co) * lout + l];
+      dbias[co] = acc;
+    } else {
+      const int i = idx - nW - nB;
+      const int p = i % lin, ci = (i / lin) % cin, b = i / (lin * cin);
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const int q = p + pad - k;               // = stride * l
+        if (q < 0 || q % stride) continue;
+        const int l = q / stride;
+        if (l >= lout) continue;
+        const float* gb = g_out + (size_t)b * cout * lout + l;
+        const float* wk = w + ci * K + k;
+        for (int co = 0; co < cout; ++co) acc += wk[(size_t)co * cin * K] * gb[co * lout];
+      }
+      if (in_act) acc *= dleaky(x[i]);
+      g_in[i] = in_accumulate ? g_in[i] + acc : acc;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(FT)
+frame_code_forward_kernel(FrameDims d, ParamPtrs P, const float* __restrict__ a, const float* __restrict__ e,
+                          float* __restrict__ enc_a, float* __restrict__ enc_e, float* __restrict__ saved) {
+  extern __shared__ float s[];
+  const FrameLayout L = frame_layout(d.D, d.M, d.A);
+  for (int i = threadIdx.x; i < NB * d.D * WIN; i += FT) s[L.x0 + i] = a[i];
+  __syncthreads();
+  conv_forward(s + L.x0, P.p[0], P.p[1], s + L.a1, NB, d.D, d.M, 16, 8, 2, 3, 1, true);   __syncthreads();
+  conv_forward(s + L.a1, P.p[2], P.p[3], s + L.a2, NB, d.M, d.M, 8, 4, 2, 3, 1, true);    __syncthreads();
+  conv_forward(s + L.a2, P.p[4], P.p[5], s + L.a3, NB, d.M, 64, 4, 2, 2, 3, 1, true);     __syncthreads();
+  conv_forward(s + L.a3, P.p[6], P.p[7], s + L.a4, NB, 64, 64, 2, 1, 2, 3, 1, true);      __syncthreads();
+  conv_forward(s + L.a4, P.p[8], P.p[9], s + L.f1, NB, 64, 64, 1, 1, 1, 1, 0, true);      __syncthreads();
+  conv_forward(s + L.f1, P.p[10], P.p[11], s + L.f2, NB, 64, d.A, 1, 1, 1, 1, 0, false);  __syncthreads();
+  for (int i = threadIdx.x; i < d.A * NB; i += FT) {            // xt[j][t] = feat[t][j]
+    const int t = i % NB, j = i / NB;
+    s[L.xt + i] = s[L.f2 + t * d.A + j];
+  }
+  if (d.has_exp && threadIdx.x >= FT - 16) {                     // expression hidden layer on an idle part of the block
+    const int h = threadIdx.x - (FT - 16);
+    float acc = 0.f;
+    for (int i = 0; i < 5; ++i) acc += P.p[24][h * 5 + i] * e[i];
+    s[L.eh + h] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  conv_forward(s + L.xt, P.p[12], P.p[13], s + L.c1, 1, d.A, 16, NB, NB, 1, 3, 1, true);  __syncthreads();
+  conv_forward(s + L.c1, P.p[14], P.p[15], s + L.c2, 1, 16, 8, NB, NB, 1, 3, 1, true);    __syncthreads();
+  conv_forward(s + L.c2, P.p[16], P.p[17], s + L.c3, 1, 8, 4, NB, NB, 1, 3, 1, true);     __syncthreads();
+  conv_forward(s + L.c3, P.p[18], P.p[19], s + L.c4, 1, 4, 2, NB, NB, 1, 3, 1, true);     __syncthreads();
+  conv_forward(s + L.c4, P.p[20], P.p[21], s + L.c5, 1, 2, 1, NB, NB, 1, 3, 1, true);     __syncthreads();
+  conv_forward(s + L.c5, P.p[22], P.p[23], s + L.z, 1, NB, NB, 1, 1, 1, 1, 0, false);     __syncthreads();
+  if (threadIdx.x < NB) {
+    float m = s[L.z];
+    for (int t = 1; t < NB; ++t) m = fmaxf(m, s[L.z + t]);
+    float sum = 0.f;
+    for (int t = 0; t < NB; ++t) sum += expf(s[L.z + t] - m);
+    s[L.y + threadIdx.x] = expf(s[L.z + threadIdx.x] - m) / sum;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < d.A; j += FT) {
+    float acc = 0.f;
+    for (int t = 0; t < NB; ++t) acc += s[L.y + t] * s[L.f2 + t * d.A + j];
+    enc_a[j] = acc;
+  }
+  if (d.has_exp && threadIdx.x >= FT - 6) {
+    const int q = threadIdx.x - (FT - 6);
+    float acc;
+    if (q < 5) {
+      acc = 0.f;
+      for (int h = 0; h < 16; ++h) acc += P.p[25][q * 16 + h] * s[L.eh + h];
+    } else {
+      acc = e[5];
+    }
+    enc_e[q] = acc;
+  }
+  for (int i = threadIdx.x; i < L.end - L.a1; i += FT) saved[i] = s[L.a1 + i];
+}
+
+__global__ void __launch_bounds__(FT)
+frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __restrict__ a,
+                           const float* __restrict__ e, const float* __restrict__ saved,
+                           const float* __restrict__ d_enc_a, const float* __restrict__ d_enc_e) {
+  extern __shared__ float s[];
+  const FrameLayout L = frame_layout(d.D, d.M, d.A);
+  float* g = s + L.end - L.a1;                  // g[L.<act>] = gradient buffer of activation <act> (offsets >= a1)
+  for (int i = threadIdx.x; i < NB * d.D * WIN; i += FT) s[L.x0 + i] = a[i];
+  for (int i = threadIdx.x; i < L.end - L.a1; i += FT) s[L.a1 + i] = saved[i];
+  __syncthreads();
+
+  // enc_a = sum_t y[t] feat[t]: d_y, d_feat; then softmax
+  if (threadIdx.x < NB) {
+    float acc = 0.f;
+    for (int j = 0; j < d.A; ++j) acc += d_enc_a[j] * s[L.f2 + threadIdx.x * d.A + j];
+    g[L.y + threadIdx.x] = acc;
+  }
+  for (int i = threadIdx.x; i < NB * d.A; i += FT) g[L.f2 + i] = s[L.y + i / d.A] * d_enc_a[i % d.A];
+  __syncthreads();
+  if (threadIdx.x < NB) {
+    float dot = 0.f;
+    for (int t = 0; t < NB; ++t) dot += s[L.y + t] * g[L.y + t];
+    g[L.z + threadIdx.x] = s[L.y + threadIdx.x] * (g[L.y + threadIdx.x] - dot);
+  }
+  __syncthreads();
+  conv_backward(s + L.c5, g + L.z, P.p[22], G.p[22], G.p[23], g + L.c5, 1, NB, NB, 1, 1, 1, 1, 0, true, false);   __syncthreads();
+  conv_backward(s + L.c4, g + L.c5, P.p[20], G.p[20], G.p[21], g + L.c4, 1, 2, 1, NB, NB, 1, 3, 1, true, false);  __syncthreads();
+  conv_backward(s + L.c3, g + L.c4, P.p[18], G.p[18], G.p[19], g + L.c3, 1, 4, 2, NB, NB, 1, 3, 1, true, false);  __syncthreads();
+  conv_backward(s + L.c2, g + L.c3, P.p[16], G.p[16], G.p[17], g + L.c2, 1, 8, 4, NB, NB, 1, 3, 1, true, false);  __syncthreads();
+  conv_backward(s + L.c1, g + L.c2, P.p[14], G.p[14], G.p[15], g + L.c1, 1, 16, 8, NB, NB, 1, 3, 1, true, false); __syncthreads();
+  conv_backward(s + L.xt, g + L.c1, P.p[12], G.p[12], G.p[13], g + L.xt, 1, d.A, 16, NB, NB, 1, 3, 1, false, false);
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB * d.A; i += FT) {            // feat[t][j] also feeds xt[j][t]
+    const int j = i % d.A, t = i / d.A;
+    g[L.f2 + i] += g[L.xt + j * NB + t];
+  }
+  __syncthreads();
+  conv_backward(s + L.f1, g + L.f2, P.p[10], G.p[10], G.p[11], g + L.f1, NB, 64, d.A, 1, 1, 1, 1, 0, true, false); __syncthreads();
+  conv_backward(s + L.a4, g + L.f1, P.p[8], G.p[8], G.p[9], g + L.a4, NB, 64, 64, 1, 1, 1, 1, 0, true, false);    __syncthreads();
+  conv_backward(s + L.a3, g + L.a4, P.p[6], G.p[6], G.p[7], g + L.a3, NB, 64, 64, 2, 1, 2, 3, 1, true, false);    __syncthreads();
+  conv_backward(s + L.a2, g + L.a3, P.p[4], G.p[4], G.p[5], g + L.a2, NB, d.M, 64, 4, 2, 2, 3, 1, true, false);   __syncthreads();
+  conv_backward(s + L.a1, g + L.a2, P.p[2], G.p[2], G.p[3], g + L.a1, NB, d.M, d.M, 8, 4, 2, 3, 1, true, false);  __syncthreads();
+  conv_backward(s + L.x0, g + L.a1, P.p[0], G.p[0], G.p[1], nullptr, NB, d.D, d.M, 16, 8, 2, 3, 1, false, false);
+
+  if (d.has_exp) {
+    // enc_e[q<5] = sum_h W2[q][h] eh[h], eh = relu(W1 e[:5]); the block's first 80 + 80 threads own one weight each
+    if (threadIdx.x < 80) {
+      const int q = threadIdx.x / 16, h = threadIdx.x % 16;
+      G.p[25][threadIdx.x] = (d_enc_e ? d_enc_e[q] : 0.f) * s[L.eh + h];
+    } else if (threadIdx.x < 160) {
+      const int i = (threadIdx.x - 80) % 5, h = (threadIdx.x - 80) / 5;
+      float dh = 0.f;
+      if (d_enc_e && s[L.eh + h] > 0.f)
+        for (int q = 0; q < 5; ++q) dh += P.p[25][q * 16 + h] * d_enc_e[q];
+      G.p[24][h * 5 + i] = dh * e[i];
+    }
+  }
+}
+
+bool g_attr_set = false;
+
+inline int set_lds_limit() {
+  if (g_attr_set) return INSTAG_OK;
+  INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_code_forward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_code_backward_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  g_attr_set = true;
+  return INSTAG_OK;
+}
+
+inline bool dims_ok(int D, int M, int A) {
+  if (D < 1 || M < 1 || A < 1) return false;
+  const FrameLayout L = frame_layout(D, M, A);
+  return (size_t)(2 * L.end - L.a1) * sizeof(float) <= 160u * 1024u;
+}
+
+}  // namespace
+}  // namespace instag
+
+using namespace instag;
+
+extern "C" {
+
+int64_t instag_frame_code_saved_floats(int32_t dim_in, int32_t mid, int32_t dim_aud) {
+  if (!dims_ok(dim_in, mid, dim_aud)) return -1;
+  const FrameLayout L = frame_layout(dim_in, mid, dim_aud);
+  return L.end - L.a1;
+}
+
+int instag_frame_code_forward(const float* a, const float* e, const float* const* params, float* enc_a,
+                              float* enc_e, float* saved, int32_t dim_in, int32_t mid, int32_t dim_aud,
+                              instag_stream_t stream) {
+  INSTAG_REQUIRE(a && params && enc_a && saved, "frame_code_forward: NULL tensor");
+  INSTAG_REQUIRE(dims_ok(dim_in, mid, dim_aud), "frame_code: activations do not fit the 160 KB LDS");
+  INSTAG_REQUIRE((e == nullptr) == (enc_e == nullptr), "frame_code_forward: e and enc_e go together");
+  const int has_exp = e != nullptr;
+  ParamPtrs P;
+  for (int i = 0; i < NPARAM; ++i) {
+    P.p[i] = params[i];
+    INSTAG_REQUIRE(P.p[i] || (i >= 24 && !has_exp), "frame_code_forward: NULL parameter");
+  }
+  if (int rc = set_lds_limit()) return rc;
+  const FrameLayout L = frame_layout(dim_in, mid, dim_aud);
+  const FrameDims d{dim_in, mid, dim_aud, has_exp};
+  frame_code_forward_kernel<<<1, FT, (size_t)L.end * sizeof(float), (hipStream_t)stream>>>(d, P, a, e, enc_a, enc_e,
+                                                                                        saved);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_frame_code_backward(const float* a, const float* e, const float* const* params, const float* saved,
+                               const float* d_enc_a, const float* d_enc_e, float* const* grads, int32_t dim_in,
+                               int32_t mid, int32_t dim_aud, instag_stream_t stream) {
+  INSTAG_REQUIRE(a && params && saved && d_enc_a && grads, "frame_code_backward: NULL tensor");
+  INSTAG_REQUIRE(dims_ok(dim_in, mid, dim_aud), "frame_code: activations do not fit the 160 KB LDS");
+  const int has_exp = e != nullptr;
+  ParamPtrs P;
+  GradPtrs G;
+  for (int i = 0; i < NPARAM; ++i) {
+    P.p[i] = params[i];
+    G.p[i] = grads[i];
+    INSTAG_REQUIRE((P.p[i] && G.p[i]) || (i >= 24 && !has_exp), "frame_code_backward: NULL parameter / gradient");
+  }
+  if (int rc = set_lds_limit()) return rc;
+  const FrameLayout L = frame_layout(dim_in, mid, dim_aud);
+  const FrameDims d{dim_in, mid, dim_aud, has_exp};
+  frame_code_backward_kernel<<<1, FT, (size_t)(2 * L.end - L.a1) * sizeof(float), (hipStream_t)stream>>>(
+      d, P, G, a, e, saved, d_enc_a, d_enc_e);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+}  // extern "C"

@@ -59,47 +59,37 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
     const int r = (int)(i / d.KX), c = (int)(i - (size_t)r * d.KX);
     d_enc_x[i] = d_h_in[(size_t)r * K + c];
   }
-  float pa[32], pe[8];          // register partials of d_enc_a / d_enc_e (statically indexed: loops fully unrolled)
-#pragma unroll
-  for (int k = 0; k < 32; ++k) pa[k] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) pe[k] = 0.f;
-  for (int r = blockIdx.x * GB + threadIdx.x; r < d.N; r += gridDim.x * GB) {
-    const float* g = d_h_in + (size_t)r * K;
-    const float na = amb[2 * r], ne = amb[2 * r + 1];
-    const float ga = (d_amb && na > 0.f) ? d_amb[2 * r] / na : 0.f;
-    const float ge = (d_amb && ne > 0.f) ? d_amb[2 * r + 1] / ne : 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      if (k < d.KA) {
-        const float a = aud[(size_t)r * d.KA + k], gw = g[d.KX + k];
-        d_aud[(size_t)r * d.KA + k] = enc_a[k] * gw + ga * a;
-        pa[k] += gw * a;
-      }
+  // element-parallel (coalesced) over the audio and eye blocks; the per-column sums of d_enc_a / d_enc_e go
+  // through one register partial per thread when the grid stride keeps a thread on one column, LDS atomics otherwise
+  const size_t stride = (size_t)gridDim.x * GB;
+  {
+    const size_t ta = (size_t)d.N * d.KA;
+    const bool fixed = (stride % d.KA) == 0;
+    float part = 0.f;
+    for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < ta; i += stride) {
+      const int r = (int)(i / d.KA), k = (int)(i - (size_t)r * d.KA);
+      const float a = aud[i], gw = d_h_in[(size_t)r * K + d.KX + k];
+      const float na = amb[2 * r];
+      const float ga = (d_amb && na > 0.f) ? d_amb[2 * r] / na : 0.f;
+      d_aud[i] = enc_a[k] * gw + ga * a;
+      if (fixed) part += gw * a; else atomicAdd(&s_acc[k], gw * a);
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k < d.KE) {
-        const float pre = eye_pre[(size_t)r * d.KE + k], gw = g[d.KX + d.KA + k];
-        const float act = fmaxf(pre, 0.f);
-        d_eye_pre[(size_t)r * d.KE + k] = pre > 0.f ? (enc_e[k] * gw + ge * act) : 0.f;
-        pe[k] += gw * act;
-      }
+    if (fixed) atomicAdd(&s_acc[(int)(((size_t)blockIdx.x * GB + threadIdx.x) % d.KA)], part);
+  }
+  {
+    const size_t te = (size_t)d.N * d.KE;
+    const bool fixed = (stride % d.KE) == 0;
+    float part = 0.f;
+    for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < te; i += stride) {
+      const int r = (int)(i / d.KE), k = (int)(i - (size_t)r * d.KE);
+      const float pre = eye_pre[i], gw = d_h_in[(size_t)r * K + d.KX + d.KA + k];
+      const float act = fmaxf(pre, 0.f);
+      const float ne = amb[2 * r + 1];
+      const float ge = (d_amb && ne > 0.f) ? d_amb[2 * r + 1] / ne : 0.f;
+      d_eye_pre[i] = pre > 0.f ? (enc_e[k] * gw + ge * act) : 0.f;
+      if (fixed) part += gw * act; else atomicAdd(&s_acc[32 + k], gw * act);
     }
-  }
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    float v = pa[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0 && k < d.KA) atomicAdd(&s_acc[k], v);
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    float v = pe[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((threadIdx.x & 63) == 0 && k < d.KE) atomicAdd(&s_acc[32 + k], v);
+    if (fixed) atomicAdd(&s_acc[32 + (int)(((size_t)blockIdx.x * GB + threadIdx.x) % d.KE)], part);
   }
   __syncthreads();
   if ((int)threadIdx.x < d.KA) atomicAdd(&d_enc_a[threadIdx.x], s_acc[threadIdx.x]);
@@ -266,7 +256,7 @@ int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const f
   INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1, "motion_glue: widths out of range");
   if (N == 0) return INSTAG_OK;
   const GlueDims d{N, KX, KA, KE};
-  motion_glue_backward_kernel<<<row_blocks(N), GB, 0, (hipStream_t)stream>>>(
+  motion_glue_backward_kernel<<<row_blocks(N * 8), GB, 0, (hipStream_t)stream>>>(
       d, d_h_in, d_amb, aud, eye_pre, enc_a, enc_e, amb, d_enc_x, d_aud, d_eye_pre, d_enc_a, d_enc_e);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;

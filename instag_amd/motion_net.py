@@ -153,54 +153,67 @@ class _TriPlaneField(nn.Module):
             return None
         return self.audio_att_net(self.audio_net(a).unsqueeze(0))
 
-    def start_audio(self, a, stream_index=0):
-        """Launch the audio branch now, on a side stream; the next forward(x, a, ...) with the same `a` picks it
-        up.  Lets the caller overlap the audio branches of several networks with earlier per-Gaussian work."""
+    def encode_exp(self, e):
+        return torch.cat([self.exp_encode_net(e[:-1]), e[-1:]], dim=-1)
+
+    def encode_frame(self, a, e):
+        """-> (enc_a [1, audio_dim], enc_e [6] or None): everything that depends on the frame only."""
+        want_e = self.exp_eye and e is not None
+        if a is not None and a.is_cuda:
+            from . import audio as _audio
+            if _audio.supported(self, a, e if want_e else None):
+                # AudioNet + AudioAttNet + expression MLP as one workgroup per pass (instag_amd/audio.py)
+                return _audio.frame_codes(self, a, e if want_e else None)
+        return self.encode_audio(a), (self.encode_exp(e) if want_e else None)
+
+    def start_audio(self, a, stream_index=0, e=None):
+        """Launch the per-frame branch now, on a side stream; the next forward(x, a, e) with the same `a` picks it
+        up.  Lets the caller overlap the frame branches of several networks with earlier per-Gaussian work."""
         if not (a.is_cuda and CONCURRENT_AUDIO):
             return
         main_stream = torch.cuda.current_stream(a.device)
         side = _side_stream(a.device, stream_index)
         side.wait_stream(main_stream)
         with torch.cuda.stream(side):
-            enc_a = self.encode_audio(a)
-        self._audio_pending = (a, enc_a, side)
+            enc_a, enc_e = self.encode_frame(a, e)
+        self._audio_pending = (a, e, enc_a, enc_e, side)
 
     def _trunk(self, x, a, e, c):
         """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim])"""
         fork = x.is_cuda and CONCURRENT_AUDIO
         pending = self.__dict__.pop("_audio_pending", None)
         if fork:
-            # the per-frame audio branch (~40 tiny kernels) only meets the per-Gaussian branch at the glue:
-            # it runs on a second stream so it overlaps the tri-plane encode and the attention MLPs
+            # the per-frame branch only meets the per-Gaussian branch at the glue: it runs on a second stream
+            # so it overlaps the tri-plane encode and the attention MLPs
             main_stream = torch.cuda.current_stream(x.device)
-            if pending is not None and pending[0] is a:
-                enc_a, side = pending[1], pending[2]          # started early by start_audio()
+            if pending is not None and pending[0] is a and pending[1] is e:
+                enc_a, enc_e, side = pending[2], pending[3], pending[4]      # started early by start_audio()
             else:
                 side = _side_stream(x.device)
                 side.wait_stream(main_stream)
                 with torch.cuda.stream(side):
-                    enc_a = self.encode_audio(a)
+                    enc_a, enc_e = self.encode_frame(a, e)
         enc_x = self.encode_x(x, bound=self.bound)
         if fork:
             aud_ch_att = self.aud_ch_att_net(enc_x)
             main_stream.wait_stream(side)
             enc_a.record_stream(main_stream)
+            if enc_e is not None:
+                enc_e.record_stream(main_stream)
         else:
-            enc_a = self.encode_audio(a)
+            enc_a, enc_e = self.encode_frame(a, e)
             aud_ch_att = self.aud_ch_att_net(enc_x)
         if self.exp_eye and c is None and enc_x.is_cuda:
             from . import glue as _glue
             eye_pre = self.eye_att_net(enc_x)
             if _glue.motion_glue_supported(enc_x, aud_ch_att, eye_pre):
                 # repeat / mul / relu / cat / norm chain as one HIP kernel per pass (instag_amd/glue.py)
-                enc_e = torch.cat([self.exp_encode_net(e[:-1]), e[-1:]], dim=-1)
                 h_in, amb = _glue.motion_glue(enc_x, aud_ch_att, eye_pre, enc_a, enc_e)
                 return enc_x, amb[:, 0:1], amb[:, 1:2], self.sigma_net(h_in)
         parts = [enc_x, enc_a.repeat(enc_x.shape[0], 1) * aud_ch_att]
         eye_att = None
         if self.exp_eye:
             eye_att = torch.relu(self.eye_att_net(enc_x))
-            enc_e = torch.cat([self.exp_encode_net(e[:-1]), e[-1:]], dim=-1)
             parts.append(enc_e * eye_att)
         if c is not None:
             parts.append(c.repeat(enc_x.shape[0], 1))

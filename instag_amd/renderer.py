@@ -74,9 +74,9 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     p_motion_preds = None
     if xyz.is_cuda and hasattr(motion_net, "start_audio"):
         # both networks' audio branches depend only on the frame: start them now, each on its own side stream
-        motion_net.start_audio(audio_feat, 1)
+        motion_net.start_audio(audio_feat, 1, exp_feat)
         if (personalized or align) and hasattr(pc.neural_motion_grid, "start_audio"):
-            pc.neural_motion_grid.start_audio(audio_feat, 2)
+            pc.neural_motion_grid.start_audio(audio_feat, 2, exp_feat)
     if personalized or align:
         p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat, exp_feat)
     if align:

@@ -114,3 +114,44 @@ def test_multi_tensor_adam_matches_torch():
             got = run(lambda gr: MultiTensorAdam(gr, lr=0.0, betas=(0.9, 0.999), eps=1e-15), False)
         for a, b in zip(got, ref):
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("extractor,net", [("deepspeech", "umf"), ("esperanto", "pmf")])
+def test_frame_codes_match_torch_modules(extractor, net):
+    """AudioNet + AudioAttNet + expression MLP in one workgroup vs the nn.Module chain (fp64, CPU)."""
+    import copy
+    from types import SimpleNamespace
+    from instag_amd import audio as A
+    from instag_amd.motion_net import MotionNetwork, PersonalizedMotionNetwork, audio_in_dim
+
+    class NoEncoder(torch.nn.Module):          # the tri-plane encoders play no part in the per-frame branch
+        def __init__(self, **kw):
+            super().__init__()
+            self.output_dim = 12
+
+    torch.manual_seed(3)
+    args = SimpleNamespace(audio_extractor=extractor, type="face")
+    cls = MotionNetwork if net == "umf" else PersonalizedMotionNetwork
+    ref = cls(args=args, encoder_cls=NoEncoder).double()
+    with torch.no_grad():
+        for p in ref.parameters():             # biases and weights large enough to exercise both LeakyReLU sides
+            p.mul_(2.0)
+    dev = copy.deepcopy(ref).float().cuda()
+    a = torch.randn(8, audio_in_dim(extractor), 16)
+    e = torch.rand(6)
+    wa, we = torch.randn(1, 32), torch.randn(6)
+
+    enc_a_r, enc_e_r = ref.encode_frame(a.double(), e.double())
+    ((enc_a_r * wa.double()).sum() + (enc_e_r * we.double()).sum()).backward()
+    assert A.supported(dev, a.cuda(), e.cuda())
+    enc_a_h, enc_e_h = dev.encode_frame(a.cuda(), e.cuda())
+    ((enc_a_h * wa.cuda()).sum() + (enc_e_h * we.cuda()).sum()).backward()
+    _close(enc_a_h, enc_a_r, "enc_a")
+    _close(enc_e_h, enc_e_r, "enc_e")
+    names = [n for n, _ in ref.named_parameters()
+             if n.startswith(("audio_net", "audio_att_net", "exp_encode_net"))]
+    assert len(names) == 26
+    pr, ph = dict(ref.named_parameters()), dict(dev.named_parameters())
+    for n in names:
+        assert ph[n].grad is not None, n
+        _close(ph[n].grad, pr[n].grad, "d_" + n, tol=5e-5)
