@@ -266,6 +266,43 @@ int instag_l1_ssim_backward(const float* img1, const float* img2, const float* m
                             instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused loss block of the face branch (csrc/ssim.hip), train_face.py:415-416 (gt_white), :426-456
+ * (hair / mouth masking, L1 + DSSIM), :508-575 (alpha and attention terms):
+ *   head = face | hair;  gt_white = (head & ~mouth) ? gt : bg;  under FLAG_HAIR_TO_BG (hair_mask_iter)
+ *   hair pixels of BOTH images become bg (no gradient there)
+ *   loss = L1 + w_dssim (1 - SSIM)
+ *        + w_alpha (mean((1-alpha) head) + mean(alpha ~head))                      [FLAG_ALPHA]
+ *        + w_attn_hair (mean(attn[1][hair]) + mean(attn[0][hair]))                 [FLAG_HAIR_ATTN]
+ *        + w_attn_lips mean(attn[1, r0:r1, c0:c1])   lips_rect = (r0, r1, c0, c1)  [FLAG_LIPS]
+ *        + w_extra * extra[0]                        (extra: optional device scalar, e.g. motion_l1_reg)
+ * image, gt, attn [3,H,W]; alpha [1,H,W]; masks [H,W] bytes (0 / non-zero); bg [3]; lips_rect int32[4] on the
+ * device (it changes per frame under graph replay).  An empty hair mask contributes 0 (the reference
+ * yields NaN there).  forward writes maps [3,3,H,W] (SSIM derivative maps), partials
+ * (instag_face_loss_num_partials floats) and out[5] = (loss, L1, SSIM, 1/#hair, 1/lips area).
+ * backward takes the upstream gradients of loss and of the separately returned L1 (device scalars, either
+ * may be NULL) and writes d_image [3,H,W], d_alpha [1,H,W] (may be NULL), d_attn [3,H,W] (may be NULL);
+ * d loss / d extra = w_extra * g_loss is left to the caller.
+ * ------------------------------------------------------------------------------------------ */
+#define INSTAG_FACE_LOSS_HAIR_TO_BG 1
+#define INSTAG_FACE_LOSS_ALPHA 2
+#define INSTAG_FACE_LOSS_HAIR_ATTN 4
+#define INSTAG_FACE_LOSS_LIPS 8
+typedef struct {
+  int32_t H, W, flags;
+  float w_dssim, w_alpha, w_attn_hair, w_attn_lips, w_extra;
+} instag_face_loss_cfg;
+int64_t instag_face_loss_num_partials(int32_t H, int32_t W);
+int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                             const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                             const float* bg, const float* alpha, const float* attn, const int32_t* lips_rect,
+                             const float* extra, float* maps, float* partials, float* out, instag_stream_t stream);
+int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                              const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                              const float* bg, const int32_t* lips_rect, const float* maps, const float* out,
+                              const float* g_loss, const float* g_l1, float* d_image, float* d_alpha, float* d_attn,
+                              instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-tensor Adam / AdamW in one launch (csrc/adam.hip); replaces motion_optimizer.step() and
  * gaussians.optimizer.step() of train_face.py:781-788.  tensors: device array of 48-byte records
  * {float* p, const float* g (NULL = skip), float* m, float* v, int64 n, int32 group, int32 pad}; groups: device array

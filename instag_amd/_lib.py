@@ -23,6 +23,12 @@ f32 = C.c_float
 sz = C.c_size_t
 
 
+class FaceLossCfg(C.Structure):
+    """struct instag_face_loss_cfg (include/instag_hip.h)."""
+    _fields_ = [("H", i32), ("W", i32), ("flags", i32), ("w_dssim", f32), ("w_alpha", f32),
+                ("w_attn_hair", f32), ("w_attn_lips", f32), ("w_extra", f32)]
+
+
 class RasterArgs(C.Structure):
     """struct instag_raster_args (include/instag_hip.h)."""
     _fields_ = [
@@ -79,6 +85,9 @@ _PROTOS = {
     "instag_l1_ssim_num_partials": (C.c_int, [i32, i32, i32]),
     "instag_l1_ssim_forward": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "instag_l1_ssim_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "instag_face_loss_num_partials": (C.c_int64, [i32, i32]),
+    "instag_face_loss_forward": (C.c_int, [vp] * 15),
+    "instag_face_loss_backward": (C.c_int, [vp] * 16),
     "instag_adam_chunk_elems": (C.c_int, []),
     "instag_adam_step": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp]),
     "instag_prof_enable": (C.c_int, [C.c_int]),

@@ -96,3 +96,109 @@ def l1_and_ssim(img1, img2):
     if img1.is_cuda and img1.dim() == 3:
         return _FusedL1SSIM.apply(img1, img2.detach())
     return l1_loss(img1, img2), ssim(img1, img2)
+
+
+# ---- the face branch's whole loss block ---------------------------------------------------------------------------
+FLAG_HAIR_TO_BG, FLAG_ALPHA, FLAG_HAIR_ATTN, FLAG_LIPS = 1, 2, 4, 8
+
+
+def face_loss_torch(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None, attn=None, lips_rect=None,
+                    extra=None, lambda_dssim=0.2, w_alpha=1e-3, w_attn=1e-4, w_extra=1e-5, hair_mask_iter=False):
+    """Plain-torch statement of train_face.py:415-416, 426-456, 508-575 -> (loss, Ll1).  `alpha` / `attn` /
+    `extra` None drops the corresponding warm-stage terms.  lips_rect = (r0, r1, c0, c1) indexes attn[1, r0:r1, c0:c1]."""
+    head = face_mask | hair_mask
+    bg3 = bg[:, None, None]
+    keep = head & ~mouth_mask
+    if hair_mask_iter:
+        keep = keep & ~hair_mask
+        image = torch.where(hair_mask[None], bg3.expand_as(image), image)
+    gt_white = torch.where(keep[None], gt, bg3.expand_as(gt))
+    Ll1 = l1_loss(image, gt_white)
+    loss = Ll1 + lambda_dssim * (1.0 - ssim(image, gt_white))
+    if extra is not None:
+        loss = loss + w_extra * extra
+    if alpha is not None:
+        hm = head.to(alpha.dtype)
+        loss = loss + w_alpha * (((1 - alpha) * hm).mean() + (alpha * (1 - hm)).mean())
+    if attn is not None:
+        if lips_rect is not None:
+            r0, r1, c0, c1 = [int(v) for v in (lips_rect.tolist() if torch.is_tensor(lips_rect) else lips_rect)]
+            loss = loss + w_attn * attn[1, r0:r1, c0:c1].mean()
+        if not hair_mask_iter:
+            hair = hair_mask.to(attn.dtype)
+            cnt = hair.sum().clamp_min(1.0)
+            loss = loss + w_attn * ((attn[1] * hair).sum() / cnt + (attn[0] * hair).sum() / cnt)
+    return loss, Ll1
+
+
+class _FusedFaceLoss(torch.autograd.Function):
+    """(loss, Ll1) of the face branch in two launches forward, one backward (csrc/ssim.hip)."""
+
+    @staticmethod
+    def forward(ctx, image, alpha, attn, extra, gt, face_mask, hair_mask, mouth_mask, bg, lips_rect, cfg_tuple):
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, ptr
+        L = _lib.lib()
+        ctx.set_materialize_grads(False)
+        image = image.contiguous().float()
+        _, H, W = image.shape
+        dev = image.device
+        flags, w_dssim, w_alpha, w_hair, w_lips, w_extra = cfg_tuple
+        cfg = _lib.FaceLossCfg(H, W, flags, w_dssim, w_alpha, w_hair, w_lips, w_extra)
+        as_u8 = lambda m: m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.contiguous().to(torch.uint8)
+        face_mask, hair_mask, mouth_mask = as_u8(face_mask), as_u8(hair_mask), as_u8(mouth_mask)
+        gt, bg = gt.contiguous().float(), bg.contiguous().float()
+        alpha = None if alpha is None else alpha.contiguous().float()
+        attn = None if attn is None else attn.contiguous().float()
+        extra = None if extra is None else extra.reshape(1).contiguous().float()
+        lips_rect = None if lips_rect is None else lips_rect.contiguous().to(torch.int32)
+        maps = torch.empty(3, 3, H, W, dtype=torch.float32, device=dev)
+        parts = torch.empty(L.instag_face_loss_num_partials(H, W), dtype=torch.float32, device=dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)
+        check(L.instag_face_loss_forward(C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask), ptr(hair_mask),
+                                         ptr(mouth_mask), ptr(bg), ptr(alpha), ptr(attn), ptr(lips_rect), ptr(extra),
+                                         ptr(maps), ptr(parts), ptr(out), _lib.current_stream()), "face_loss_forward")
+        ctx.cfg = cfg
+        ctx.shapes = (alpha is not None, attn is not None, extra is not None)
+        ctx.save_for_backward(image, gt, face_mask, hair_mask, mouth_mask, bg, maps, out,
+                              *([lips_rect] if lips_rect is not None else []))
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_l1):
+        import ctypes as C
+        from . import _lib
+        from ._lib import check, ptr
+        saved = ctx.saved_tensors
+        image, gt, face_mask, hair_mask, mouth_mask, bg, maps, out = saved[:8]
+        lips_rect = saved[8] if len(saved) > 8 else None
+        has_alpha, has_attn, has_extra = ctx.shapes
+        cfg = ctx.cfg
+        _, H, W = image.shape
+        g_loss = None if g_loss is None else g_loss.contiguous().float()
+        g_l1 = None if g_l1 is None else g_l1.contiguous().float()
+        d_image = torch.empty_like(image)
+        d_alpha = torch.empty(1, H, W, dtype=torch.float32, device=image.device) if has_alpha else None
+        d_attn = torch.empty(3, H, W, dtype=torch.float32, device=image.device) if has_attn else None
+        check(_lib.lib().instag_face_loss_backward(C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask), ptr(hair_mask),
+                                                   ptr(mouth_mask), ptr(bg), ptr(lips_rect), ptr(maps), ptr(out),
+                                                   ptr(g_loss), ptr(g_l1), ptr(d_image), ptr(d_alpha), ptr(d_attn),
+                                                   _lib.current_stream()), "face_loss_backward")
+        d_extra = (g_loss * cfg.w_extra) if (has_extra and g_loss is not None) else None
+        return d_image, d_alpha, d_attn, d_extra, None, None, None, None, None, None, None
+
+
+def face_loss(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None, attn=None, lips_rect=None, extra=None,
+              lambda_dssim=0.2, w_alpha=1e-3, w_attn=1e-4, w_extra=1e-5, hair_mask_iter=False):
+    """Loss block of the face branch -> (loss, Ll1); fused HIP kernels on the device, face_loss_torch otherwise."""
+    if not (image.is_cuda and image.dim() == 3 and image.shape[0] == 3):
+        return face_loss_torch(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha, attn, lips_rect, extra,
+                               lambda_dssim, w_alpha, w_attn, w_extra, hair_mask_iter)
+    flags = (FLAG_HAIR_TO_BG if hair_mask_iter else 0) | (FLAG_ALPHA if alpha is not None else 0)
+    if attn is not None:
+        flags |= (FLAG_LIPS if lips_rect is not None else 0) | (0 if hair_mask_iter else FLAG_HAIR_ATTN)
+    if lips_rect is not None and not torch.is_tensor(lips_rect):
+        lips_rect = torch.tensor(list(lips_rect), dtype=torch.int32, device=image.device)
+    cfg = (flags, float(lambda_dssim), float(w_alpha), float(w_attn), float(w_attn), float(w_extra))
+    return _FusedFaceLoss.apply(image, alpha, attn, extra, gt, face_mask, hair_mask, mouth_mask, bg, lips_rect, cfg)

@@ -126,5 +126,9 @@ def synthetic_frame(size=512, seed=0, device="cpu"):
     head = r2 < (0.33 * size) ** 2
     mouth = ((xx - c) ** 2 + (yy - 1.25 * c) ** 2) < (0.06 * size) ** 2
     hair = (r2 < (0.36 * size) ** 2) & (yy < 0.35 * size) & ~head
-    out = dict(auds=auds, au_exp=au_exp, gt_image=gt, face_mask=head, hair_mask=hair, mouth_mask=mouth)
+    # lips_rect = (xmin, xmax, ymin, ymax) as the reference stores it: it indexes attn[1, xmin:xmax, ymin:ymax]
+    lips_rect = torch.tensor([int(1.25 * c - 0.07 * size), int(1.25 * c + 0.07 * size),
+                              int(c - 0.1 * size), int(c + 0.1 * size)], dtype=torch.int32)
+    out = dict(auds=auds, au_exp=au_exp, gt_image=gt, face_mask=head, hair_mask=hair, mouth_mask=mouth,
+               lips_rect=lips_rect)
     return {k: v.to(device) for k, v in out.items()}

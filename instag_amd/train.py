@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 
 from .gaussian_model import GaussianModel, OptimizationParams
-from .losses import l1_and_ssim
+from .losses import face_loss
 
 
 @dataclass
@@ -45,7 +45,7 @@ class Frame:
     original_image: torch.Tensor      # [3,H,W] in [0,1]
 
     TENSORS = ("world_view_transform", "full_proj_transform", "camera_center", "original_image")
-    DICT_TENSORS = ("auds", "au_exp", "face_mask", "hair_mask", "mouth_mask")
+    DICT_TENSORS = ("auds", "au_exp", "face_mask", "hair_mask", "mouth_mask", "lips_rect")
 
     def clone_static(self):
         td = {k: self.talking_dict[k].clone() for k in self.DICT_TENSORS}
@@ -64,7 +64,8 @@ class Frame:
 
 def make_frame(cam, frame_data) -> Frame:
     td = dict(auds=frame_data["auds"], au_exp=frame_data["au_exp"], face_mask=frame_data["face_mask"],
-              hair_mask=frame_data["hair_mask"], mouth_mask=frame_data["mouth_mask"])
+              hair_mask=frame_data["hair_mask"], mouth_mask=frame_data["mouth_mask"],
+              lips_rect=frame_data["lips_rect"])
     return Frame(cam.image_height, cam.image_width, cam.FoVx, cam.FoVy, cam.world_view_transform,
                  cam.full_proj_transform, cam.camera_center, td, frame_data["gt_image"])
 
@@ -103,11 +104,6 @@ def allreduce_gradients(params: List[torch.Tensor], extras: Optional[List[torch.
     for e in extras:
         e.copy_(bucket[o:o + e.numel()].view_as(e))
         o += e.numel()
-
-
-def masked_mean(x, mask, count):
-    """mean of x over the True elements of mask == x[mask].mean(), without the host sync of boolean indexing."""
-    return (x * mask).sum() / count
 
 
 class FaceTrainer:
@@ -165,34 +161,23 @@ class FaceTrainer:
         return ps
 
     # ---- loss block (train_face.py:450-456, 508-540) --------------------------------------------------------
-    def loss_fn(self, frame: Frame, pkg, warm: bool):
+    def loss_fn(self, frame: Frame, pkg, warm: bool, hair_mask_iter: bool = False):
+        """-> (loss, Ll1).  `warm` = iteration > warm_step: motion regularisers, alpha and attention terms."""
         dev = self.bg.device
         td = frame.talking_dict
-        face_mask = td["face_mask"].to(dev)
-        hair_mask = td["hair_mask"].to(dev)
-        mouth_mask = td["mouth_mask"].to(dev)
-        head_mask = face_mask | hair_mask
-        image, alpha = pkg["render"], pkg["alpha"]
-        gt = frame.original_image.to(dev)
-        bg3 = self.bg[:, None, None]
-        gt_white = torch.where(head_mask[None] & ~mouth_mask[None], gt, bg3.expand_as(gt))
-        Ll1, ssim_val = l1_and_ssim(image, gt_white)
-        loss = Ll1 + self.opt.lambda_dssim * (1.0 - ssim_val)
+        extra = alpha = attn = lips = None
         if warm:
             m, pm = pkg["motion"], pkg["p_motion"]
-            if image.is_cuda and m.get("_h") is not None and pm.get("_p") is not None:
+            if pkg["render"].is_cuda and m.get("_h") is not None and pm.get("_p") is not None:
                 from .glue import motion_l1_reg
-                loss = loss + 1e-5 * motion_l1_reg(m["_h"], pm["_p"])
+                extra = motion_l1_reg(m["_h"], pm["_p"])
             else:
-                loss = loss + 1e-5 * (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()
-                                      + m["d_scale"].abs().mean() + pm["p_xyz"].abs().mean())
-            hm = head_mask.to(alpha.dtype)
-            loss = loss + 1e-3 * (((1 - alpha) * hm).mean() + (alpha * (1 - hm)).mean())
-            attn = pkg["attn"]
-            hair = hair_mask.to(alpha.dtype)
-            cnt = hair.sum().clamp_min(1.0)
-            loss = loss + 1e-4 * (masked_mean(attn[1], hair, cnt) + masked_mean(attn[0], hair, cnt))
-        return loss, Ll1
+                extra = (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()
+                         + m["d_scale"].abs().mean() + pm["p_xyz"].abs().mean())
+            alpha, attn, lips = pkg["alpha"], pkg["attn"], td["lips_rect"].to(dev)
+        return face_loss(pkg["render"], frame.original_image.to(dev), td["face_mask"].to(dev), td["hair_mask"].to(dev),
+                         td["mouth_mask"].to(dev), self.bg, alpha=alpha, attn=attn, lips_rect=lips, extra=extra,
+                         lambda_dssim=self.opt.lambda_dssim, hair_mask_iter=hair_mask_iter)
 
     # ---- one step ---------------------------------------------------------------------------------------------
     def _forward_backward(self, frame: Frame):

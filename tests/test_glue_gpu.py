@@ -155,3 +155,38 @@ def test_frame_codes_match_torch_modules(extractor, net):
     for n in names:
         assert ph[n].grad is not None, n
         _close(ph[n].grad, pr[n].grad, "d_" + n, tol=5e-5)
+
+
+@pytest.mark.parametrize("hair_mask_iter,size", [(False, (96, 80)), (True, (70, 53))])
+def test_face_loss_matches_torch(hair_mask_iter, size):
+    """Fused loss block (gt_white composition, L1 + DSSIM, alpha / attention / lips terms) vs torch fp64."""
+    from instag_amd.losses import face_loss, face_loss_torch
+    H, W = size
+    g = torch.Generator().manual_seed(11)
+    image, gt = torch.rand(3, H, W, generator=g), torch.rand(3, H, W, generator=g)
+    alpha, attn = torch.rand(1, H, W, generator=g), torch.rand(3, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    face = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2) < (0.3 * H) ** 2
+    hair = (((yy - H / 2) ** 2 + (xx - W / 2) ** 2) < (0.4 * H) ** 2) & (yy < 0.4 * H) & ~face
+    mouth = ((yy - 0.65 * H) ** 2 + (xx - W / 2) ** 2) < (0.08 * H) ** 2
+    bg = torch.tensor([0.0, 1.0, 0.0])
+    lips = torch.tensor([int(0.55 * H), int(0.75 * H), int(0.3 * W), int(0.7 * W)], dtype=torch.int32)
+    extra = torch.tensor(0.37)
+
+    def run(fn, dev, dt):
+        leaves = [t.to(dev, dt).requires_grad_(True) for t in (image, alpha, attn, extra)]
+        loss, l1 = fn(leaves[0], gt.to(dev, dt), face.to(dev), hair.to(dev), mouth.to(dev), bg.to(dev, dt),
+                      alpha=leaves[1], attn=leaves[2], lips_rect=lips.to(dev), extra=leaves[3],
+                      hair_mask_iter=hair_mask_iter)
+        (loss + 0.5 * l1).backward()
+        return loss, l1, [t.grad for t in leaves]
+
+    loss_r, l1_r, g_r = run(face_loss_torch, "cpu", torch.float64)
+    loss_h, l1_h, g_h = run(face_loss, "cuda", torch.float32)
+    assert abs(float(loss_h) - float(loss_r)) < 2e-6, (float(loss_h), float(loss_r))
+    assert abs(float(l1_h) - float(l1_r)) < 2e-6
+    for name, a, b in zip(("d_image", "d_alpha", "d_attn", "d_extra"), g_h, g_r):
+        err = float((a.double().cpu() - b).abs().max())
+        assert err <= 2e-5 * max(float(b.abs().max()), 1e-4), f"{name}: {err} vs {float(b.abs().max())}"
+    if hair_mask_iter:
+        assert float(g_h[0][:, hair.cuda()].abs().max()) == 0.0
