@@ -65,15 +65,18 @@ int instag_grid_total_variation(const float* inputs, const float* embeddings, fl
 /* Tri-plane encoder: the three identically configured 2-D, C=1 grid encoders of a motion field (planes xy, yz, xz;
  * scene/motion_net.py:214-216,244-258) in one pass: xyz [N,3] in [-bound,bound] -> out [N,3L] = cat(enc_xy, enc_yz,
  * enc_xz), including the (x+bound)/(2 bound) mapping (gridencoder/grid.py:149).  Each plane's table ([total_params,1],
- * shared `offsets` [L+1]) must fit 64 KB.  backward: grad [N,3L] -> dxyz [N,3] (zero-filled by the caller, may be
- * NULL) and the three table gradients (zero-filled by the caller, accumulated into). */
+ * shared `offsets` [L+1]) must fit 50 KB.  backward: grad [N,3L] -> dxyz [N,3] (written, may be NULL) and the three
+ * table gradients (written, not accumulated; summed over workgroups in a fixed order).  workspace:
+ * instag_triplane_backward_workspace_bytes(N, total_params) bytes of scratch. */
 int instag_triplane_forward(const float* xyz, const float* table_xy, const float* table_yz,
                             const float* table_xz, const int32_t* offsets, float* out, uint32_t N, uint32_t L,
                             float S, uint32_t H, float bound, uint32_t total_params, instag_stream_t stream);
+size_t instag_triplane_backward_workspace_bytes(uint32_t N, uint32_t total_params);
 int instag_triplane_backward(const float* grad, const float* xyz, const float* table_xy, const float* table_yz,
                              const float* table_xz, const int32_t* offsets, float* dxyz, float* dtable_xy,
-                             float* dtable_yz, float* dtable_xz, uint32_t N, uint32_t L, float S, uint32_t H,
-                             float bound, uint32_t total_params, instag_stream_t stream);
+                             float* dtable_yz, float* dtable_xz, void* workspace, size_t workspace_bytes,
+                             uint32_t N, uint32_t L, float S, uint32_t H, float bound, uint32_t total_params,
+                             instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spherical-harmonics encoder.  Replaces shencoder/src/shencoder.h:8-9:
@@ -227,6 +230,11 @@ int instag_motion_l1_reg_forward(const float* h, const float* p, float* partial,
                                  instag_stream_t stream);
 int instag_motion_l1_reg_backward(const float* h, const float* p, const float* g, float* d_h, float* d_p,
                                   int32_t N, instag_stream_t stream);
+/* Densification statistics of one step (train_face.py:626-629, GaussianModel.add_densification_stats), in place,
+ * for the Gaussians with radii > 0: max_radii2D = max(max_radii2D, radii), grad_accum += ||viewspace_grad[:, :2]||,
+ * denom += 1.  viewspace_grad [N,3], radii int32 [N], the three statistics float [N]. */
+int instag_densify_stats(const float* viewspace_grad, const int32_t* radii, float* max_radii2D, float* grad_accum,
+                         float* denom, int32_t N, instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Per-frame conditioning codes of one motion network, one workgroup per pass (csrc/audio.hip):

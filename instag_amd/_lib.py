@@ -51,7 +51,9 @@ _PROTOS = {
                                               C.c_int, u32, vp, sz, u32, vp]),
     "instag_grid_total_variation": (C.c_int, [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, C.c_int, vp]),
     "instag_triplane_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, u32, u32, f32, u32, f32, u32, vp]),
-    "instag_triplane_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, f32, u32, f32, u32, vp]),
+    "instag_triplane_backward_workspace_bytes": (sz, [u32, u32]),
+    "instag_triplane_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, u32, u32, f32, u32, f32, u32,
+                                           vp]),
     "instag_sh_encode_forward": (C.c_int, [vp, vp, u32, u32, u32, vp, vp]),
     "instag_sh_encode_backward": (C.c_int, [vp, vp, u32, u32, u32, vp, vp, vp]),
     "instag_raster_geom_bytes": (sz, [i32]),
@@ -79,6 +81,7 @@ _PROTOS = {
     "instag_motion_l1_reg_num_partials": (C.c_int, [i32]),
     "instag_motion_l1_reg_forward": (C.c_int, [vp, vp, vp, i32, vp]),
     "instag_motion_l1_reg_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
+    "instag_densify_stats": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
     "instag_frame_code_saved_floats": (C.c_int64, [i32, i32, i32]),
     "instag_frame_code_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "instag_frame_code_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),

@@ -2,8 +2,8 @@
 //   enc_a = AudioAttNet(AudioNet(a))            scene/motion_net.py:29-64, :67-99 (used at :283-289 / :672-677)
 //   enc_e = cat(exp_encode_net(e[:-1]), e[-1:]) scene/motion_net.py:152-173, :297-299 / :684-686
 // The reference runs this as ~11 cuDNN conv1d / GEMM launches plus their activations (and three times that in
-// backward) on an 8-window batch: launch-latency bound.  Here every activation lives in LDS, weights stream
-// from L2, and the backward pass produces every parameter gradient without atomics (deterministic).
+// backward) on an 8-window batch: launch-latency bound.  Here every activation lives in LDS, weights are staged
+// through LDS per layer group, and the backward pass produces every parameter gradient without atomics (deterministic).
 //
 // Layer stack (B = 8 windows, W = 16 samples, D = dim_in, M = mid, A = dim_aud, LeakyReLU slope 0.02):
 //   conv k3 s2 p1: D->M (16->8), M->M (8->4), M->64 (4->2), 64->64 (2->1); fc 64->64 (leaky), fc 64->A
@@ -56,6 +56,48 @@ struct GradPtrs { float* p[NPARAM]; };
 
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : SLOPE * v; }
 __device__ __forceinline__ float dleaky(float post) { return post > 0.f ? 1.f : SLOPE; }
+
+// Weights are staged into LDS one layer group at a time (coalesced 16-byte loads, all issued before the first
+// wait): a MAC loop that reads its weight from global memory pays one L2 round trip per iteration.
+// Groups: 0 conv1, 1 conv2, 2 conv3, 3 conv4, 4 fc1+fc2, 5 attention convs + linear + expression MLP.
+__host__ __device__ inline int att_floats(int A) { return 48 * A + 784; }   // segments padded to 4 floats
+__host__ __device__ inline int weight_stage_floats(int D, int M, int A) {
+  int m = M * D * 3 + M;
+  m = max(m, M * M * 3 + M);
+  m = max(m, 64 * M * 3 + 64);
+  m = max(m, 64 * 64 * 3 + 64);
+  m = max(m, 64 * 64 + 64 + A * 64 + A);
+  m = max(m, att_floats(A));
+  return (m + 3) & ~3;
+}
+
+__device__ __forceinline__ void stage(float* dst, const float* __restrict__ src, int n) {
+  if (src == nullptr) return;
+  if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n / 4; i += FT) d4[i] = s4[i];
+  } else {
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n; i += FT) dst[i] = src[i];
+  }
+}
+
+// offsets of the group-5 segments inside the staging buffer
+struct AttW { int w[6], b[6], e1, e2; };
+__device__ __forceinline__ AttW att_layout(int A) {
+  AttW o;
+  const int cin[6] = {A, 16, 8, 4, 2, 8}, cout[6] = {16, 8, 4, 2, 1, 8}, K[6] = {3, 3, 3, 3, 3, 1};
+  int p = 0;
+  for (int i = 0; i < 6; ++i) {
+    o.w[i] = p; p += (cout[i] * cin[i] * K[i] + 3) & ~3;
+    o.b[i] = p; p += (cout[i] + 3) & ~3;
+  }
+  o.e1 = p; p += 80;
+  o.e2 = p;
+  return o;
+}
 
 // y[b][co][l] = act(bias[co] + sum_{ci,k} w[co][ci][k] * x[b][ci][stride*l + k - pad]); K = 1 is a linear layer
 __device__ void conv_forward(const float* x, const float* __restrict__ w, const float* __restrict__ bias, float* y,
@@ -124,33 +166,60 @@ __device__ void conv_backward(const float* x, const float* g_out, const float* _
 __global__ void __launch_bounds__(FT)
 frame_code_forward_kernel(FrameDims d, ParamPtrs P, const float* __restrict__ a, const float* __restrict__ e,
                           float* __restrict__ enc_a, float* __restrict__ enc_e, float* __restrict__ saved) {
-  extern __shared__ float s[];
+  extern __shared__ __align__(16) float s[];
   const FrameLayout L = frame_layout(d.D, d.M, d.A);
-  for (int i = threadIdx.x; i < NB * d.D * WIN; i += FT) s[L.x0 + i] = a[i];
+  float* sw = s + ((L.end + 3) & ~3);            // weight staging buffer
+  const int D = d.D, M = d.M, A = d.A;
+  for (int i = threadIdx.x; i < NB * D * WIN; i += FT) s[L.x0 + i] = a[i];
+  stage(sw, P.p[0], M * D * 3); stage(sw + M * D * 3, P.p[1], M);
   __syncthreads();
-  conv_forward(s + L.x0, P.p[0], P.p[1], s + L.a1, NB, d.D, d.M, 16, 8, 2, 3, 1, true);   __syncthreads();
-  conv_forward(s + L.a1, P.p[2], P.p[3], s + L.a2, NB, d.M, d.M, 8, 4, 2, 3, 1, true);    __syncthreads();
-  conv_forward(s + L.a2, P.p[4], P.p[5], s + L.a3, NB, d.M, 64, 4, 2, 2, 3, 1, true);     __syncthreads();
-  conv_forward(s + L.a3, P.p[6], P.p[7], s + L.a4, NB, 64, 64, 2, 1, 2, 3, 1, true);      __syncthreads();
-  conv_forward(s + L.a4, P.p[8], P.p[9], s + L.f1, NB, 64, 64, 1, 1, 1, 1, 0, true);      __syncthreads();
-  conv_forward(s + L.f1, P.p[10], P.p[11], s + L.f2, NB, 64, d.A, 1, 1, 1, 1, 0, false);  __syncthreads();
-  for (int i = threadIdx.x; i < d.A * NB; i += FT) {            // xt[j][t] = feat[t][j]
-    const int t = i % NB, j = i / NB;
-    s[L.xt + i] = s[L.f2 + t * d.A + j];
+  conv_forward(s + L.x0, sw, sw + M * D * 3, s + L.a1, NB, D, M, 16, 8, 2, 3, 1, true);
+  __syncthreads();
+  stage(sw, P.p[2], M * M * 3); stage(sw + M * M * 3, P.p[3], M);
+  __syncthreads();
+  conv_forward(s + L.a1, sw, sw + M * M * 3, s + L.a2, NB, M, M, 8, 4, 2, 3, 1, true);
+  __syncthreads();
+  stage(sw, P.p[4], 64 * M * 3); stage(sw + 64 * M * 3, P.p[5], 64);
+  __syncthreads();
+  conv_forward(s + L.a2, sw, sw + 64 * M * 3, s + L.a3, NB, M, 64, 4, 2, 2, 3, 1, true);
+  __syncthreads();
+  stage(sw, P.p[6], 64 * 64 * 3); stage(sw + 64 * 64 * 3, P.p[7], 64);
+  __syncthreads();
+  conv_forward(s + L.a3, sw, sw + 64 * 64 * 3, s + L.a4, NB, 64, 64, 2, 1, 2, 3, 1, true);
+  __syncthreads();
+  stage(sw, P.p[8], 4096); stage(sw + 4096, P.p[9], 64); stage(sw + 4160, P.p[10], A * 64);
+  stage(sw + 4160 + A * 64, P.p[11], A);
+  __syncthreads();
+  conv_forward(s + L.a4, sw, sw + 4096, s + L.f1, NB, 64, 64, 1, 1, 1, 1, 0, true);
+  __syncthreads();
+  conv_forward(s + L.f1, sw + 4160, sw + 4160 + A * 64, s + L.f2, NB, 64, A, 1, 1, 1, 1, 0, false);
+  __syncthreads();
+  const AttW aw = att_layout(A);
+  {
+    const int cin[6] = {A, 16, 8, 4, 2, 8}, cout[6] = {16, 8, 4, 2, 1, 8}, K[6] = {3, 3, 3, 3, 3, 1};
+    for (int i = 0; i < 6; ++i) {
+      stage(sw + aw.w[i], P.p[12 + 2 * i], cout[i] * cin[i] * K[i]);
+      stage(sw + aw.b[i], P.p[13 + 2 * i], cout[i]);
+    }
+    if (d.has_exp) { stage(sw + aw.e1, P.p[24], 80); stage(sw + aw.e2, P.p[25], 80); }
   }
+  for (int i = threadIdx.x; i < A * NB; i += FT) {            // xt[j][t] = feat[t][j]
+    const int t = i % NB, j = i / NB;
+    s[L.xt + i] = s[L.f2 + t * A + j];
+  }
+  __syncthreads();
   if (d.has_exp && threadIdx.x >= FT - 16) {                     // expression hidden layer on an idle part of the block
     const int h = threadIdx.x - (FT - 16);
     float acc = 0.f;
-    for (int i = 0; i < 5; ++i) acc += P.p[24][h * 5 + i] * e[i];
+    for (int i = 0; i < 5; ++i) acc += sw[aw.e1 + h * 5 + i] * e[i];
     s[L.eh + h] = fmaxf(acc, 0.f);
   }
-  __syncthreads();
-  conv_forward(s + L.xt, P.p[12], P.p[13], s + L.c1, 1, d.A, 16, NB, NB, 1, 3, 1, true);  __syncthreads();
-  conv_forward(s + L.c1, P.p[14], P.p[15], s + L.c2, 1, 16, 8, NB, NB, 1, 3, 1, true);    __syncthreads();
-  conv_forward(s + L.c2, P.p[16], P.p[17], s + L.c3, 1, 8, 4, NB, NB, 1, 3, 1, true);     __syncthreads();
-  conv_forward(s + L.c3, P.p[18], P.p[19], s + L.c4, 1, 4, 2, NB, NB, 1, 3, 1, true);     __syncthreads();
-  conv_forward(s + L.c4, P.p[20], P.p[21], s + L.c5, 1, 2, 1, NB, NB, 1, 3, 1, true);     __syncthreads();
-  conv_forward(s + L.c5, P.p[22], P.p[23], s + L.z, 1, NB, NB, 1, 1, 1, 1, 0, false);     __syncthreads();
+  conv_forward(s + L.xt, sw + aw.w[0], sw + aw.b[0], s + L.c1, 1, A, 16, NB, NB, 1, 3, 1, true);  __syncthreads();
+  conv_forward(s + L.c1, sw + aw.w[1], sw + aw.b[1], s + L.c2, 1, 16, 8, NB, NB, 1, 3, 1, true);  __syncthreads();
+  conv_forward(s + L.c2, sw + aw.w[2], sw + aw.b[2], s + L.c3, 1, 8, 4, NB, NB, 1, 3, 1, true);   __syncthreads();
+  conv_forward(s + L.c3, sw + aw.w[3], sw + aw.b[3], s + L.c4, 1, 4, 2, NB, NB, 1, 3, 1, true);   __syncthreads();
+  conv_forward(s + L.c4, sw + aw.w[4], sw + aw.b[4], s + L.c5, 1, 2, 1, NB, NB, 1, 3, 1, true);   __syncthreads();
+  conv_forward(s + L.c5, sw + aw.w[5], sw + aw.b[5], s + L.z, 1, NB, NB, 1, 1, 1, 1, 0, false);   __syncthreads();
   if (threadIdx.x < NB) {
     float m = s[L.z];
     for (int t = 1; t < NB; ++t) m = fmaxf(m, s[L.z + t]);
@@ -159,9 +228,9 @@ frame_code_forward_kernel(FrameDims d, ParamPtrs P, const float* __restrict__ a,
     s[L.y + threadIdx.x] = expf(s[L.z + threadIdx.x] - m) / sum;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < d.A; j += FT) {
+  for (int j = threadIdx.x; j < A; j += FT) {
     float acc = 0.f;
-    for (int t = 0; t < NB; ++t) acc += s[L.y + t] * s[L.f2 + t * d.A + j];
+    for (int t = 0; t < NB; ++t) acc += s[L.y + t] * s[L.f2 + t * A + j];
     enc_a[j] = acc;
   }
   if (d.has_exp && threadIdx.x >= FT - 6) {
@@ -169,7 +238,7 @@ frame_code_forward_kernel(FrameDims d, ParamPtrs P, const float* __restrict__ a,
     float acc;
     if (q < 5) {
       acc = 0.f;
-      for (int h = 0; h < 16; ++h) acc += P.p[25][q * 16 + h] * s[L.eh + h];
+      for (int h = 0; h < 16; ++h) acc += sw[aw.e2 + q * 16 + h] * s[L.eh + h];
     } else {
       acc = e[5];
     }
@@ -182,20 +251,42 @@ __global__ void __launch_bounds__(FT)
 frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __restrict__ a,
                            const float* __restrict__ e, const float* __restrict__ saved,
                            const float* __restrict__ d_enc_a, const float* __restrict__ d_enc_e) {
-  extern __shared__ float s[];
+  extern __shared__ __align__(16) float s[];
   const FrameLayout L = frame_layout(d.D, d.M, d.A);
+  const int D = d.D, M = d.M, A = d.A;
   float* g = s + L.end - L.a1;                  // g[L.<act>] = gradient buffer of activation <act> (offsets >= a1)
-  for (int i = threadIdx.x; i < NB * d.D * WIN; i += FT) s[L.x0 + i] = a[i];
+  float* sw = s + ((2 * L.end - L.a1 + 3) & ~3);
+  const AttW aw = att_layout(A);
+  for (int i = threadIdx.x; i < NB * D * WIN; i += FT) s[L.x0 + i] = a[i];
   for (int i = threadIdx.x; i < L.end - L.a1; i += FT) s[L.a1 + i] = saved[i];
+  {
+    const int cin[6] = {A, 16, 8, 4, 2, 8}, cout[6] = {16, 8, 4, 2, 1, 8}, K[6] = {3, 3, 3, 3, 3, 1};
+    for (int i = 0; i < 6; ++i) stage(sw + aw.w[i], P.p[12 + 2 * i], cout[i] * cin[i] * K[i]);
+    if (d.has_exp) stage(sw + aw.e2, P.p[25], 80);
+  }
   __syncthreads();
 
   // enc_a = sum_t y[t] feat[t]: d_y, d_feat; then softmax
   if (threadIdx.x < NB) {
     float acc = 0.f;
-    for (int j = 0; j < d.A; ++j) acc += d_enc_a[j] * s[L.f2 + threadIdx.x * d.A + j];
+    for (int j = 0; j < A; ++j) acc += d_enc_a[j] * s[L.f2 + threadIdx.x * A + j];
     g[L.y + threadIdx.x] = acc;
   }
-  for (int i = threadIdx.x; i < NB * d.A; i += FT) g[L.f2 + i] = s[L.y + i / d.A] * d_enc_a[i % d.A];
+  for (int i = threadIdx.x; i < NB * A; i += FT) g[L.f2 + i] = s[L.y + i / A] * d_enc_a[i % A];
+  if (d.has_exp) {
+    // enc_e[q<5] = sum_h W2[q][h] eh[h], eh = relu(W1 e[:5]); 80 + 80 threads own one weight each
+    const int t = (int)threadIdx.x - 64;
+    if (t >= 0 && t < 80) {
+      const int q = t / 16, h = t % 16;
+      G.p[25][t] = (d_enc_e ? d_enc_e[q] : 0.f) * s[L.eh + h];
+    } else if (t >= 80 && t < 160) {
+      const int i = (t - 80) % 5, h = (t - 80) / 5;
+      float dh = 0.f;
+      if (d_enc_e && s[L.eh + h] > 0.f)
+        for (int q = 0; q < 5; ++q) dh += sw[aw.e2 + q * 16 + h] * d_enc_e[q];
+      G.p[24][h * 5 + i] = dh * e[i];
+    }
+  }
   __syncthreads();
   if (threadIdx.x < NB) {
     float dot = 0.f;
@@ -203,38 +294,31 @@ frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __
     g[L.z + threadIdx.x] = s[L.y + threadIdx.x] * (g[L.y + threadIdx.x] - dot);
   }
   __syncthreads();
-  conv_backward(s + L.c5, g + L.z, P.p[22], G.p[22], G.p[23], g + L.c5, 1, NB, NB, 1, 1, 1, 1, 0, true, false);   __syncthreads();
-  conv_backward(s + L.c4, g + L.c5, P.p[20], G.p[20], G.p[21], g + L.c4, 1, 2, 1, NB, NB, 1, 3, 1, true, false);  __syncthreads();
-  conv_backward(s + L.c3, g + L.c4, P.p[18], G.p[18], G.p[19], g + L.c3, 1, 4, 2, NB, NB, 1, 3, 1, true, false);  __syncthreads();
-  conv_backward(s + L.c2, g + L.c3, P.p[16], G.p[16], G.p[17], g + L.c2, 1, 8, 4, NB, NB, 1, 3, 1, true, false);  __syncthreads();
-  conv_backward(s + L.c1, g + L.c2, P.p[14], G.p[14], G.p[15], g + L.c1, 1, 16, 8, NB, NB, 1, 3, 1, true, false); __syncthreads();
-  conv_backward(s + L.xt, g + L.c1, P.p[12], G.p[12], G.p[13], g + L.xt, 1, d.A, 16, NB, NB, 1, 3, 1, false, false);
+  conv_backward(s + L.c5, g + L.z, sw + aw.w[5], G.p[22], G.p[23], g + L.c5, 1, NB, NB, 1, 1, 1, 1, 0, true, false);   __syncthreads();
+  conv_backward(s + L.c4, g + L.c5, sw + aw.w[4], G.p[20], G.p[21], g + L.c4, 1, 2, 1, NB, NB, 1, 3, 1, true, false);  __syncthreads();
+  conv_backward(s + L.c3, g + L.c4, sw + aw.w[3], G.p[18], G.p[19], g + L.c3, 1, 4, 2, NB, NB, 1, 3, 1, true, false);  __syncthreads();
+  conv_backward(s + L.c2, g + L.c3, sw + aw.w[2], G.p[16], G.p[17], g + L.c2, 1, 8, 4, NB, NB, 1, 3, 1, true, false);  __syncthreads();
+  conv_backward(s + L.c1, g + L.c2, sw + aw.w[1], G.p[14], G.p[15], g + L.c1, 1, 16, 8, NB, NB, 1, 3, 1, true, false); __syncthreads();
+  conv_backward(s + L.xt, g + L.c1, sw + aw.w[0], G.p[12], G.p[13], g + L.xt, 1, A, 16, NB, NB, 1, 3, 1, false, false);
   __syncthreads();
-  for (int i = threadIdx.x; i < NB * d.A; i += FT) {            // feat[t][j] also feeds xt[j][t]
-    const int j = i % d.A, t = i / d.A;
+  for (int i = threadIdx.x; i < NB * A; i += FT) {            // feat[t][j] also feeds xt[j][t]
+    const int j = i % A, t = i / A;
     g[L.f2 + i] += g[L.xt + j * NB + t];
   }
+  stage(sw, P.p[8], 4096); stage(sw + 4096, P.p[10], A * 64);
   __syncthreads();
-  conv_backward(s + L.f1, g + L.f2, P.p[10], G.p[10], G.p[11], g + L.f1, NB, 64, d.A, 1, 1, 1, 1, 0, true, false); __syncthreads();
-  conv_backward(s + L.a4, g + L.f1, P.p[8], G.p[8], G.p[9], g + L.a4, NB, 64, 64, 1, 1, 1, 1, 0, true, false);    __syncthreads();
-  conv_backward(s + L.a3, g + L.a4, P.p[6], G.p[6], G.p[7], g + L.a3, NB, 64, 64, 2, 1, 2, 3, 1, true, false);    __syncthreads();
-  conv_backward(s + L.a2, g + L.a3, P.p[4], G.p[4], G.p[5], g + L.a2, NB, d.M, 64, 4, 2, 2, 3, 1, true, false);   __syncthreads();
-  conv_backward(s + L.a1, g + L.a2, P.p[2], G.p[2], G.p[3], g + L.a1, NB, d.M, d.M, 8, 4, 2, 3, 1, true, false);  __syncthreads();
-  conv_backward(s + L.x0, g + L.a1, P.p[0], G.p[0], G.p[1], nullptr, NB, d.D, d.M, 16, 8, 2, 3, 1, false, false);
-
-  if (d.has_exp) {
-    // enc_e[q<5] = sum_h W2[q][h] eh[h], eh = relu(W1 e[:5]); the block's first 80 + 80 threads own one weight each
-    if (threadIdx.x < 80) {
-      const int q = threadIdx.x / 16, h = threadIdx.x % 16;
-      G.p[25][threadIdx.x] = (d_enc_e ? d_enc_e[q] : 0.f) * s[L.eh + h];
-    } else if (threadIdx.x < 160) {
-      const int i = (threadIdx.x - 80) % 5, h = (threadIdx.x - 80) / 5;
-      float dh = 0.f;
-      if (d_enc_e && s[L.eh + h] > 0.f)
-        for (int q = 0; q < 5; ++q) dh += P.p[25][q * 16 + h] * d_enc_e[q];
-      G.p[24][h * 5 + i] = dh * e[i];
-    }
-  }
+  conv_backward(s + L.f1, g + L.f2, sw + 4096, G.p[10], G.p[11], g + L.f1, NB, 64, A, 1, 1, 1, 1, 0, true, false); __syncthreads();
+  conv_backward(s + L.a4, g + L.f1, sw, G.p[8], G.p[9], g + L.a4, NB, 64, 64, 1, 1, 1, 1, 0, true, false);         __syncthreads();
+  stage(sw, P.p[6], 64 * 64 * 3);
+  __syncthreads();
+  conv_backward(s + L.a3, g + L.a4, sw, G.p[6], G.p[7], g + L.a3, NB, 64, 64, 2, 1, 2, 3, 1, true, false);         __syncthreads();
+  stage(sw, P.p[4], 64 * M * 3);
+  __syncthreads();
+  conv_backward(s + L.a2, g + L.a3, sw, G.p[4], G.p[5], g + L.a2, NB, M, 64, 4, 2, 2, 3, 1, true, false);          __syncthreads();
+  stage(sw, P.p[2], M * M * 3);
+  __syncthreads();
+  conv_backward(s + L.a1, g + L.a2, sw, G.p[2], G.p[3], g + L.a1, NB, M, M, 8, 4, 2, 3, 1, true, false);           __syncthreads();
+  conv_backward(s + L.x0, g + L.a1, nullptr, G.p[0], G.p[1], nullptr, NB, D, M, 16, 8, 2, 3, 1, false, false);
 }
 
 bool g_attr_set = false;
@@ -252,7 +336,7 @@ inline int set_lds_limit() {
 inline bool dims_ok(int D, int M, int A) {
   if (D < 1 || M < 1 || A < 1) return false;
   const FrameLayout L = frame_layout(D, M, A);
-  return (size_t)(2 * L.end - L.a1) * sizeof(float) <= 160u * 1024u;
+  return (size_t)(2 * L.end - L.a1 + 4 + weight_stage_floats(D, M, A)) * sizeof(float) <= 160u * 1024u;
 }
 
 }  // namespace
@@ -283,7 +367,8 @@ int instag_frame_code_forward(const float* a, const float* e, const float* const
   if (int rc = set_lds_limit()) return rc;
   const FrameLayout L = frame_layout(dim_in, mid, dim_aud);
   const FrameDims d{dim_in, mid, dim_aud, has_exp};
-  frame_code_forward_kernel<<<1, FT, (size_t)L.end * sizeof(float), (hipStream_t)stream>>>(d, P, a, e, enc_a, enc_e,
+  frame_code_forward_kernel<<<1, FT, (size_t)(L.end + 4 + weight_stage_floats(dim_in, mid, dim_aud)) * sizeof(float),
+                              (hipStream_t)stream>>>(d, P, a, e, enc_a, enc_e,
                                                                                         saved);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
@@ -305,7 +390,8 @@ int instag_frame_code_backward(const float* a, const float* e, const float* cons
   if (int rc = set_lds_limit()) return rc;
   const FrameLayout L = frame_layout(dim_in, mid, dim_aud);
   const FrameDims d{dim_in, mid, dim_aud, has_exp};
-  frame_code_backward_kernel<<<1, FT, (size_t)(2 * L.end - L.a1) * sizeof(float), (hipStream_t)stream>>>(
+  frame_code_backward_kernel<<<1, FT, (size_t)(2 * L.end - L.a1 + 4 + weight_stage_floats(dim_in, mid, dim_aud)) *
+                                          sizeof(float), (hipStream_t)stream>>>(
       d, P, G, a, e, saved, d_enc_a, d_enc_e);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;

@@ -225,6 +225,22 @@ motion_l1_reg_backward_kernel(int N, const float* __restrict__ h, const float* _
   dp[3] = 0.f; dp[4] = 0.f; dp[5] = 0.f;
 }
 
+// ---- densification statistics (train_face.py:626-629, scene/gaussian_model.py add_densification_stats) ------------
+//   max_radii2D[vis] = max(max_radii2D[vis], radii[vis]); xyz_gradient_accum[vis] += ||viewspace_grad[vis, :2]||;
+//   denom[vis] += 1          with vis = radii > 0
+__global__ void __launch_bounds__(GB)
+densify_stats_kernel(int N, const float* __restrict__ vs_grad, const int32_t* __restrict__ radii,
+                     float* __restrict__ max_radii2D, float* __restrict__ grad_accum, float* __restrict__ denom) {
+  const int i = blockIdx.x * GB + threadIdx.x;
+  if (i >= N) return;
+  const int r = radii[i];
+  if (r <= 0) return;
+  max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+  const float gx = vs_grad[3 * i], gy = vs_grad[3 * i + 1];
+  grad_accum[i] += sqrtf(gx * gx + gy * gy);
+  denom[i] += 1.f;
+}
+
 inline int row_blocks(int N) { return std::max(1, std::min(2048, (N + GB - 1) / GB)); }
 
 }  // namespace
@@ -303,6 +319,16 @@ int instag_motion_l1_reg_backward(const float* h, const float* p, const float* g
   INSTAG_REQUIRE(h && p && g && d_h && d_p, "motion_l1_reg_backward: NULL tensor");
   INSTAG_REQUIRE(N >= 1, "motion_l1_reg: N must be >= 1");
   motion_l1_reg_backward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, h, p, g, d_h, d_p);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_densify_stats(const float* viewspace_grad, const int32_t* radii, float* max_radii2D, float* grad_accum,
+                         float* denom, int32_t N, instag_stream_t stream) {
+  INSTAG_REQUIRE(viewspace_grad && radii && max_radii2D && grad_accum && denom, "densify_stats: NULL tensor");
+  if (N == 0) return INSTAG_OK;
+  densify_stats_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, viewspace_grad, radii, max_radii2D,
+                                                                         grad_accum, denom);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -538,67 +538,94 @@ triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
   }
 }
 
-__global__ void __launch_bounds__(GRID_BLOCK)
+// Backward, stage 1: one point per thread across the three planes.  The three table gradients of the workgroup's
+// points accumulate in LDS (3T floats, float atomics), d/dxyz stays in registers and is written once; the LDS copy
+// is then stored to the workgroup's slice of `ws` with plain coalesced stores (no global atomics: with ~400 points
+// per workgroup nearly every cell of every level is touched, so an atomic flush would cost 3T global atomics per
+// workgroup).  Stage 2 sums the slices in a fixed order.
+constexpr int TP_BWD_BLOCK = 512;
+constexpr uint32_t TP_BWD_MAX_BLOCKS = 256;
+
+inline unsigned tp_bwd_blocks(uint32_t N) {
+  return (unsigned)std::max<uint32_t>(1u, std::min<uint32_t>(div_up<uint32_t>(N, TP_BWD_BLOCK), TP_BWD_MAX_BLOCKS));
+}
+
+__global__ void __launch_bounds__(TP_BWD_BLOCK)
 triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]*/, float* __restrict__ dxyz /*[N,3] or null*/,
-                         float* __restrict__ dtab0, float* __restrict__ dtab1, float* __restrict__ dtab2) {
-  extern __shared__ __align__(16) float s_mem[];
+                         float* __restrict__ ws /*[gridDim.x][3T]*/) {
+  extern __shared__ __align__(16) float s_acc[];      // [3][T]
+  __shared__ TpLevel s_lv[TP_MAX_L];
   const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;
   const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
   const uint32_t T = (uint32_t)a.offsets[a.L];
-  __shared__ TpLevel s_lv[TP_MAX_L];
-  float* s_tab = s_mem;
-  float* s_acc = s_mem + T;
   const float inv2b = 1.0f / (2.0f * a.bound);
+  for (uint32_t i = threadIdx.x; i < 3 * T; i += TP_BWD_BLOCK) s_acc[i] = 0.f;
   tp_levels(a, s_lv);
-  // this thread's points: at most ceil(per_block / GRID_BLOCK); d/dxyz is accumulated across the three planes in
-  // global memory (plain read-modify-write: each point is owned by exactly one thread of one block)
-  for (int plane = 0; plane < 3; ++plane) {
-    float* dtab = plane == 0 ? dtab0 : (plane == 1 ? dtab1 : dtab2);
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < T; i += GRID_BLOCK) { s_tab[i] = a.tables[plane][i]; s_acc[i] = 0.f; }
-    __syncthreads();
-    for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
-      const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
-      float xw[2], x[2];
+  __syncthreads();
+  for (uint32_t b = b0 + threadIdx.x; b < b1; b += TP_BWD_BLOCK) {
+    const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
+    float d[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int plane = 0; plane < 3; ++plane) {
+      float xw[2];
       plane_coords(plane, p, xw);
-      x[0] = (xw[0] + a.bound) * inv2b;
-      x[1] = (xw[1] + a.bound) * inv2b;
-      const bool oob = x[0] < 0.f || x[0] > 1.f || x[1] < 0.f || x[1] > 1.f;
-      if (oob) continue;
-      const float* g = grad + (size_t)b * 3 * a.L + plane * a.L;
+      const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
+      if (x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f) continue;
+      const float* __restrict__ g = grad + (size_t)b * 3 * a.L + plane * a.L;
+      const float* __restrict__ tab = a.tables[plane];
+      float* acc = s_acc + plane * T;
       float gx = 0.f, gy = 0.f;
+#pragma unroll 4
       for (uint32_t l = 0; l < a.L; ++l) {
         const TpLevel lv = s_lv[l];
         const float gl = g[l];
-        const float px = x[0] * lv.scale + 0.5f, py = x[1] * lv.scale + 0.5f;
+        const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
         const float flx = floorf(px), fly = floorf(py);
         const float fx = px - flx, fy = py - fly;
         const uint32_t i00 = lv.offset + (uint32_t)flx + (uint32_t)fly * lv.stride;
         const uint32_t i10 = i00 + 1, i01 = i00 + lv.stride, i11 = i01 + 1;
-        __hip_atomic_fetch_add(&s_acc[i00], (1.f - fx) * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&s_acc[i10], fx * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&s_acc[i01], (1.f - fx) * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&s_acc[i11], fx * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[i00], (1.f - fx) * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[i10], fx * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[i01], (1.f - fx) * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&acc[i11], fx * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (dxyz) {
-          const float v00 = s_tab[i00], v10 = s_tab[i10], v01 = s_tab[i01], v11 = s_tab[i11];
+          const float v00 = tab[i00], v10 = tab[i10], v01 = tab[i01], v11 = tab[i11];
           // dy_dx of kernel_grid (gridencoder.cu:201-244) for D=2, linear interpolation
           gx += gl * lv.scale * ((1.f - fy) * (v10 - v00) + fy * (v11 - v01));
           gy += gl * lv.scale * ((1.f - fx) * (v01 - v00) + fx * (v11 - v10));
         }
       }
-      if (dxyz) {
-        gx *= inv2b; gy *= inv2b;
-        float* d = dxyz + (size_t)b * 3;
-        const int ia = plane == 1 ? 1 : 0, ib = plane == 0 ? 1 : 2;
-        d[ia] += gx;
-        d[ib] += gy;
-      }
+      d[plane == 1 ? 1 : 0] += gx * inv2b;
+      d[plane == 0 ? 1 : 2] += gy * inv2b;
     }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < T; i += GRID_BLOCK) {
-      const float v = s_acc[i];
-      if (v != 0.f) atomicAdd(&dtab[i], v);
-    }
+    if (dxyz) { dxyz[3 * (size_t)b] = d[0]; dxyz[3 * (size_t)b + 1] = d[1]; dxyz[3 * (size_t)b + 2] = d[2]; }
+  }
+  __syncthreads();
+  float* out = ws + (size_t)blockIdx.x * 3 * T;
+  for (uint32_t i = threadIdx.x; i < 3 * T; i += TP_BWD_BLOCK) out[i] = s_acc[i];
+}
+
+// stage 2: dtab[plane][i] = sum over workgroup slices, fixed order.  32 cells x 8 slice-groups per workgroup.
+__global__ void __launch_bounds__(256)
+triplane_reduce_kernel(const float* __restrict__ ws, uint32_t nslices, uint32_t T, float* __restrict__ dtab0,
+                       float* __restrict__ dtab1, float* __restrict__ dtab2) {
+  __shared__ float s_part[8][32];
+  const uint32_t cell = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+  const uint32_t per = (nslices + 7) / 8;
+  const uint32_t s0 = grp * per, s1 = min(nslices, s0 + per);
+  float acc = 0.f;
+  if (cell < 3 * T) {
+#pragma unroll 8
+    for (uint32_t sl = s0; sl < s1; ++sl) acc += ws[(size_t)sl * 3 * T + cell];
+  }
+  s_part[grp][threadIdx.x & 31] = acc;
+  __syncthreads();
+  if (threadIdx.x < 32 && cell < 3 * T) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += s_part[k][threadIdx.x];
+    const uint32_t plane = cell / T, i = cell - plane * T;
+    (plane == 0 ? dtab0 : (plane == 1 ? dtab1 : dtab2))[i] = v;
   }
 }
 
@@ -623,21 +650,44 @@ int instag_triplane_forward(const float* xyz, const float* table_xy, const float
   return INSTAG_OK;
 }
 
+size_t instag_triplane_backward_workspace_bytes(uint32_t N, uint32_t total_params) {
+  return (size_t)instag::tp_bwd_blocks(N) * 3 * total_params * sizeof(float);
+}
+
 int instag_triplane_backward(const float* grad, const float* xyz, const float* table_xy, const float* table_yz,
                              const float* table_xz, const int32_t* offsets, float* dxyz, float* dtable_xy,
-                             float* dtable_yz, float* dtable_xz, uint32_t N, uint32_t L, float S, uint32_t H,
-                             float bound, uint32_t total_params, instag_stream_t stream) {
+                             float* dtable_yz, float* dtable_xz, void* workspace, size_t workspace_bytes, uint32_t N,
+                             uint32_t L, float S, uint32_t H, float bound, uint32_t total_params,
+                             instag_stream_t stream) {
   using namespace instag;
   INSTAG_REQUIRE(grad && xyz && table_xy && table_yz && table_xz && offsets && dtable_xy && dtable_yz && dtable_xz,
                  "triplane_backward: NULL tensor");
   INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
-  INSTAG_REQUIRE(total_params * sizeof(float) <= 64 * 1024, "triplane: a plane's table must fit 64 KB of LDS");
-  if (N == 0) return INSTAG_OK;
-  TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound};
+  INSTAG_REQUIRE((size_t)3 * total_params * sizeof(float) <= 150 * 1024,
+                 "triplane: the three table gradients must fit 150 KB of LDS");
   hipStream_t s = (hipStream_t)stream;
+  if (N == 0) {
+    for (float* d : {dtable_xy, dtable_yz, dtable_xz})
+      INSTAG_CHECK_HIP(hipMemsetAsync(d, 0, (size_t)total_params * sizeof(float), s));
+    return INSTAG_OK;
+  }
+  const unsigned blocks = tp_bwd_blocks(N);
+  const size_t need = (size_t)blocks * 3 * total_params * sizeof(float);
+  if (!workspace || workspace_bytes < need) { set_error("triplane_backward: workspace too small"); return INSTAG_E_SPACE; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(triplane_backward_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound};
   ProfScope p(K_GRID_BWD, s);
-  triplane_backward_kernel<<<bwd_blocks(N), GRID_BLOCK, 2 * total_params * sizeof(float), s>>>(
-      a, grad, dxyz, dtable_xy, dtable_yz, dtable_xz);
+  triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)3 * total_params * sizeof(float), s>>>(
+      a, grad, dxyz, (float*)workspace);
+  INSTAG_CHECK_LAUNCH();
+  triplane_reduce_kernel<<<div_up<uint32_t>(3 * total_params, 32), 256, 0, s>>>((const float*)workspace, blocks,
+                                                                              total_params, dtable_xy, dtable_yz,
+                                                                              dtable_xz);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

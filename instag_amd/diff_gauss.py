@@ -195,6 +195,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 extra_attrs, raster_settings):
         _require_cuda(means3D=means3D)
+        ctx.set_materialize_grads(False)      # unused outputs (depth / normal / extra) stay NULL in backward
         m3, shs, col = _f32c(means3D), _f32c(sh), _f32c(colors_precomp)
         op, sc, ro = _f32c(opacities), _f32c(scales), _f32c(rotations)
         cov, ex = _f32c(cov3Ds_precomp), _f32c(extra_attrs)

@@ -20,6 +20,7 @@ class _MotionGlue(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc_x, aud, eye_pre, enc_a, enc_e):
         L = _lib.lib()
+        ctx.set_materialize_grads(False)
         enc_x, aud, eye_pre, enc_a, enc_e = _c(enc_x), _c(aud), _c(eye_pre), _c(enc_a), _c(enc_e)
         N, KX = enc_x.shape
         KA, KE = aud.shape[1], eye_pre.shape[1]
@@ -38,6 +39,8 @@ class _MotionGlue(torch.autograd.Function):
         aud, eye_pre, enc_a, enc_e, amb = ctx.saved_tensors
         N, KX, KA, KE = ctx.dims
         dev = aud.device
+        if d_h_in is None:
+            d_h_in = torch.zeros(N, KX + KA + KE, dtype=torch.float32, device=dev)
         d_h_in = _c(d_h_in)
         d_amb = None if d_amb is None else _c(d_amb)
         d_enc_x = torch.empty(N, KX, dtype=torch.float32, device=dev)
@@ -129,3 +132,14 @@ class _MotionL1Reg(torch.autograd.Function):
 def motion_l1_reg(h, p):
     """mean|d_xyz| + mean|d_rot| + mean|d_opa| + mean|d_scale| + mean|p_xyz| from the raw head outputs."""
     return _MotionL1Reg.apply(h, p)
+
+
+@torch.no_grad()
+def densify_stats(viewspace_grad, radii, max_radii2D, xyz_gradient_accum, denom):
+    """In-place densification statistics of one step (train_face.py:626-629) as one launch."""
+    N = radii.shape[0]
+    assert viewspace_grad.is_contiguous() and max_radii2D.is_contiguous() and xyz_gradient_accum.is_contiguous() \
+        and denom.is_contiguous() and radii.dtype == torch.int32 and max_radii2D.dtype == torch.float32
+    check(_lib.lib().instag_densify_stats(ptr(viewspace_grad), ptr(radii.contiguous()), ptr(max_radii2D),
+                                          ptr(xyz_gradient_accum), ptr(denom), N, _lib.current_stream()),
+          "densify_stats")

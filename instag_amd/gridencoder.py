@@ -173,11 +173,14 @@ class _tri_plane_encode(Function):
         xyz, t0, t1, t2, offsets = ctx.saved_tensors
         N, L, S, H, bound, T = ctx.meta
         grad = grad.contiguous().float()
-        dxyz = torch.zeros_like(xyz) if ctx.needs_input_grad[0] else None
-        dt = torch.zeros(3, T, 1, device=xyz.device, dtype=torch.float32)
-        check(_lib.lib().instag_triplane_backward(ptr(grad), ptr(xyz), ptr(t0), ptr(t1), ptr(t2), ptr(offsets),
-                                                  ptr(dxyz), ptr(dt[0]), ptr(dt[1]), ptr(dt[2]), N, L, S, H, bound, T,
-                                                  _lib.current_stream()), "triplane_backward")
+        L_ = _lib.lib()
+        dxyz = torch.empty_like(xyz) if ctx.needs_input_grad[0] else None
+        dt = torch.empty(3, T, 1, device=xyz.device, dtype=torch.float32)
+        ws_bytes = L_.instag_triplane_backward_workspace_bytes(N, T)
+        ws = torch.empty(max(1, ws_bytes // 4), device=xyz.device, dtype=torch.float32)
+        check(L_.instag_triplane_backward(ptr(grad), ptr(xyz), ptr(t0), ptr(t1), ptr(t2), ptr(offsets),
+                                          ptr(dxyz), ptr(dt[0]), ptr(dt[1]), ptr(dt[2]), ptr(ws), ws_bytes, N, L, S, H,
+                                          bound, T, _lib.current_stream()), "triplane_backward")
         return dxyz, dt[0], dt[1], dt[2], None, None, None, None
 
 
@@ -190,7 +193,7 @@ def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
                and e.base_resolution == e0.base_resolution and e.per_level_scale == e0.per_level_scale
                and e.gridtype_id == 0 and not e.align_corners and e.interp_id == 0
                and e.embeddings.shape == e0.embeddings.shape and e.embeddings.is_cuda for e in encs)
-    if not (same and e0.num_levels <= 16 and e0.embeddings.shape[0] * 4 <= 64 * 1024):
+    if not (same and e0.num_levels <= 16 and e0.embeddings.shape[0] * 12 <= 150 * 1024):
         return False
     # the fused kernels index every level densely (x + y*(res+1)): no level may be hashed
     for i in range(e0.num_levels):

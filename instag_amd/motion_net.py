@@ -25,6 +25,28 @@ def _side_stream(device, index=0):
     return _SIDE_STREAMS[key]
 
 
+class LazyOutputs(dict):
+    """dict whose values may be zero-argument callables, evaluated (once) on first access.  The fused render
+    path consumes only the raw head outputs ``_h`` / ``_p``; the derived entries of the reference's result dict
+    (d_xyz = h[:, :3] * 1e-2, p_scale = tanh(.)*0.25+1, ...) cost a launch each and are built on demand."""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if callable(v) and not torch.is_tensor(v):
+            v = v()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
 _AUDIO_DIMS = (("esperanto", 44), ("deepspeech", 29), ("hubert", 1024), ("ave", 32))
 
 
@@ -231,14 +253,17 @@ class MotionNetwork(_TriPlaneField):
 
     def forward(self, x, a, e=None, c=None):
         _, amb_aud, amb_eye, h = self._trunk(x, a, e, c)
-        results = {
-            "d_xyz": h[..., :3] * 1e-2, "d_rot": h[..., 3:7], "d_opa": h[..., 7:8], "d_scale": h[..., 8:11],
-            "ambient_aud": amb_aud, "ambient_eye": amb_eye,
-            "_h": h,          # raw head output, consumed by the fused deform / regulariser operators
-        }
+        def outputs(h, amb_aud, amb_eye):
+            return LazyOutputs({
+                "d_xyz": lambda: h[..., :3] * 1e-2, "d_rot": h[..., 3:7], "d_opa": h[..., 7:8],
+                "d_scale": h[..., 8:11], "ambient_aud": amb_aud, "ambient_eye": amb_eye,
+                "_h": h,          # raw head output, consumed by the fused deform / regulariser operators
+            })
+
+        results = outputs(h, amb_aud, amb_eye)
         # consumed without gradients by the mouth branch at inference (gaussian_renderer/__init__.py:362-363);
         # detached so that a finished step does not keep its autograd graph (and grad accumulators) alive
-        self.cache = {k: v.detach() for k, v in results.items()}
+        self.cache = outputs(h.detach(), amb_aud.detach(), None if amb_eye is None else amb_eye.detach())
         return results
 
     def get_params(self, lr, lr_net, wd=0):
@@ -274,14 +299,14 @@ class PersonalizedMotionNetwork(_TriPlaneField):
         enc_x, amb_aud, amb_eye, h = self._trunk(x, a, e, c)
         face = self.args.type == "face"
         p = self.align_net(enc_x)
-        return {
-            "d_xyz": h[..., :3] * 1e-2, "d_rot": h[..., 3:7],
+        return LazyOutputs({
+            "d_xyz": lambda: h[..., :3] * 1e-2, "d_rot": h[..., 3:7],
             "d_opa": h[..., 7:8] if face else None, "d_scale": h[..., 8:11] if face else None,
             "ambient_aud": amb_aud, "ambient_eye": amb_eye if self.exp_eye else None,
-            "p_xyz": p[..., :3] * 1e-2,
-            "p_scale": torch.tanh(p[..., 3:] / 5) * 0.25 + 1,
+            "p_xyz": lambda: p[..., :3] * 1e-2,
+            "p_scale": lambda: torch.tanh(p[..., 3:] / 5) * 0.25 + 1,
             "_h": h, "_p": p,
-        }
+        })
 
     def get_params(self, lr, lr_net, wd=0):
         params = [

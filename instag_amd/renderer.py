@@ -80,17 +80,10 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     if personalized or align:
         p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat, exp_feat)
     if align:
-        xyz = xyz + p_motion_preds["p_xyz"]
+        p_raw = p_motion_preds.get("_p")
+        # xyz + p_xyz with p_xyz = p[:, :3] * 1e-2 as one launch
+        xyz = torch.add(xyz, p_raw[..., :3], alpha=1e-2) if p_raw is not None else xyz + p_motion_preds["p_xyz"]
     motion_preds = motion_net(xyz, audio_feat, exp_feat)
-    d_xyz, d_scale, d_rot = motion_preds["d_xyz"], motion_preds["d_scale"], motion_preds["d_rot"]
-    if personalized:
-        d_xyz = d_xyz + p_motion_preds["d_xyz"]
-        d_scale = d_scale + p_motion_preds["d_scale"]
-        d_rot = d_rot + p_motion_preds["d_rot"]
-    if align:
-        d_xyz = d_xyz * p_motion_preds["p_scale"]
-    if detach_motion:
-        d_xyz, d_scale, d_rot = d_xyz.detach(), d_scale.detach(), d_rot.detach()
 
     fused = (align and not personalized and not detach_motion and pc.get_xyz.is_cuda
              and motion_preds.get("_h") is not None and p_motion_preds.get("_p") is not None
@@ -101,6 +94,15 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         means3D, scales, rotations, opacity = deform_activate(pc.get_xyz, pc._scaling, pc._rotation, pc._opacity,
                                                               motion_preds["_h"], p_motion_preds["_p"])
     else:
+        d_xyz, d_scale, d_rot = motion_preds["d_xyz"], motion_preds["d_scale"], motion_preds["d_rot"]
+        if personalized:
+            d_xyz = d_xyz + p_motion_preds["d_xyz"]
+            d_scale = d_scale + p_motion_preds["d_scale"]
+            d_rot = d_rot + p_motion_preds["d_rot"]
+        if align:
+            d_xyz = d_xyz * p_motion_preds["p_scale"]
+        if detach_motion:
+            d_xyz, d_scale, d_rot = d_xyz.detach(), d_scale.detach(), d_rot.detach()
         means3D = pc.get_xyz + d_xyz
         opacity = pc.get_opacity
         scales = pc.scaling_activation(pc._scaling + d_scale)

@@ -47,15 +47,43 @@ class Frame:
     TENSORS = ("world_view_transform", "full_proj_transform", "camera_center", "original_image")
     DICT_TENSORS = ("auds", "au_exp", "face_mask", "hair_mask", "mouth_mask", "lips_rect")
 
+    def _named_tensors(self):
+        return [(k, getattr(self, k)) for k in self.TENSORS] + [(k, self.talking_dict[k]) for k in self.DICT_TENSORS]
+
+    def packed(self, device=None) -> "Frame":
+        """Copy whose tensors are views into ONE byte buffer, so that feeding a frame to a captured step is a
+        single device copy instead of one per tensor."""
+        named = self._named_tensors()
+        device = device if device is not None else named[0][1].device
+        offs, total = [], 0
+        for _, t in named:
+            offs.append(total)
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+        buf = torch.zeros(total, dtype=torch.uint8, device=device)
+        views = {}
+        for (k, t), o in zip(named, offs):
+            nbytes = t.numel() * t.element_size()
+            v = buf[o:o + nbytes].view(t.dtype).view(t.shape)
+            v.copy_(t)
+            views[k] = v
+        td = {k: views[k] for k in self.DICT_TENSORS}
+        f = Frame(self.image_height, self.image_width, self.FoVx, self.FoVy, views["world_view_transform"],
+                  views["full_proj_transform"], views["camera_center"], td, views["original_image"])
+        f._buf = buf
+        f._layout = tuple((k, tuple(t.shape), t.dtype) for k, t in named)
+        return f
+
     def clone_static(self):
-        td = {k: self.talking_dict[k].clone() for k in self.DICT_TENSORS}
-        return Frame(self.image_height, self.image_width, self.FoVx, self.FoVy, self.world_view_transform.clone(),
-                     self.full_proj_transform.clone(), self.camera_center.clone(), td, self.original_image.clone())
+        return self.packed()
 
     def copy_from(self, other: "Frame"):
         assert (self.image_height, self.image_width) == (other.image_height, other.image_width)
         assert abs(self.FoVx - other.FoVx) < 1e-12 and abs(self.FoVy - other.FoVy) < 1e-12, \
             "graph mode bakes the field of view into the captured launches"
+        if getattr(self, "_buf", None) is not None and getattr(other, "_buf", None) is not None \
+                and self._layout == other._layout:
+            self._buf.copy_(other._buf, non_blocking=True)
+            return
         for k in self.TENSORS:
             getattr(self, k).copy_(getattr(other, k), non_blocking=True)
         for k in self.DICT_TENSORS:
@@ -66,8 +94,9 @@ def make_frame(cam, frame_data) -> Frame:
     td = dict(auds=frame_data["auds"], au_exp=frame_data["au_exp"], face_mask=frame_data["face_mask"],
               hair_mask=frame_data["hair_mask"], mouth_mask=frame_data["mouth_mask"],
               lips_rect=frame_data["lips_rect"])
-    return Frame(cam.image_height, cam.image_width, cam.FoVx, cam.FoVy, cam.world_view_transform,
-                 cam.full_proj_transform, cam.camera_center, td, frame_data["gt_image"])
+    f = Frame(cam.image_height, cam.image_width, cam.FoVx, cam.FoVy, cam.world_view_transform,
+              cam.full_proj_transform, cam.camera_center, td, frame_data["gt_image"])
+    return f.packed() if frame_data["gt_image"].is_cuda else f
 
 
 def flat_grad_bucket(params: List[torch.Tensor]) -> torch.Tensor:
@@ -190,9 +219,17 @@ class FaceTrainer:
 
     @torch.no_grad()
     def _stats_and_optimizers(self, pkg, distributed: bool):
+        vs_grad = pkg["viewspace_points"].grad
+        g = self.g
+        if not distributed and vs_grad.is_cuda and g.max_radii2D.dtype == torch.float32 \
+                and pkg["radii"].dtype == torch.int32 and vs_grad.is_contiguous():
+            from .glue import densify_stats
+            densify_stats(vs_grad, pkg["radii"], g.max_radii2D, g.xyz_gradient_accum, g.denom)
+            self.motion_optimizer.step()
+            g.optimizer.step()
+            return
         vis = pkg["visibility_filter"]
         radii = pkg["radii"].to(self.g.max_radii2D.dtype)
-        vs_grad = pkg["viewspace_points"].grad
         norm = torch.norm(vs_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
         cnt = vis[:, None].to(norm.dtype)
         rmax = torch.where(vis, radii, torch.zeros_like(radii))

@@ -190,3 +190,20 @@ def test_face_loss_matches_torch(hair_mask_iter, size):
         assert err <= 2e-5 * max(float(b.abs().max()), 1e-4), f"{name}: {err} vs {float(b.abs().max())}"
     if hair_mask_iter:
         assert float(g_h[0][:, hair.cuda()].abs().max()) == 0.0
+
+
+def test_densify_stats_matches_torch():
+    from instag_amd.glue import densify_stats
+    g = torch.Generator().manual_seed(5)
+    N = 4099
+    vs = torch.randn(N, 3, generator=g)
+    radii = torch.randint(-1, 40, (N,), generator=g, dtype=torch.int32)
+    mr, acc, den = torch.rand(N, generator=g) * 30, torch.rand(N, 1, generator=g), torch.rand(N, 1, generator=g).round()
+    vis = radii > 0
+    mr_r = torch.where(vis, torch.max(mr, radii.float()), mr)
+    acc_r = acc + vs[:, :2].norm(dim=-1, keepdim=True) * vis[:, None]
+    den_r = den + vis[:, None].float()
+    mr_h, acc_h, den_h = mr.cuda(), acc.cuda(), den.cuda()
+    densify_stats(vs.cuda(), radii.cuda(), mr_h, acc_h, den_h)
+    assert torch.equal(mr_h.cpu(), mr_r) and torch.equal(den_h.cpu(), den_r)
+    _close(acc_h, acc_r, "grad_accum", tol=1e-6)
