@@ -76,20 +76,33 @@ __device__ __forceinline__ void store_block(float* __restrict__ Y, size_t row, b
   }
 }
 
-// ---- weights: global [O][K] row-major -> LDS [OP][KP+1], zero padded --------------------------------
-__device__ __forceinline__ void stage_weights(float* __restrict__ lds, const float* __restrict__ W, int O, int K,
-                                              int OP, int KP) {
-  const int KS = KP + 1;
-  for (int i = threadIdx.x; i < OP * KS; i += MLP_BLOCK) {
-    const int o = i / KS, k = i - o * KS;
-    lds[i] = (o < O && k < K) ? W[o * K + k] : 0.f;
-  }
+// ---- weights: global [O][K] row-major -> LDS [OP][32*KB+1], zero padded ------------------------------
+// 8 rows x 32 consecutive columns per pass: coalesced, division-free, fully unrolled (every load of a thread is
+// issued before the first wait).  The pad column (index 32*KB) is never read.
+template <int OP, int KB>
+__device__ __forceinline__ void stage_weights(float* __restrict__ lds, const float* __restrict__ W, int O, int K) {
+  constexpr int KS = KB * 32 + 1;
+  const int ro = threadIdx.x >> 5, kk = threadIdx.x & 31;
+  float v[OP / 8][KB];
+#pragma unroll
+  for (int i = 0; i < OP / 8; ++i)
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+      const int o = ro + 8 * i, k = 32 * b + kk;
+      v[i][b] = (o < O && k < K) ? W[o * K + k] : 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < OP / 8; ++i)
+#pragma unroll
+    for (int b = 0; b < KB; ++b) lds[(ro + 8 * i) * KS + 32 * b + kk] = v[i][b];
 }
 
-// Z^T = W X^T for one layer: in[KB] (layout L) -> acc[OB] (layout L)
-template <int KB, int OB>
-__device__ __forceinline__ void layer_forward(const float* __restrict__ Wl, int K, const f32x16 (&in)[KB],
-                                              f32x16 (&acc)[OB], int l31, int h) {
+// Z^T = W X^T for one layer: in[KB] (layout L) -> acc[OB] (layout L).  KQ = number of 8-feature groups of the
+// input that hold data (compile time: a run-time test per k-step would split the chain into basic blocks and
+// make the compiler shuttle the accumulators between AGPRs and VGPRs around every MFMA).
+template <int KQ, int KB, int OB>
+__device__ __forceinline__ void layer_forward(const float* __restrict__ Wl, const f32x16 (&in)[KB], f32x16 (&acc)[OB],
+                                              int l31, int h) {
   constexpr int KS = KB * 32 + 1;
 #pragma unroll
   for (int t = 0; t < OB; ++t)
@@ -99,7 +112,7 @@ __device__ __forceinline__ void layer_forward(const float* __restrict__ Wl, int 
   for (int b = 0; b < KB; ++b) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      if (32 * b + feat(r, 0) < K) {   // wave-uniform: both halves' features are padding beyond K
+      if (4 * b + (r >> 2) < KQ) {       // folds at compile time
         const int k = 32 * b + feat(r, h);
 #pragma unroll
         for (int t = 0; t < OB; ++t) {
@@ -111,10 +124,10 @@ __device__ __forceinline__ void layer_forward(const float* __restrict__ Wl, int 
   }
 }
 
-// dIn^T = W^T dZ^T for one layer: dz[OB] -> din[KB]
-template <int OB, int KB>
-__device__ __forceinline__ void layer_backward(const float* __restrict__ Wl, int O, const f32x16 (&dz)[OB],
-                                               f32x16 (&din)[KB], int l31, int h) {
+// dIn^T = W^T dZ^T for one layer: dz[OB] -> din[KB]; OQ = number of 8-feature groups of dz that hold data
+template <int OQ, int OB, int KB>
+__device__ __forceinline__ void layer_backward(const float* __restrict__ Wl, const f32x16 (&dz)[OB], f32x16 (&din)[KB],
+                                               int l31, int h) {
   constexpr int KS = KB * 32 + 1;
 #pragma unroll
   for (int b = 0; b < KB; ++b)
@@ -124,7 +137,7 @@ __device__ __forceinline__ void layer_backward(const float* __restrict__ Wl, int
   for (int t = 0; t < OB; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      if (32 * t + feat(r, 0) < O) {
+      if (4 * t + (r >> 2) < OQ) {
         const int o = 32 * t + feat(r, h);
 #pragma unroll
         for (int b = 0; b < KB; ++b) {
@@ -154,19 +167,21 @@ __device__ __forceinline__ void mask_blocks(f32x16 (&g)[NB], const f32x16 (&act)
 
 struct MlpDims { int N, K0, H, O; };
 
-template <int KB0, int HB, int NL>
+// KQ0 / HQ / OQ: input, hidden and output widths in groups of 8 features (rounded up)
+template <int KQ0, int HQ, int OQ, int NL>
 __global__ void __launch_bounds__(MLP_BLOCK)
 mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restrict__ W1,
                    const float* __restrict__ W2, const float* __restrict__ W3, float* __restrict__ Y,
                    float* __restrict__ A1, float* __restrict__ A2) {
   extern __shared__ __align__(16) float s_w[];
+  constexpr int KB0 = (KQ0 + 3) / 4, HB = (HQ + 3) / 4;
   constexpr int KP0 = KB0 * 32, HP = HB * 32;
   float* w1 = s_w;                                    // [HP][KP0+1]
   float* w2 = w1 + HP * (KP0 + 1);                    // [NL==3 ? HP : 32][HP+1]
   float* w3 = w2 + (NL == 3 ? HP : 32) * (HP + 1);    // [32][HP+1]  (NL==3 only)
-  stage_weights(w1, W1, d.H, d.K0, HP, KP0);
-  stage_weights(w2, W2, NL == 3 ? d.H : d.O, d.H, NL == 3 ? HP : 32, HP);
-  if (NL == 3) stage_weights(w3, W3, d.O, d.H, 32, HP);
+  stage_weights<HP, KB0>(w1, W1, d.H, d.K0);
+  stage_weights<(NL == 3 ? HP : 32), HB>(w2, W2, NL == 3 ? d.H : d.O, d.H);
+  if (NL == 3) stage_weights<32, HB>(w3, W3, d.O, d.H);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int ntiles = (d.N + 31) / 32;
@@ -177,7 +192,7 @@ mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restri
 #pragma unroll
     for (int b = 0; b < KB0; ++b) load_block(X, row, valid, d.K0, b, h, in0[b]);
     f32x16 h1[HB];
-    layer_forward<KB0, HB>(w1, d.K0, in0, h1, l31, h);
+    layer_forward<KQ0, KB0, HB>(w1, in0, h1, l31, h);
     relu_blocks<HB>(h1);
     if (A1) {
 #pragma unroll
@@ -186,34 +201,35 @@ mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restri
     f32x16 out[1];
     if (NL == 3) {
       f32x16 h2[HB];
-      layer_forward<HB, HB>(w2, d.H, h1, h2, l31, h);
+      layer_forward<HQ, HB, HB>(w2, h1, h2, l31, h);
       relu_blocks<HB>(h2);
       if (A2) {
 #pragma unroll
         for (int b = 0; b < HB; ++b) store_block(A2, row, valid, d.H, b, h, h2[b]);
       }
-      layer_forward<HB, 1>(w3, d.H, h2, out, l31, h);
+      layer_forward<HQ, HB, 1>(w3, h2, out, l31, h);
     } else {
-      layer_forward<HB, 1>(w2, d.H, h1, out, l31, h);
+      layer_forward<HQ, HB, 1>(w2, h1, out, l31, h);
     }
     store_block(Y, row, valid, d.O, 0, h, out[0]);
   }
 }
 
-template <int KB0, int HB, int NL>
+template <int KQ0, int HQ, int OQ, int NL>
 __global__ void __launch_bounds__(MLP_BLOCK)
 mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __restrict__ A1,
                     const float* __restrict__ A2, const float* __restrict__ W1, const float* __restrict__ W2,
                     const float* __restrict__ W3, float* __restrict__ dZ1, float* __restrict__ dZ2,
                     float* __restrict__ dX) {
   extern __shared__ __align__(16) float s_w[];
+  constexpr int KB0 = (KQ0 + 3) / 4, HB = (HQ + 3) / 4;
   constexpr int KP0 = KB0 * 32, HP = HB * 32;
   float* w1 = s_w;
   float* w2 = w1 + HP * (KP0 + 1);
   float* w3 = w2 + (NL == 3 ? HP : 32) * (HP + 1);
-  if (dX) stage_weights(w1, W1, d.H, d.K0, HP, KP0);
-  stage_weights(w2, W2, NL == 3 ? d.H : d.O, d.H, NL == 3 ? HP : 32, HP);
-  if (NL == 3) stage_weights(w3, W3, d.O, d.H, 32, HP);
+  if (dX) stage_weights<HP, KB0>(w1, W1, d.H, d.K0);
+  stage_weights<(NL == 3 ? HP : 32), HB>(w2, W2, NL == 3 ? d.H : d.O, d.H);
+  if (NL == 3) stage_weights<32, HB>(w3, W3, d.O, d.H);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int ntiles = (d.N + 31) / 32;
@@ -225,15 +241,15 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
     f32x16 g1[HB];
     if (NL == 3) {
       f32x16 g2[HB], act[HB];
-      layer_backward<1, HB>(w3, d.O, dy, g2, l31, h);
+      layer_backward<OQ, 1, HB>(w3, dy, g2, l31, h);
 #pragma unroll
       for (int b = 0; b < HB; ++b) load_block(A2, row, valid, d.H, b, h, act[b]);
       mask_blocks<HB>(g2, act);
 #pragma unroll
       for (int b = 0; b < HB; ++b) store_block(dZ2, row, valid, d.H, b, h, g2[b]);
-      layer_backward<HB, HB>(w2, d.H, g2, g1, l31, h);
+      layer_backward<HQ, HB, HB>(w2, g2, g1, l31, h);
     } else {
-      layer_backward<1, HB>(w2, d.O, dy, g1, l31, h);
+      layer_backward<OQ, 1, HB>(w2, dy, g1, l31, h);
     }
     {
       f32x16 act[HB];
@@ -245,7 +261,7 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
     for (int b = 0; b < HB; ++b) store_block(dZ1, row, valid, d.H, b, h, g1[b]);
     if (dX) {
       f32x16 gx[KB0];
-      layer_backward<HB, KB0>(w1, d.H, g1, gx, l31, h);
+      layer_backward<HQ, HB, KB0>(w1, g1, gx, l31, h);
 #pragma unroll
       for (int b = 0; b < KB0; ++b) store_block(dX, row, valid, d.K0, b, h, gx[b]);
     }
@@ -339,7 +355,14 @@ weight_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int cou
   if (g == 0 && i < count) dW[i] = ((s_part[0][e] + s_part[1][e]) + s_part[2][e]) + s_part[3][e];
 }
 
-inline int wg_blocks(int N) { return std::max(1, std::min(128, (N + 511) / 512)); }
+inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256)); }
+
+// Two workgroups per CU, each staging the weights once and walking a strided list of 32-row tiles.
+inline int mlp_blocks(int ntiles) {
+  int b = 512;
+  if (const char* e = getenv("INSTAG_MLP_BLOCKS")) b = std::max(1, atoi(e));
+  return std::max(1, std::min(b, (ntiles + 3) / 4));
+}
 
 template <int KB0, int HB, int NL>
 size_t mlp_lds_bytes() {
@@ -347,24 +370,25 @@ size_t mlp_lds_bytes() {
   return sizeof(float) * (HP * (KP0 + 1) + (NL == 3 ? HP : 32) * (HP + 1) + (NL == 3 ? 32 * (HP + 1) : 0));
 }
 
-template <int KB0, int HB, int NL>
+template <int KQ0, int HQ, int OQ, int NL>
 int run_fwd(const MlpDims& d, const float* x, const float* w1, const float* w2, const float* w3, float* y, float* a1,
             float* a2, hipStream_t s) {
   const int ntiles = (d.N + 31) / 32;
-  const int blocks = std::max(1, std::min(1024, (ntiles + 3) / 4));
+  const int blocks = mlp_blocks(ntiles);
   ProfScope p(K_MLP_FWD, s);
-  mlp_forward_kernel<KB0, HB, NL><<<blocks, MLP_BLOCK, mlp_lds_bytes<KB0, HB, NL>(), s>>>(d, x, w1, w2, w3, y, a1, a2);
+  mlp_forward_kernel<KQ0, HQ, OQ, NL><<<blocks, MLP_BLOCK, mlp_lds_bytes<(KQ0 + 3) / 4, (HQ + 3) / 4, NL>(), s>>>(
+      d, x, w1, w2, w3, y, a1, a2);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
-template <int KB0, int HB, int NL>
+template <int KQ0, int HQ, int OQ, int NL>
 int run_bwd(const MlpDims& d, const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
             const float* w3, float* dz1, float* dz2, float* dx, hipStream_t s) {
   const int ntiles = (d.N + 31) / 32;
-  const int blocks = std::max(1, std::min(1024, (ntiles + 3) / 4));
+  const int blocks = mlp_blocks(ntiles);
   ProfScope p(K_MLP_BWD, s);
-  mlp_backward_kernel<KB0, HB, NL><<<blocks, MLP_BLOCK, mlp_lds_bytes<KB0, HB, NL>(), s>>>(d, dy, a1, a2, w1, w2, w3,
-                                                                                        dz1, dz2, dx);
+  mlp_backward_kernel<KQ0, HQ, OQ, NL><<<blocks, MLP_BLOCK, mlp_lds_bytes<(KQ0 + 3) / 4, (HQ + 3) / 4, NL>(), s>>>(
+      d, dy, a1, a2, w1, w2, w3, dz1, dz2, dx);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -379,23 +403,35 @@ int run_wg(const float* dz, const float* in, int N, int O, int K, float* partial
   return INSTAG_OK;
 }
 
+// Exact 8-feature-group counts for the widths the motion networks use (74 / 36 inputs, 64 / 32 / 16 hidden,
+// 6 / 7 / 11 / 32 outputs); any other shape runs on whole 32-feature blocks (zero-padded weights).
 #define MLP_DISPATCH(FN, ...)                                                                      \
   do {                                                                                             \
+    const int kq = (d.K0 + 7) / 8, hq = (d.H + 7) / 8, oq = (d.O + 7) / 8;                          \
+    if (NL == 3) {                                                                                 \
+      if (kq == 10 && hq == 8 && oq == 2) return FN<10, 8, 2, 3>(__VA_ARGS__);                      \
+      if (kq == 10 && hq == 4 && oq == 2) return FN<10, 4, 2, 3>(__VA_ARGS__);                      \
+      if (kq == 10 && hq == 2 && oq == 1) return FN<10, 2, 1, 3>(__VA_ARGS__);                      \
+    } else {                                                                                       \
+      if (kq == 5 && hq == 4 && oq == 4) return FN<5, 4, 4, 2>(__VA_ARGS__);                        \
+      if (kq == 5 && hq == 4 && oq == 1) return FN<5, 4, 1, 2>(__VA_ARGS__);                        \
+      if (kq == 5 && hq == 2 && oq == 1) return FN<5, 2, 1, 2>(__VA_ARGS__);                        \
+    }                                                                                              \
     const int kb = (d.K0 + 31) / 32, hb = (d.H + 31) / 32;                                           \
     if (NL == 2) {                                                                                 \
-      if (kb == 1 && hb == 1) return FN<1, 1, 2>(__VA_ARGS__);                                      \
-      if (kb == 2 && hb == 1) return FN<2, 1, 2>(__VA_ARGS__);                                      \
-      if (kb == 3 && hb == 1) return FN<3, 1, 2>(__VA_ARGS__);                                      \
-      if (kb == 1 && hb == 2) return FN<1, 2, 2>(__VA_ARGS__);                                      \
-      if (kb == 2 && hb == 2) return FN<2, 2, 2>(__VA_ARGS__);                                      \
-      if (kb == 3 && hb == 2) return FN<3, 2, 2>(__VA_ARGS__);                                      \
+      if (kb == 1 && hb == 1) return FN<4, 4, 4, 2>(__VA_ARGS__);                                   \
+      if (kb == 2 && hb == 1) return FN<8, 4, 4, 2>(__VA_ARGS__);                                   \
+      if (kb == 3 && hb == 1) return FN<12, 4, 4, 2>(__VA_ARGS__);                                  \
+      if (kb == 1 && hb == 2) return FN<4, 8, 4, 2>(__VA_ARGS__);                                   \
+      if (kb == 2 && hb == 2) return FN<8, 8, 4, 2>(__VA_ARGS__);                                   \
+      if (kb == 3 && hb == 2) return FN<12, 8, 4, 2>(__VA_ARGS__);                                  \
     } else {                                                                                       \
-      if (kb == 1 && hb == 1) return FN<1, 1, 3>(__VA_ARGS__);                                      \
-      if (kb == 2 && hb == 1) return FN<2, 1, 3>(__VA_ARGS__);                                      \
-      if (kb == 3 && hb == 1) return FN<3, 1, 3>(__VA_ARGS__);                                      \
-      if (kb == 1 && hb == 2) return FN<1, 2, 3>(__VA_ARGS__);                                      \
-      if (kb == 2 && hb == 2) return FN<2, 2, 3>(__VA_ARGS__);                                      \
-      if (kb == 3 && hb == 2) return FN<3, 2, 3>(__VA_ARGS__);                                      \
+      if (kb == 1 && hb == 1) return FN<4, 4, 4, 3>(__VA_ARGS__);                                   \
+      if (kb == 2 && hb == 1) return FN<8, 4, 4, 3>(__VA_ARGS__);                                   \
+      if (kb == 3 && hb == 1) return FN<12, 4, 4, 3>(__VA_ARGS__);                                  \
+      if (kb == 1 && hb == 2) return FN<4, 8, 4, 3>(__VA_ARGS__);                                   \
+      if (kb == 2 && hb == 2) return FN<8, 8, 4, 3>(__VA_ARGS__);                                   \
+      if (kb == 3 && hb == 2) return FN<12, 8, 4, 3>(__VA_ARGS__);                                  \
     }                                                                                              \
   } while (0)
 
