@@ -134,11 +134,17 @@ size_t instag_raster_backward_workspace_bytes(int32_t N, int64_t R);
 int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t geom_bytes,
                                  int32_t* radii, int64_t* num_rendered /* (host) */,
                                  instag_stream_t stream);
-/* stage 2: outputs color [3,H,W], depth [1,H,W], normal [3,H,W], alpha [1,H,W], extra [E,H,W] (NULL if E==0) */
+/* stage 2: outputs color [3,H,W], depth [1,H,W], normal [3,H,W], alpha [1,H,W], extra [E,H,W] (NULL if E==0).
+ * aux_colors [N,3] / out_aux [3,H,W] (both NULL or both set): a second colour set blended over the SAME instances
+ * with the same alpha and transmittance, out_aux = sum c_aux alpha T + T_final bg.  It equals the colour image
+ * of a second rasterizer call with colors_precomp = aux_colors on the same (detached) geometry, which is how the
+ * reference renders the attention map (gaussian_renderer/__init__.py:243-258), without preprocessing, binning
+ * and sorting twice. */
 int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes,
                                  void* binning, size_t binning_bytes, void* image, size_t image_bytes,
                                  int64_t R, float* out_color, float* out_depth, float* out_normal,
-                                 float* out_alpha, float* out_extra, instag_stream_t stream);
+                                 float* out_alpha, float* out_extra, const float* aux_colors, float* out_aux,
+                                 instag_stream_t stream);
 /* Sync-free forward (hipGraph-capturable): stage1 + stage2 in one call with a caller-chosen instance
  * capacity instead of the host round trip.  binning / backward workspace are sized for `capacity`
  * (instag_raster_binning_bytes(capacity), instag_raster_backward_workspace_bytes(N, capacity)) and
@@ -148,7 +154,8 @@ int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size
                                    void* binning, size_t binning_bytes, void* image, size_t image_bytes,
                                    int64_t capacity, int32_t* radii, int32_t* status, float* out_color,
                                    float* out_depth, float* out_normal, float* out_alpha,
-                                   float* out_extra, instag_stream_t stream);
+                                   float* out_extra, const float* aux_colors, float* out_aux,
+                                   instag_stream_t stream);
 /* backward.  dL_dout_* may be NULL (treated as zero).  Gradient outputs may be NULL when not
  * needed; non-NULL ones are fully written (not accumulated).  dL_dmeans2D is [N,3]
  * (x,y in NDC units = pixel gradient * 0.5*(W,H); z = 0), the quantity
@@ -163,6 +170,17 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                            float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
                            instag_stream_t stream);
+
+/* backward of the auxiliary colour set over the forward's state: dL_dout_aux [3,H,W] -> dL_daux_colors [N,3] and
+ * the aux image's contribution to dL_dmeans2D [N,3] (same convention as above; either may be NULL).  The geometry
+ * and the opacities receive NO gradient from the aux image (the reference detaches them for that pass).
+ * workspace: instag_raster_backward_workspace_bytes(N, R) bytes, distinct from a concurrently running
+ * instag_raster_backward's. */
+int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes,
+                               const void* binning, size_t binning_bytes, const void* image,
+                               size_t image_bytes, int64_t R, const int32_t* radii, const float* aux_colors,
+                               const float* dL_dout_aux, void* workspace, size_t workspace_bytes,
+                               float* dL_daux_colors, float* dL_dmeans2D, instag_stream_t stream);
 
 /* Debug / test access to the integer state (bit-exact parity checks against the oracle).
  * Copies are enqueued on `stream`; destination pointers are DEVICE memory. */

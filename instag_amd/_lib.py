@@ -62,9 +62,11 @@ _PROTOS = {
     "instag_raster_backward_workspace_bytes": (sz, [i32, i64]),
     "instag_raster_forward_stage1": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, C.POINTER(i64), vp]),
     "instag_raster_forward_stage2": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, sz, vp, sz, i64,
-                                               vp, vp, vp, vp, vp, vp]),
+                                               vp, vp, vp, vp, vp, vp, vp, vp]),
     "instag_raster_forward_capacity": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, sz, vp, sz, i64, vp, vp,
-                                                 vp, vp, vp, vp, vp, vp]),
+                                                 vp, vp, vp, vp, vp, vp, vp, vp]),
+    "instag_raster_aux_backward": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, sz, vp, sz, i64, vp, vp, vp, vp, sz,
+                                             vp, vp, vp]),
     "instag_raster_backward": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, sz, vp, sz, i64, vp,
                                          vp, vp, vp, vp, vp, vp, sz,
                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -150,7 +150,7 @@ using namespace instag;
 extern "C" {
 
 const char* instag_last_error(void) { return g_err.c_str(); }
-int instag_abi_version(void) { return 1; }
+int instag_abi_version(void) { return 2; }
 
 size_t instag_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t instag_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
@@ -186,8 +186,9 @@ int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t
 static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
                         size_t binning_bytes, void* image, size_t image_bytes, int64_t R, bool pad,
                         float* out_color, float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
-                        hipStream_t s) {
+                        const float* aux_colors, float* out_aux, hipStream_t s) {
   INSTAG_REQUIRE(out_color && out_depth && out_normal && out_alpha, "output images must not be NULL");
+  INSTAG_REQUIRE((aux_colors == nullptr) == (out_aux == nullptr), "aux_colors and out_aux go together");
   INSTAG_REQUIRE(R >= 0 && R < (int64_t)1 << 31, "instance count out of range");
   const GeomLayout GL = geom_layout(a->N);
   const ImageLayout IL = image_layout(a->image_height, a->image_width);
@@ -225,23 +226,24 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   }
   return launch_blend_forward(c, ranges, point_list, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
                               (float*)(ib + IL.final_T), out_color, out_depth, out_normal, out_alpha,
-                              a->E > 0 ? out_extra : nullptr, s);
+                              a->E > 0 ? out_extra : nullptr, aux_colors, out_aux, s);
 }
 
 int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
                                  size_t binning_bytes, void* image, size_t image_bytes, int64_t R,
                                  float* out_color, float* out_depth, float* out_normal, float* out_alpha,
-                                 float* out_extra, instag_stream_t stream_) {
+                                 float* out_extra, const float* aux_colors, float* out_aux,
+                                 instag_stream_t stream_) {
   if (int e = validate(a)) return e;
   return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, R, false, out_color,
-                      out_depth, out_normal, out_alpha, out_extra, (hipStream_t)stream_);
+                      out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux, (hipStream_t)stream_);
 }
 
 int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
                                    size_t binning_bytes, void* image, size_t image_bytes, int64_t capacity,
                                    int32_t* radii, int32_t* status, float* out_color, float* out_depth,
                                    float* out_normal, float* out_alpha, float* out_extra,
-                                   instag_stream_t stream_) {
+                                   const float* aux_colors, float* out_aux, instag_stream_t stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (int e = validate(a)) return e;
   INSTAG_REQUIRE(status != nullptr && radii != nullptr, "status / radii is NULL");
@@ -256,7 +258,7 @@ int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size
   }
   if (int e = launch_status(a->N, point_offsets, (uint32_t)capacity, status, s)) return e;
   return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, capacity, true, out_color,
-                      out_depth, out_normal, out_alpha, out_extra, s);
+                      out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux, s);
 }
 
 int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes, const void* binning,
@@ -288,13 +290,45 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                                       (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d), (const uint32_t*)(ib + IL.n_contrib),
                                       (const float*)(ib + IL.final_T), dL_dout_color, dL_dout_depth,
                                       dL_dout_normal, dL_dout_alpha, a->E > 0 ? dL_dout_extra : nullptr,
-                                      inst_grad, s)) return e;
+                                      inst_grad, nullptr, s)) return e;
   }
   return launch_preprocess_backward(c, a, (const float*)(gb + GL.rec2d), (const float*)(gb + GL.cov3d),
                                     (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
                                     radii, inst_grad, (uint32_t)R, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp,
                                     dL_dopacities, dL_dscales, dL_drotations, dL_dcov3Ds_precomp,
                                     a->E > 0 ? dL_dextra_attrs : nullptr, s);
+}
+
+int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes, const void* binning,
+                               size_t binning_bytes, const void* image, size_t image_bytes, int64_t R,
+                               const int32_t* radii, const float* aux_colors, const float* dL_dout_aux,
+                               void* workspace, size_t workspace_bytes, float* dL_daux_colors, float* dL_dmeans2D,
+                               instag_stream_t stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  if (int e = validate(a)) return e;
+  INSTAG_REQUIRE(aux_colors && dL_dout_aux, "aux_backward: aux_colors / dL_dout_aux is NULL");
+  INSTAG_REQUIRE(radii != nullptr || a->N == 0, "radii is NULL");
+  const GeomLayout GL = geom_layout(a->N);
+  const ImageLayout IL = image_layout(a->image_height, a->image_width);
+  const BinningLayout BL = binning_layout(R);
+  if (geom_bytes < GL.total || image_bytes < IL.total || binning_bytes < BL.total) {
+    set_error("state buffer too small"); return INSTAG_E_SPACE;
+  }
+  const size_t need = instag_raster_backward_workspace_bytes(a->N, R);
+  if (workspace_bytes < need || workspace == nullptr) { set_error("backward workspace too small"); return INSTAG_E_SPACE; }
+  if (a->N == 0) return INSTAG_OK;
+  const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)image;
+  const Camera c = make_camera(a);
+  float* inst_grad = (float*)workspace;
+  INSTAG_CHECK_HIP(hipMemsetAsync(inst_grad, 0, need, s));
+  if (R > 0) {
+    if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
+                                      (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),
+                                      (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
+                                      nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, s)) return e;
+  }
+  return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,
+                                    inst_grad, (uint32_t)R, dL_daux_colors, dL_dmeans2D, s);
 }
 
 int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,

@@ -279,6 +279,35 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
   }
 }
 
+// Auxiliary colour set (blended over detached geometry): only the colours and the screen-space means receive a
+// gradient.  Sums the Gaussian's instance rows written by blend-backward run with the colour override.
+__global__ void __launch_bounds__(256)
+aux_backward_reduce_kernel(Camera c, const float* __restrict__ rec2d, const uint32_t* __restrict__ tiles_touched,
+                           const int32_t* __restrict__ radii, const float* __restrict__ inst_grad, uint32_t capacity,
+                           float* __restrict__ dL_daux, float* __restrict__ dL_dmeans2D) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= c.N) return;
+  float gx = 0.f, gy = 0.f, dc[3] = {0.f, 0.f, 0.f};
+  if (radii[g] > 0) {
+    const uint32_t tt = tiles_touched[g];
+    const uint32_t off = __float_as_uint(rec2d[(size_t)g * REC_FLOATS + R_OFFSET]);
+    if ((uint64_t)off + tt <= (uint64_t)capacity) {
+      const float4* rows = reinterpret_cast<const float4*>(inst_grad + (size_t)off * REC_FLOATS);
+      for (uint32_t t = 0; t < tt; ++t) {
+        const float4 q0 = rows[4 * t + 0], q1 = rows[4 * t + 1], q2 = rows[4 * t + 2];
+        gx += q0.x; gy += q0.y;
+        dc[0] += q1.z; dc[1] += q1.w; dc[2] += q2.x;
+      }
+    }
+  }
+  if (dL_daux) { dL_daux[3 * g] = dc[0]; dL_daux[3 * g + 1] = dc[1]; dL_daux[3 * g + 2] = dc[2]; }
+  if (dL_dmeans2D) {
+    dL_dmeans2D[3 * g] = 0.5f * (float)c.W * gx;
+    dL_dmeans2D[3 * g + 1] = 0.5f * (float)c.H * gy;
+    dL_dmeans2D[3 * g + 2] = 0.f;
+  }
+}
+
 }  // namespace
 
 int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, const float* rec2d,
@@ -294,6 +323,17 @@ int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, con
   ProfScope p(K_PREPROCESS_BWD, s);
   preprocess_backward_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, io, rec2d, cov3d, tiles_touched, flags,
                                                                radii, inst_grad, capacity);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int launch_aux_backward_reduce(const Camera& c, const float* rec2d, const uint32_t* tiles_touched, const int32_t* radii,
+                               const float* inst_grad, uint32_t capacity, float* dL_daux_colors, float* dL_dmeans2D,
+                               hipStream_t s) {
+  if (c.N == 0) return INSTAG_OK;
+  ProfScope p(K_PREPROCESS_BWD, s);
+  aux_backward_reduce_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, rec2d, tiles_touched, radii, inst_grad, capacity,
+                                                               dL_daux_colors, dL_dmeans2D);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -23,13 +23,18 @@ constexpr int NCH = 8;  // r g b depth nx ny nz extra
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_MIN = 0.0001f;
 
+// AUX: a second colour set [N,3] is blended over the same instances with the same alpha / T (the reference renders
+// it as a separate rasterizer call on detached geometry: gaussian_renderer/__init__.py:243-258, the attention map)
+template <bool AUX>
 __global__ void __launch_bounds__(BLOCK)
 blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                      const float* __restrict__ rec2d, uint32_t* __restrict__ n_contrib,
                      float* __restrict__ final_T, float* __restrict__ out_color,
                      float* __restrict__ out_depth, float* __restrict__ out_normal,
-                     float* __restrict__ out_alpha, float* __restrict__ out_extra) {
+                     float* __restrict__ out_alpha, float* __restrict__ out_extra,
+                     const float* __restrict__ aux_colors, float* __restrict__ out_aux) {
   __shared__ float4 s_rec[BLOCK][4];
+  __shared__ float s_aux[AUX ? BLOCK : 1][3];
   const int tile = blockIdx.x;
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
   const int tid = threadIdx.x;
@@ -46,17 +51,21 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   float acc[NCH];
 #pragma unroll
   for (int k = 0; k < NCH; ++k) acc[k] = 0.f;
+  float xacc[3] = {0.f, 0.f, 0.f};
 
   // the records of batch i+1 are fetched while batch i is being blended
   float4 nrec0 = make_float4(0.f, 0.f, 0.f, 0.f), nrec1 = nrec0, nrec2 = nrec0, nrec3 = nrec0;
+  float naux[3] = {0.f, 0.f, 0.f};
   if (start + tid < end) {
     const uint32_t gid = point_list[start + tid];
     const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
     nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
+    if (AUX) { naux[0] = aux_colors[3 * (size_t)gid]; naux[1] = aux_colors[3 * (size_t)gid + 1]; naux[2] = aux_colors[3 * (size_t)gid + 2]; }
   }
   for (int i = 0; i < rounds; ++i, toDo -= BLOCK) {
     if (__syncthreads_count(done) == BLOCK) break;
     s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
+    if (AUX) { s_aux[tid][0] = naux[0]; s_aux[tid][1] = naux[1]; s_aux[tid][2] = naux[2]; }
     __syncthreads();
     {
       const int nprog = (i + 1) * BLOCK + tid;
@@ -64,6 +73,7 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
         const uint32_t gid = point_list[start + nprog];
         const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
         nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
+        if (AUX) { naux[0] = aux_colors[3 * (size_t)gid]; naux[1] = aux_colors[3 * (size_t)gid + 1]; naux[2] = aux_colors[3 * (size_t)gid + 2]; }
       }
     }
     const int cnt = min(BLOCK, toDo);
@@ -85,6 +95,7 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
       const float w = take ? alpha * T : 0.f;
       acc[0] += b.z * w; acc[1] += b.w * w; acc[2] += cc.x * w; acc[3] += cc.y * w;
       acc[4] += cc.z * w; acc[5] += cc.w * w; acc[6] += dd.x * w; acc[7] += dd.y * w;
+      if (AUX) { xacc[0] += s_aux[j][0] * w; xacc[1] += s_aux[j][1] * w; xacc[2] += s_aux[j][2] * w; }
       T = take ? test_T : T;
       last_contributor = take ? (uint32_t)(i * BLOCK + j + 1) : last_contributor;
     }
@@ -103,6 +114,11 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
     out_normal[2 * P + pix] = acc[6];
     out_alpha[pix] = 1.0f - T;
     if (out_extra) out_extra[pix] = acc[7];
+    if (AUX) {
+      out_aux[pix] = xacc[0] + T * c.bg[0];
+      out_aux[P + pix] = xacc[1] + T * c.bg[1];
+      out_aux[2 * P + pix] = xacc[2] + T * c.bg[2];
+    }
   }
 }
 
@@ -128,7 +144,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
                       const float* __restrict__ final_T, const float* __restrict__ dL_dcolor,
                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dnormal,
                       const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
-                      float* __restrict__ inst_grad) {
+                      float* __restrict__ inst_grad, const float* __restrict__ color_override /*[N,3] or null*/) {
   __shared__ float4 s_rec[BB][4];
   __shared__ __align__(16) float s_W[4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
   __shared__ __align__(16) float s_T[4 * BB * WROW];
@@ -211,6 +227,10 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
     nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
     nrec3.z = __uint_as_float(slot_list[start + (n - 1) - tid]);   // the instance's gradient row
+    if (color_override) {
+      nrec1.z = color_override[3 * (size_t)gid]; nrec1.w = color_override[3 * (size_t)gid + 1];
+      nrec2.x = color_override[3 * (size_t)gid + 2];
+    }
   }
   for (int i = 0; i < rounds; ++i) {
     __syncthreads();                          // previous batch fully consumed (s_rec, s_W/s_T, s_res, s_F)
@@ -227,6 +247,10 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
         const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
         nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
         nrec3.z = __uint_as_float(slot_list[start + nbase - tid]);
+        if (color_override) {
+          nrec1.z = color_override[3 * (size_t)gid]; nrec1.w = color_override[3 * (size_t)gid + 1];
+          nrec2.x = color_override[3 * (size_t)gid + 2];
+        }
       }
     }
     // ---- phase A: advance the per-pixel recurrence, emit w and t (branch-free, unrolled) ------------------
@@ -302,12 +326,16 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
 int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
                          const float* rec2d, uint32_t* n_contrib, float* final_T, float* out_color,
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
-                         hipStream_t s) {
+                         const float* aux_colors, float* out_aux, hipStream_t s) {
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
   ProfScope p(K_BLEND_FWD, s);
-  blend_forward_kernel<<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
-                                               out_depth, out_normal, out_alpha, out_extra);
+  if (aux_colors)
+    blend_forward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
+                                                       out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux);
+  else
+    blend_forward_kernel<false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
+                                                        out_depth, out_normal, out_alpha, out_extra, nullptr, nullptr);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -316,16 +344,18 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
                           const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
-                          hipStream_t s) {
+                          const float* color_override, hipStream_t s) {
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
   ProfScope p(K_BLEND_BWD, s);
   if (dL_ddepth || dL_dnormal || dL_dextra)
     blend_backward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T, dL_dcolor,
-                                                        dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad);
+                                                        dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad,
+                                                        color_override);
   else
     blend_backward_kernel<false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T, dL_dcolor,
-                                                         dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad);
+                                                         dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad,
+                                                         color_override);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

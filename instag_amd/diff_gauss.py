@@ -97,7 +97,7 @@ def set_capacity_plan(plan):
 
 class _State:
     """Opaque device buffers kept between forward and backward (geom / binning / image)."""
-    __slots__ = ("args", "keep", "geom", "binning", "image", "R", "radii", "N", "H", "W", "E", "M")
+    __slots__ = ("args", "keep", "geom", "binning", "image", "R", "radii", "N", "H", "W", "E", "M", "aux")
 
 
 def _make_args(s: GaussianRasterizationSettings, means3D, shs, colors, opac, scales, rots, cov3D, extra):
@@ -118,9 +118,9 @@ def _make_args(s: GaussianRasterizationSettings, means3D, shs, colors, opac, sca
     return a, keep, N, M, E
 
 
-def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D, extra):
+def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D, extra, aux_colors=None):
     """Run the forward (two-stage with one host round trip, or sync-free under a CapacityPlan).
-    Returns (outputs, state)."""
+    Returns (outputs, state); with aux_colors [N,3] the outputs carry a 7th image [3,H,W]."""
     L = _lib.lib()
     dev = means3D.device
     a, keep, N, M, E = _make_args(settings, means3D, shs, colors, opac, scales, rots, cov3D, extra)
@@ -134,13 +134,15 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
     normal = torch.empty(3, H, W, dtype=torch.float32, device=dev)
     alpha = torch.empty(1, H, W, dtype=torch.float32, device=dev)
     extra_img = torch.empty(E, H, W, dtype=torch.float32, device=dev)
+    aux_img = torch.empty(3, H, W, dtype=torch.float32, device=dev) if aux_colors is not None else None
     if _CAPACITY_PLAN is not None:
         R, status = _CAPACITY_PLAN.next_slot()
         binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
         check(L.instag_raster_forward_capacity(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
                                                ptr(image), image.numel(), R, ptr(radii), ptr(status), ptr(color),
                                                ptr(depth), ptr(normal), ptr(alpha),
-                                               ptr(extra_img) if E > 0 else None, stream), "rasterize_gaussians")
+                                               ptr(extra_img) if E > 0 else None, ptr(aux_colors), ptr(aux_img),
+                                               stream), "rasterize_gaussians")
     else:
         Rc = C.c_int64(0)
         check(L.instag_raster_forward_stage1(C.byref(a), ptr(geom), geom.numel(), ptr(radii), C.byref(Rc), stream),
@@ -150,12 +152,36 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
         binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
         check(L.instag_raster_forward_stage2(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
                                              ptr(image), image.numel(), R, ptr(color), ptr(depth), ptr(normal),
-                                             ptr(alpha), ptr(extra_img) if E > 0 else None, stream),
+                                             ptr(alpha), ptr(extra_img) if E > 0 else None, ptr(aux_colors),
+                                             ptr(aux_img), stream),
               "rasterize_gaussians")
     st = _State()
     st.args, st.keep, st.geom, st.binning, st.image = a, keep, geom, binning, image
     st.R, st.radii, st.N, st.H, st.W, st.E, st.M = R, radii, N, H, W, E, M
+    st.aux = aux_colors
+    if aux_colors is not None:
+        return (color, depth, normal, alpha, radii, extra_img, aux_img), st
     return (color, depth, normal, alpha, radii, extra_img), st
+
+
+_AUX_STREAMS = {}
+
+
+def rasterize_aux_backward(st: "_State", g_aux, want_colors=True, want_means2D=True, stream=None):
+    """Backward of the auxiliary colour image -> (dL_daux_colors [N,3], dL_dmeans2D contribution [N,3])."""
+    L = _lib.lib()
+    dev = st.geom.device
+    N = st.N
+    d_aux = torch.empty(N, 3, dtype=torch.float32, device=dev) if want_colors else None
+    d_m2d = torch.empty(N, 3, dtype=torch.float32, device=dev) if want_means2D else None
+    ws = torch.empty(L.instag_raster_backward_workspace_bytes(N, st.R), dtype=torch.uint8, device=dev)
+    g_aux = _f32c(g_aux)
+    check(L.instag_raster_aux_backward(C.byref(st.args), ptr(st.geom), st.geom.numel(), ptr(st.binning),
+                                       st.binning.numel(), ptr(st.image), st.image.numel(), st.R, ptr(st.radii),
+                                       ptr(st.aux), ptr(g_aux), ptr(ws), ws.numel(), ptr(d_aux), ptr(d_m2d),
+                                       _lib.current_stream() if stream is None else stream),
+          "rasterize_gaussians_aux_backward")
+    return d_aux, d_m2d
 
 
 def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra, want):
@@ -193,39 +219,65 @@ def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra,
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                extra_attrs, raster_settings):
+                extra_attrs, raster_settings, aux_colors=None):
         _require_cuda(means3D=means3D)
         ctx.set_materialize_grads(False)      # unused outputs (depth / normal / extra) stay NULL in backward
         m3, shs, col = _f32c(means3D), _f32c(sh), _f32c(colors_precomp)
         op, sc, ro = _f32c(opacities), _f32c(scales), _f32c(rotations)
-        cov, ex = _f32c(cov3Ds_precomp), _f32c(extra_attrs)
+        cov, ex, aux = _f32c(cov3Ds_precomp), _f32c(extra_attrs), _f32c(aux_colors)
         _require_cuda(shs=shs, colors_precomp=col, opacities=op, scales=sc, rotations=ro, cov3Ds_precomp=cov,
-                      extra_attrs=ex)
-        outs, st = rasterize_forward(raster_settings, m3, shs, col, op, sc, ro, cov, ex)
+                      extra_attrs=ex, aux_colors=aux)
+        if aux is not None and tuple(aux.shape) != (m3.shape[0], 3):
+            raise RuntimeError("aux_colors must be [N,3]")
+        outs, st = rasterize_forward(raster_settings, m3, shs, col, op, sc, ro, cov, ex, aux)
         ctx.state = st
         ctx.shapes = (opacities.shape, None if extra_attrs is None else extra_attrs.shape)
-        color, depth, normal, alpha, radii, extra = outs
-        ctx.mark_non_differentiable(radii)
-        return color, depth, normal, alpha, radii, extra
+        ctx.mark_non_differentiable(outs[4])
+        return outs
 
     @staticmethod
-    def backward(ctx, g_color, g_depth, g_normal, g_alpha, _g_radii, g_extra):
+    def backward(ctx, g_color, g_depth, g_normal, g_alpha, _g_radii, g_extra, g_aux=None):
         st = ctx.state
         need = ctx.needs_input_grad
         want = dict(means3D=need[0], means2D=need[1], shs=need[2], colors=need[3], opacities=need[4],
                     scales=need[5], rotations=need[6], cov3D=need[7], extra=need[8])
-        g = rasterize_backward(st, g_color, g_depth, g_normal, g_alpha, g_extra, want)
+        d_aux = m2d_aux = None
+        side = None
+        if st.aux is not None and g_aux is not None and (need[10] or need[1]):
+            # the aux image only shares the forward state with the main images: its backward runs beside theirs
+            dev = st.geom.device
+            main = torch.cuda.current_stream(dev)
+            key = (dev.type, dev.index)
+            side = _AUX_STREAMS.get(key)
+            if side is None:
+                side = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                d_aux, m2d_aux = rasterize_aux_backward(st, g_aux, need[10], need[1])
+            for t in (g_aux, d_aux, m2d_aux):
+                if t is not None:
+                    t.record_stream(side)
+        main_grads = any(g is not None for g in (g_color, g_depth, g_normal, g_alpha, g_extra))
+        if main_grads:
+            g = rasterize_backward(st, g_color, g_depth, g_normal, g_alpha, g_extra, want)
+        else:
+            g = dict(means3D=None, means2D=None, shs=None, colors=None, opacities=None, scales=None, rotations=None,
+                     cov3D=None, extra=None)
+        if side is not None:
+            torch.cuda.current_stream(st.geom.device).wait_stream(side)
+            if m2d_aux is not None:
+                g["means2D"] = m2d_aux if g["means2D"] is None else g["means2D"].add_(m2d_aux)
         op_shape, ex_shape = ctx.shapes
         g_op = None if g["opacities"] is None else g["opacities"].reshape(op_shape)
         g_ex = None if g["extra"] is None else g["extra"].reshape(ex_shape)
         return (g["means3D"], g["means2D"], g["shs"], g["colors"], g_op, g["scales"], g["rotations"],
-                g["cov3D"], g_ex, None)
+                g["cov3D"], g_ex, None, d_aux)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        extra_attrs, raster_settings):
+                        extra_attrs, raster_settings, aux_colors=None):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, extra_attrs, raster_settings)
+                                     cov3Ds_precomp, extra_attrs, raster_settings, aux_colors)
 
 
 class GaussianRasterizer(nn.Module):
@@ -241,7 +293,10 @@ class GaussianRasterizer(nn.Module):
             return z > 0.2
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3Ds_precomp=None, extra_attrs=None):
+                cov3Ds_precomp=None, extra_attrs=None, aux_colors=None):
+        """Same call and 6-tuple as the reference's rasterizer.  Extension: ``aux_colors`` [N,3] appends a 7th
+        output, the image a second call with ``colors_precomp=aux_colors`` on the detached geometry would
+        return (gradients reach aux_colors and means2D only), at the cost of three more blend channels."""
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3Ds_precomp is None) or \
@@ -250,7 +305,7 @@ class GaussianRasterizer(nn.Module):
         if extra_attrs is not None and extra_attrs.dim() > 1 and extra_attrs.shape[1] > 1:
             raise RuntimeError("extra_attrs: only [N] / [N,1] is supported by the MI355X rasterizer")
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                   cov3Ds_precomp, extra_attrs, self.raster_settings)
+                                   cov3Ds_precomp, extra_attrs, self.raster_settings, aux_colors)
 
 
 def debug_export(st: _State):

@@ -14,6 +14,7 @@ import torch
 from .diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
 
 CONCURRENT_PASSES = True      # fork the attention raster pass(es) onto a second stream
+SHARED_ATTN_PASS = True       # attention map as an auxiliary colour set of the main raster pass
 
 
 _SIDE_STREAMS = {}
@@ -109,29 +110,39 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         rotations = pc.rotation_activation(pc._rotation + d_rot)
     ones = torch.ones_like(opacity)
 
-    def attn_pass(preds):
+    def attn_colors(preds):
         eye = preds["ambient_eye"]
-        attn_precomp = torch.cat([preds["ambient_aud"], eye, torch.zeros_like(eye)], dim=-1)
+        return torch.cat([preds["ambient_aud"], eye, torch.zeros_like(eye)], dim=-1)
+
+    def attn_pass(preds):
         out = rasterizer(means3D=means3D.detach(), means2D=screenspace_points, shs=None,
-                         colors_precomp=attn_precomp, opacities=opacity.detach(), scales=scales.detach(),
+                         colors_precomp=attn_colors(preds), opacities=opacity.detach(), scales=scales.detach(),
                          rotations=rotations.detach(), cov3Ds_precomp=None, extra_attrs=ones)
         return out[0]
 
     rendered_attn = p_rendered_attn = None
-    fork = return_attn and means3D.is_cuda and CONCURRENT_PASSES
+    # The attention map is rendered over the same (detached) geometry as the image: on the device it rides along
+    # the main pass as an auxiliary colour set (one preprocess / binning / sort instead of two).
+    shared = return_attn and means3D.is_cuda and SHARED_ATTN_PASS
+    fork = return_attn and means3D.is_cuda and CONCURRENT_PASSES and (personalized or not shared)
     if fork:
-        # the attention pass(es) only share inputs with the main pass: run them on a second stream
+        # remaining attention pass(es) only share inputs with the main pass: run them on a second stream
         main_stream = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
         side.wait_stream(main_stream)
         with torch.cuda.stream(side):
-            rendered_attn = attn_pass(motion_preds)
+            if not shared:
+                rendered_attn = attn_pass(motion_preds)
             if personalized:
                 p_rendered_attn = attn_pass(p_motion_preds)
 
-    image, depth, normal, alpha, radii, extra = rasterizer(
+    outs = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
-        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=ones)
+        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=ones,
+        **({"aux_colors": attn_colors(motion_preds)} if shared else {}))
+    image, depth, normal, alpha, radii, extra = outs[:6]
+    if shared:
+        rendered_attn = outs[6]
 
     if fork:
         main_stream.wait_stream(side)
@@ -139,7 +150,8 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             if t is not None:
                 t.record_stream(main_stream)
     elif return_attn:
-        rendered_attn = attn_pass(motion_preds)
+        if not shared:
+            rendered_attn = attn_pass(motion_preds)
         if personalized:
             p_rendered_attn = attn_pass(p_motion_preds)
 

@@ -251,3 +251,46 @@ def test_graphed_train_step_matches_eager():
         for a_, b_ in zip(losses["eager"], losses[mode]):
             assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (mode, losses["eager"], losses[mode])
         assert float((params["eager"] - params[mode]).abs().max()) <= 1e-5
+
+
+def test_aux_colors_match_second_pass():
+    """aux_colors rides along the main pass: image and gradients equal a second rasterizer call on detached geometry."""
+    import torch
+    from instag_amd.diff_gauss import GaussianRasterizer
+    N, size = 3000, 96
+    a, sd = make_scene(N, size, sh_degree=1, seed=7)
+    a = {k: a[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+    settings = hip_settings(sd)
+    g = torch.Generator().manual_seed(2)
+    aux0 = torch.rand(N, 3, generator=g)
+    w_img, w_aux = torch.randn(3, size, size, generator=g).cuda(), torch.randn(3, size, size, generator=g).cuda()
+
+    def leaves():
+        d = {k: v.cuda().clone().requires_grad_(True) for k, v in a.items()}
+        d["aux"] = aux0.cuda().clone().requires_grad_(True)
+        d["m2d"] = torch.zeros(N, 3, device="cuda", requires_grad=True)
+        return d
+
+    rast = GaussianRasterizer(settings)
+    ones = torch.ones(N, 1, device="cuda")
+    # reference: two calls
+    r = leaves()
+    out_main = rast(means3D=r["means3D"], means2D=r["m2d"], shs=r["shs"], opacities=r["opacities"],
+                    scales=r["scales"], rotations=r["rotations"], extra_attrs=ones)
+    out_attn = rast(means3D=r["means3D"].detach(), means2D=r["m2d"], colors_precomp=r["aux"],
+                    opacities=r["opacities"].detach(), scales=r["scales"].detach(), rotations=r["rotations"].detach(),
+                    extra_attrs=ones)
+    ((out_main[0] * w_img).sum() + out_main[3].sum() + (out_attn[0] * w_aux).sum()).backward()
+    # fused: one call
+    f = leaves()
+    outs = rast(means3D=f["means3D"], means2D=f["m2d"], shs=f["shs"], opacities=f["opacities"], scales=f["scales"],
+                rotations=f["rotations"], extra_attrs=ones, aux_colors=f["aux"])
+    assert len(outs) == 7
+    ((outs[0] * w_img).sum() + outs[3].sum() + (outs[6] * w_aux).sum()).backward()
+    assert torch.equal(outs[0], out_main[0])
+    assert float((outs[6] - out_attn[0]).abs().max()) <= 1e-6
+    for k in r:
+        gr, gf = r[k].grad, f[k].grad
+        assert gr is not None and gf is not None, k
+        scale = max(float(gr.abs().max()), 1e-6)
+        assert float((gr - gf).abs().max()) <= 2e-5 * scale, (k, float((gr - gf).abs().max()), scale)
