@@ -220,7 +220,7 @@ int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void*
 /* ------------------------------------------------------------------------------------------
  * Fused per-Gaussian glue (csrc/glue.hip).
  *  motion_glue  (scene/motion_net.py:291-306, :679-692): h_in [N,KX+KA+KE] = cat(enc_x, enc_a*aud, enc_e*relu(eye_pre)),
- *               amb [N,2] = (||aud||, ||relu(eye_pre)||); backward returns d_enc_x, d_aud, d_eye_pre and accumulates
+ *               amb [N,3] = (||aud||, ||relu(eye_pre)||, 0); backward returns d_enc_x, d_aud, d_eye_pre and accumulates
  *               d_enc_a [KA], d_enc_e [KE] (zero-filled by the caller).  KA <= 32, KE <= 8.
  *  deform_activate (gaussian_renderer/__init__.py:200-235, personalized=False, align=True): h [N,11] = UMF head output,
  *               p [N,6] = PMF align head output -> means3D, scales, rotations, opacity.

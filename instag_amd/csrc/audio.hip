@@ -99,29 +99,43 @@ __device__ __forceinline__ AttW att_layout(int A) {
   return o;
 }
 
-// y[b][co][l] = act(bias[co] + sum_{ci,k} w[co][ci][k] * x[b][ci][stride*l + k - pad]); K = 1 is a linear layer
-__device__ void conv_forward(const float* x, const float* __restrict__ w, const float* __restrict__ bias, float* y,
-                             int B, int cin, int cout, int lin, int lout, int stride, int K, int pad, bool act) {
+// y[b][co][l] = act(bias[co] + sum_{ci,k} w[co][ci][k] * x[b][ci][STRIDE*l + k - pad]); K = 1 is a linear layer.
+// x, w, bias live in LDS; the ci loop is unrolled so that several LDS reads are in flight per thread (one
+// workgroup on one CU: the passes are latency-, not throughput-bound).
+template <int K, int STRIDE>
+__device__ __forceinline__ void conv_forward(const float* x, const float* w, const float* bias, float* y, int B, int cin,
+                                             int cout, int lin, int lout, bool act) {
+  constexpr int PAD = K == 3 ? 1 : 0;
   const int total = B * cout * lout;
   for (int o = threadIdx.x; o < total; o += FT) {
     const int l = o % lout, co = (o / lout) % cout, b = o / (lout * cout);
-    float acc = bias ? bias[co] : 0.f;
-    const float* wr = w + (size_t)co * cin * K;
-    const float* xb = x + (size_t)b * cin * lin;
-    for (int ci = 0; ci < cin; ++ci)
+    const float* wr = w + co * cin * K;
+    const float* xb = x + b * cin * lin;
+    const int p0 = STRIDE * l - PAD;
+    bool ok[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) ok[k] = p0 + k >= 0 && p0 + k < lin;
+    float acc0 = bias ? bias[co] : 0.f, acc1 = 0.f;
+#pragma unroll 4
+    for (int ci = 0; ci < cin; ++ci) {
+#pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int p = stride * l + k - pad;
-        if (p >= 0 && p < lin) acc += wr[ci * K + k] * xb[ci * lin + p];
+        const float xv = ok[k] ? xb[ci * lin + p0 + k] : 0.f;
+        if (ci & 1) acc1 += wr[ci * K + k] * xv; else acc0 += wr[ci * K + k] * xv;
       }
+    }
+    const float acc = acc0 + acc1;
     y[o] = act ? leaky(acc) : acc;
   }
 }
 
 // g_out holds d(pre-activation) of the layer's output.  Writes dW, dbias to global and, when g_in != nullptr,
 // d(pre-activation) of the layer's input (x is a leaky output when in_act) or the plain input gradient.
-__device__ void conv_backward(const float* x, const float* g_out, const float* __restrict__ w, float* __restrict__ dW,
-                              float* __restrict__ dbias, float* g_in, int B, int cin, int cout, int lin, int lout,
-                              int stride, int K, int pad, bool in_act, bool in_accumulate) {
+template <int K, int STRIDE>
+__device__ __forceinline__ void conv_backward(const float* x, const float* g_out, const float* w, float* __restrict__ dW,
+                                              float* __restrict__ dbias, float* g_in, int B, int cin, int cout, int lin,
+                                              int lout, bool in_act) {
+  constexpr int PAD = K == 3 ? 1 : 0;
   const int nW = cout * cin * K;
   const int nB = dbias ? cout : 0;
   const int nI = g_in ? B * cin * lin : 0;
@@ -130,11 +144,13 @@ __device__ void conv_backward(const float* x, const float* g_out, const float* _
       const int k = idx % K, ci = (idx / K) % cin, co = idx / (K * cin);
       float acc = 0.f;
       for (int b = 0; b < B; ++b) {
-        const float* gb = g_out + ((size_t)b * cout + co) * lout;
-        const float* xb = x + ((size_t)b * cin + ci) * lin;
+        const float* gb = g_out + (b * cout + co) * lout;
+        const float* xb = x + (b * cin + ci) * lin;
+#pragma unroll 4
         for (int l = 0; l < lout; ++l) {
-          const int p = stride * l + k - pad;
-          if (p >= 0 && p < lin) acc += gb[l] * xb[p];
+          const int p = STRIDE * l + k - PAD;
+          const float xv = (p >= 0 && p < lin) ? xb[p] : 0.f;
+          acc += gb[l] * xv;
         }
       }
       dW[idx] = acc;
@@ -142,23 +158,31 @@ __device__ void conv_backward(const float* x, const float* g_out, const float* _
       const int co = idx - nW;
       float acc = 0.f;
       for (int b = 0; b < B; ++b)
-        for (int l = 0; l < lout; ++l) acc += g_out[((size_t)b * cout + co) * lout + l];
+#pragma unroll 4
+        for (int l = 0; l < lout; ++l) acc += g_out[(b * cout + co) * lout + l];
       dbias[co] = acc;
     } else {
       const int i = idx - nW - nB;
       const int p = i % lin, ci = (i / lin) % cin, b = i / (lin * cin);
-      float acc = 0.f;
+      float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
       for (int k = 0; k < K; ++k) {
-        const int q = p + pad - k;               // = stride * l
-        if (q < 0 || q % stride) continue;
-        const int l = q / stride;
-        if (l >= lout) continue;
-        const float* gb = g_out + (size_t)b * cout * lout + l;
-        const float* wk = w + ci * K + k;
-        for (int co = 0; co < cout; ++co) acc += wk[(size_t)co * cin * K] * gb[co * lout];
+        const int q = p + PAD - k;               // = STRIDE * l
+        const int l = q / STRIDE;
+        const bool ok = q >= 0 && (q % STRIDE) == 0 && l < lout;
+        if (ok) {
+          const float* gb = g_out + b * cout * lout + l;
+          const float* wk = w + ci * K + k;
+#pragma unroll 4
+          for (int co = 0; co < cout; ++co) {
+            const float t = wk[co * cin * K] * gb[co * lout];
+            if (co & 1) acc1 += t; else acc0 += t;
+          }
+        }
       }
+      float acc = acc0 + acc1;
       if (in_act) acc *= dleaky(x[i]);
-      g_in[i] = in_accumulate ? g_in[i] + acc : acc;
+      g_in[i] = acc;
     }
   }
 }
@@ -173,26 +197,26 @@ frame_code_forward_kernel(FrameDims d, ParamPtrs P, const float* __restrict__ a,
   for (int i = threadIdx.x; i < NB * D * WIN; i += FT) s[L.x0 + i] = a[i];
   stage(sw, P.p[0], M * D * 3); stage(sw + M * D * 3, P.p[1], M);
   __syncthreads();
-  conv_forward(s + L.x0, sw, sw + M * D * 3, s + L.a1, NB, D, M, 16, 8, 2, 3, 1, true);
+  conv_forward<3, 2>(s + L.x0, sw, sw + M * D * 3, s + L.a1, NB, D, M, 16, 8, true);
   __syncthreads();
   stage(sw, P.p[2], M * M * 3); stage(sw + M * M * 3, P.p[3], M);
   __syncthreads();
-  conv_forward(s + L.a1, sw, sw + M * M * 3, s + L.a2, NB, M, M, 8, 4, 2, 3, 1, true);
+  conv_forward<3, 2>(s + L.a1, sw, sw + M * M * 3, s + L.a2, NB, M, M, 8, 4, true);
   __syncthreads();
   stage(sw, P.p[4], 64 * M * 3); stage(sw + 64 * M * 3, P.p[5], 64);
   __syncthreads();
-  conv_forward(s + L.a2, sw, sw + 64 * M * 3, s + L.a3, NB, M, 64, 4, 2, 2, 3, 1, true);
+  conv_forward<3, 2>(s + L.a2, sw, sw + 64 * M * 3, s + L.a3, NB, M, 64, 4, 2, true);
   __syncthreads();
   stage(sw, P.p[6], 64 * 64 * 3); stage(sw + 64 * 64 * 3, P.p[7], 64);
   __syncthreads();
-  conv_forward(s + L.a3, sw, sw + 64 * 64 * 3, s + L.a4, NB, 64, 64, 2, 1, 2, 3, 1, true);
+  conv_forward<3, 2>(s + L.a3, sw, sw + 64 * 64 * 3, s + L.a4, NB, 64, 64, 2, 1, true);
   __syncthreads();
   stage(sw, P.p[8], 4096); stage(sw + 4096, P.p[9], 64); stage(sw + 4160, P.p[10], A * 64);
   stage(sw + 4160 + A * 64, P.p[11], A);
   __syncthreads();
-  conv_forward(s + L.a4, sw, sw + 4096, s + L.f1, NB, 64, 64, 1, 1, 1, 1, 0, true);
+  conv_forward<1, 1>(s + L.a4, sw, sw + 4096, s + L.f1, NB, 64, 64, 1, 1, true);
   __syncthreads();
-  conv_forward(s + L.f1, sw + 4160, sw + 4160 + A * 64, s + L.f2, NB, 64, A, 1, 1, 1, 1, 0, false);
+  conv_forward<1, 1>(s + L.f1, sw + 4160, sw + 4160 + A * 64, s + L.f2, NB, 64, A, 1, 1, false);
   __syncthreads();
   const AttW aw = att_layout(A);
   {
@@ -214,12 +238,12 @@ frame_code_forward_kernel(FrameDims d, ParamPtrs P, const float* __restrict__ a,
     for (int i = 0; i < 5; ++i) acc += sw[aw.e1 + h * 5 + i] * e[i];
     s[L.eh + h] = fmaxf(acc, 0.f);
   }
-  conv_forward(s + L.xt, sw + aw.w[0], sw + aw.b[0], s + L.c1, 1, A, 16, NB, NB, 1, 3, 1, true);  __syncthreads();
-  conv_forward(s + L.c1, sw + aw.w[1], sw + aw.b[1], s + L.c2, 1, 16, 8, NB, NB, 1, 3, 1, true);  __syncthreads();
-  conv_forward(s + L.c2, sw + aw.w[2], sw + aw.b[2], s + L.c3, 1, 8, 4, NB, NB, 1, 3, 1, true);   __syncthreads();
-  conv_forward(s + L.c3, sw + aw.w[3], sw + aw.b[3], s + L.c4, 1, 4, 2, NB, NB, 1, 3, 1, true);   __syncthreads();
-  conv_forward(s + L.c4, sw + aw.w[4], sw + aw.b[4], s + L.c5, 1, 2, 1, NB, NB, 1, 3, 1, true);   __syncthreads();
-  conv_forward(s + L.c5, sw + aw.w[5], sw + aw.b[5], s + L.z, 1, NB, NB, 1, 1, 1, 1, 0, false);   __syncthreads();
+  conv_forward<3, 1>(s + L.xt, sw + aw.w[0], sw + aw.b[0], s + L.c1, 1, A, 16, NB, NB, true);  __syncthreads();
+  conv_forward<3, 1>(s + L.c1, sw + aw.w[1], sw + aw.b[1], s + L.c2, 1, 16, 8, NB, NB, true);  __syncthreads();
+  conv_forward<3, 1>(s + L.c2, sw + aw.w[2], sw + aw.b[2], s + L.c3, 1, 8, 4, NB, NB, true);   __syncthreads();
+  conv_forward<3, 1>(s + L.c3, sw + aw.w[3], sw + aw.b[3], s + L.c4, 1, 4, 2, NB, NB, true);   __syncthreads();
+  conv_forward<3, 1>(s + L.c4, sw + aw.w[4], sw + aw.b[4], s + L.c5, 1, 2, 1, NB, NB, true);   __syncthreads();
+  conv_forward<1, 1>(s + L.c5, sw + aw.w[5], sw + aw.b[5], s + L.z, 1, NB, NB, 1, 1, false);   __syncthreads();
   if (threadIdx.x < NB) {
     float m = s[L.z];
     for (int t = 1; t < NB; ++t) m = fmaxf(m, s[L.z + t]);
@@ -294,12 +318,12 @@ frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __
     g[L.z + threadIdx.x] = s[L.y + threadIdx.x] * (g[L.y + threadIdx.x] - dot);
   }
   __syncthreads();
-  conv_backward(s + L.c5, g + L.z, sw + aw.w[5], G.p[22], G.p[23], g + L.c5, 1, NB, NB, 1, 1, 1, 1, 0, true, false);   __syncthreads();
-  conv_backward(s + L.c4, g + L.c5, sw + aw.w[4], G.p[20], G.p[21], g + L.c4, 1, 2, 1, NB, NB, 1, 3, 1, true, false);  __syncthreads();
-  conv_backward(s + L.c3, g + L.c4, sw + aw.w[3], G.p[18], G.p[19], g + L.c3, 1, 4, 2, NB, NB, 1, 3, 1, true, false);  __syncthreads();
-  conv_backward(s + L.c2, g + L.c3, sw + aw.w[2], G.p[16], G.p[17], g + L.c2, 1, 8, 4, NB, NB, 1, 3, 1, true, false);  __syncthreads();
-  conv_backward(s + L.c1, g + L.c2, sw + aw.w[1], G.p[14], G.p[15], g + L.c1, 1, 16, 8, NB, NB, 1, 3, 1, true, false); __syncthreads();
-  conv_backward(s + L.xt, g + L.c1, sw + aw.w[0], G.p[12], G.p[13], g + L.xt, 1, A, 16, NB, NB, 1, 3, 1, false, false);
+  conv_backward<1, 1>(s + L.c5, g + L.z, sw + aw.w[5], G.p[22], G.p[23], g + L.c5, 1, NB, NB, 1, 1, true);   __syncthreads();
+  conv_backward<3, 1>(s + L.c4, g + L.c5, sw + aw.w[4], G.p[20], G.p[21], g + L.c4, 1, 2, 1, NB, NB, true);  __syncthreads();
+  conv_backward<3, 1>(s + L.c3, g + L.c4, sw + aw.w[3], G.p[18], G.p[19], g + L.c3, 1, 4, 2, NB, NB, true);  __syncthreads();
+  conv_backward<3, 1>(s + L.c2, g + L.c3, sw + aw.w[2], G.p[16], G.p[17], g + L.c2, 1, 8, 4, NB, NB, true);  __syncthreads();
+  conv_backward<3, 1>(s + L.c1, g + L.c2, sw + aw.w[1], G.p[14], G.p[15], g + L.c1, 1, 16, 8, NB, NB, true); __syncthreads();
+  conv_backward<3, 1>(s + L.xt, g + L.c1, sw + aw.w[0], G.p[12], G.p[13], g + L.xt, 1, A, 16, NB, NB, false);
   __syncthreads();
   for (int i = threadIdx.x; i < NB * A; i += FT) {            // feat[t][j] also feeds xt[j][t]
     const int j = i % A, t = i / A;
@@ -307,18 +331,18 @@ frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __
   }
   stage(sw, P.p[8], 4096); stage(sw + 4096, P.p[10], A * 64);
   __syncthreads();
-  conv_backward(s + L.f1, g + L.f2, sw + 4096, G.p[10], G.p[11], g + L.f1, NB, 64, A, 1, 1, 1, 1, 0, true, false); __syncthreads();
-  conv_backward(s + L.a4, g + L.f1, sw, G.p[8], G.p[9], g + L.a4, NB, 64, 64, 1, 1, 1, 1, 0, true, false);         __syncthreads();
+  conv_backward<1, 1>(s + L.f1, g + L.f2, sw + 4096, G.p[10], G.p[11], g + L.f1, NB, 64, A, 1, 1, true); __syncthreads();
+  conv_backward<1, 1>(s + L.a4, g + L.f1, sw, G.p[8], G.p[9], g + L.a4, NB, 64, 64, 1, 1, true);         __syncthreads();
   stage(sw, P.p[6], 64 * 64 * 3);
   __syncthreads();
-  conv_backward(s + L.a3, g + L.a4, sw, G.p[6], G.p[7], g + L.a3, NB, 64, 64, 2, 1, 2, 3, 1, true, false);         __syncthreads();
+  conv_backward<3, 2>(s + L.a3, g + L.a4, sw, G.p[6], G.p[7], g + L.a3, NB, 64, 64, 2, 1, true);         __syncthreads();
   stage(sw, P.p[4], 64 * M * 3);
   __syncthreads();
-  conv_backward(s + L.a2, g + L.a3, sw, G.p[4], G.p[5], g + L.a2, NB, M, 64, 4, 2, 2, 3, 1, true, false);          __syncthreads();
+  conv_backward<3, 2>(s + L.a2, g + L.a3, sw, G.p[4], G.p[5], g + L.a2, NB, M, 64, 4, 2, true);          __syncthreads();
   stage(sw, P.p[2], M * M * 3);
   __syncthreads();
-  conv_backward(s + L.a1, g + L.a2, sw, G.p[2], G.p[3], g + L.a1, NB, M, M, 8, 4, 2, 3, 1, true, false);           __syncthreads();
-  conv_backward(s + L.x0, g + L.a1, nullptr, G.p[0], G.p[1], nullptr, NB, D, M, 16, 8, 2, 3, 1, false, false);
+  conv_backward<3, 2>(s + L.a1, g + L.a2, sw, G.p[2], G.p[3], g + L.a1, NB, M, M, 8, 4, true);           __syncthreads();
+  conv_backward<3, 2>(s + L.x0, g + L.a1, nullptr, G.p[0], G.p[1], nullptr, NB, D, M, 16, 8, false);
 }
 
 bool g_attr_set = false;

@@ -4,7 +4,8 @@
 //
 //  motion_glue      scene/motion_net.py:291-306 (UMF) / :679-692 (PMF):
 //                     h_in = cat(enc_x, enc_a * aud_ch_att, enc_e * relu(eye_pre)),
-//                     ambient_aud = ||aud_ch_att||, ambient_eye = ||relu(eye_pre)||
+//                     ambient_aud = ||aud_ch_att||, ambient_eye = ||relu(eye_pre)||; amb rows are (aud, eye, 0): the
+//                     attention colours of gaussian_renderer/__init__.py:243-246 without a cat
 //  deform_activate  gaussian_renderer/__init__.py:200-235 for render_motion(personalized=False, align=True):
 //                     means3D = xyz + (h[:, :3]*1e-2) * (tanh(p[:,3:]/5)*0.25+1), scales = softplus(scaling + h[:,8:11]),
 //                     rotations = normalize(rotation + h[:,3:7]), opacity = sigmoid(opacity_raw)
@@ -39,8 +40,9 @@ motion_glue_forward_kernel(GlueDims d, const float* __restrict__ enc_x, const fl
     float sa = 0.f, se = 0.f;
     for (int k = 0; k < d.KA; ++k) { const float v = aud[(size_t)r * d.KA + k]; sa += v * v; }
     for (int k = 0; k < d.KE; ++k) { const float v = fmaxf(eye_pre[(size_t)r * d.KE + k], 0.f); se += v * v; }
-    amb[2 * r] = sqrtf(sa);
-    amb[2 * r + 1] = sqrtf(se);
+    amb[3 * r] = sqrtf(sa);
+    amb[3 * r + 1] = sqrtf(se);
+    amb[3 * r + 2] = 0.f;
   }
 }
 
@@ -69,8 +71,8 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
     for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < ta; i += stride) {
       const int r = (int)(i / d.KA), k = (int)(i - (size_t)r * d.KA);
       const float a = aud[i], gw = d_h_in[(size_t)r * K + d.KX + k];
-      const float na = amb[2 * r];
-      const float ga = (d_amb && na > 0.f) ? d_amb[2 * r] / na : 0.f;
+      const float na = amb[3 * r];
+      const float ga = (d_amb && na > 0.f) ? d_amb[3 * r] / na : 0.f;
       d_aud[i] = enc_a[k] * gw + ga * a;
       if (fixed) part += gw * a; else atomicAdd(&s_acc[k], gw * a);
     }
@@ -84,8 +86,8 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
       const int r = (int)(i / d.KE), k = (int)(i - (size_t)r * d.KE);
       const float pre = eye_pre[i], gw = d_h_in[(size_t)r * K + d.KX + d.KA + k];
       const float act = fmaxf(pre, 0.f);
-      const float ne = amb[2 * r + 1];
-      const float ge = (d_amb && ne > 0.f) ? d_amb[2 * r + 1] / ne : 0.f;
+      const float ne = amb[3 * r + 1];
+      const float ge = (d_amb && ne > 0.f) ? d_amb[3 * r + 1] / ne : 0.f;
       d_eye_pre[i] = pre > 0.f ? (enc_e[k] * gw + ge * act) : 0.f;
       if (fixed) part += gw * act; else atomicAdd(&s_acc[32 + k], gw * act);
     }
@@ -272,7 +274,13 @@ int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const f
   INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1, "motion_glue: widths out of range");
   if (N == 0) return INSTAG_OK;
   const GlueDims d{N, KX, KA, KE};
-  motion_glue_backward_kernel<<<row_blocks(N * 8), GB, 0, (hipStream_t)stream>>>(
+  // a grid whose stride is a multiple of both column counts keeps every thread on one column of d_enc_a / d_enc_e
+  // (register partials instead of an LDS atomic per element)
+  auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+  const int ga = KA / gcd(KA, GB), ge = KE / gcd(KE, GB);
+  const int unit = ga / gcd(ga, ge) * ge;
+  const int blocks = std::max(unit, row_blocks(N * 8) / unit * unit);
+  motion_glue_backward_kernel<<<blocks, GB, 0, (hipStream_t)stream>>>(
       d, d_h_in, d_amb, aud, eye_pre, enc_a, enc_e, amb, d_enc_x, d_aud, d_eye_pre, d_enc_a, d_enc_e);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;

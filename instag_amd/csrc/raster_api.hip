@@ -284,7 +284,6 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
   const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)image;
   const Camera c = make_camera(a);
   float* inst_grad = (float*)workspace;
-  INSTAG_CHECK_HIP(hipMemsetAsync(inst_grad, 0, need, s));
   if (R > 0) {
     if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
                                       (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d), (const uint32_t*)(ib + IL.n_contrib),
@@ -320,7 +319,6 @@ int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, si
   const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)image;
   const Camera c = make_camera(a);
   float* inst_grad = (float*)workspace;
-  INSTAG_CHECK_HIP(hipMemsetAsync(inst_grad, 0, need, s));
   if (R > 0) {
     if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
                                       (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),

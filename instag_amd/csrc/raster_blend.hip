@@ -169,6 +169,13 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   if (lane == 0) s_max[wave] = m;
   __syncthreads();
   const int n = min(end - start, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+  // instances behind the last contributor of every pixel get an all-zero gradient row (every row of the tile's
+  // list is written exactly once, so the caller does not have to clear inst_grad)
+  for (int i = max(n, 0) + tid; i < end - start; i += BLOCK) {
+    float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)slot_list[start + i] * REC_FLOATS);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    dst[0] = z; dst[1] = z; dst[2] = z; dst[3] = z;
+  }
   if (n <= 0) return;
 
   const float T_final = inside ? final_T[pix] : 0.f;

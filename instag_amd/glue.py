@@ -25,7 +25,7 @@ class _MotionGlue(torch.autograd.Function):
         N, KX = enc_x.shape
         KA, KE = aud.shape[1], eye_pre.shape[1]
         h_in = torch.empty(N, KX + KA + KE, dtype=torch.float32, device=enc_x.device)
-        amb = torch.empty(N, 2, dtype=torch.float32, device=enc_x.device)
+        amb = torch.empty(N, 3, dtype=torch.float32, device=enc_x.device)
         check(L.instag_motion_glue_forward(ptr(enc_x), ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e), ptr(h_in),
                                            ptr(amb), N, KX, KA, KE, _lib.current_stream()), "motion_glue_forward")
         ctx.save_for_backward(aud, eye_pre, enc_a, enc_e, amb)
@@ -55,7 +55,7 @@ class _MotionGlue(torch.autograd.Function):
 
 
 def motion_glue(enc_x, aud, eye_pre, enc_a, enc_e):
-    """-> (h_in [N, KX+KA+KE], amb [N,2]); enc_a [KA], enc_e [KE] are per-frame vectors."""
+    """-> (h_in [N, KX+KA+KE], amb [N,3] = (||aud||, ||relu(eye_pre)||, 0)); enc_a [KA], enc_e [KE] per-frame vectors."""
     return _MotionGlue.apply(enc_x, aud, eye_pre, enc_a.reshape(-1), enc_e.reshape(-1))
 
 

@@ -201,7 +201,9 @@ class _TriPlaneField(nn.Module):
         self._audio_pending = (a, e, enc_a, enc_e, side)
 
     def _trunk(self, x, a, e, c):
-        """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim])"""
+        """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim], amb3); amb3 = the [N,3] tensor
+        (aud, eye, 0) the two ambient columns are views of (fused path) or None.  (Nothing of a step may be kept
+        on the module: a live autograd graph across steps breaks stream capture.)"""
         fork = x.is_cuda and CONCURRENT_AUDIO
         pending = self.__dict__.pop("_audio_pending", None)
         if fork:
@@ -231,7 +233,7 @@ class _TriPlaneField(nn.Module):
             if _glue.motion_glue_supported(enc_x, aud_ch_att, eye_pre):
                 # repeat / mul / relu / cat / norm chain as one HIP kernel per pass (instag_amd/glue.py)
                 h_in, amb = _glue.motion_glue(enc_x, aud_ch_att, eye_pre, enc_a, enc_e)
-                return enc_x, amb[:, 0:1], amb[:, 1:2], self.sigma_net(h_in)
+                return enc_x, amb[:, 0:1], amb[:, 1:2], self.sigma_net(h_in), amb
         parts = [enc_x, enc_a.repeat(enc_x.shape[0], 1) * aud_ch_att]
         eye_att = None
         if self.exp_eye:
@@ -241,7 +243,7 @@ class _TriPlaneField(nn.Module):
             parts.append(c.repeat(enc_x.shape[0], 1))
         h = self.sigma_net(torch.cat(parts, dim=-1))
         amb_eye = eye_att.norm(dim=-1, keepdim=True) if eye_att is not None else None
-        return enc_x, aud_ch_att.norm(dim=-1, keepdim=True), amb_eye, h
+        return enc_x, aud_ch_att.norm(dim=-1, keepdim=True), amb_eye, h, None
 
 
 class MotionNetwork(_TriPlaneField):
@@ -252,7 +254,7 @@ class MotionNetwork(_TriPlaneField):
         self.cache = None
 
     def forward(self, x, a, e=None, c=None):
-        _, amb_aud, amb_eye, h = self._trunk(x, a, e, c)
+        _, amb_aud, amb_eye, h, amb3 = self._trunk(x, a, e, c)
         def outputs(h, amb_aud, amb_eye):
             return LazyOutputs({
                 "d_xyz": lambda: h[..., :3] * 1e-2, "d_rot": h[..., 3:7], "d_opa": h[..., 7:8],
@@ -261,6 +263,7 @@ class MotionNetwork(_TriPlaneField):
             })
 
         results = outputs(h, amb_aud, amb_eye)
+        results["_amb3"] = amb3            # (ambient_aud, ambient_eye, 0) as one tensor = the attention colours
         # consumed without gradients by the mouth branch at inference (gaussian_renderer/__init__.py:362-363);
         # detached so that a finished step does not keep its autograd graph (and grad accumulators) alive
         self.cache = outputs(h.detach(), amb_aud.detach(), None if amb_eye is None else amb_eye.detach())
@@ -296,7 +299,7 @@ class PersonalizedMotionNetwork(_TriPlaneField):
         self.align_net = MLP(self.in_dim, 6, self.hidden_dim, 2)
 
     def forward(self, x, a, e=None, c=None, va=None):
-        enc_x, amb_aud, amb_eye, h = self._trunk(x, a, e, c)
+        enc_x, amb_aud, amb_eye, h, amb3 = self._trunk(x, a, e, c)
         face = self.args.type == "face"
         p = self.align_net(enc_x)
         return LazyOutputs({
@@ -305,7 +308,7 @@ class PersonalizedMotionNetwork(_TriPlaneField):
             "ambient_aud": amb_aud, "ambient_eye": amb_eye if self.exp_eye else None,
             "p_xyz": lambda: p[..., :3] * 1e-2,
             "p_scale": lambda: torch.tanh(p[..., 3:] / 5) * 0.25 + 1,
-            "_h": h, "_p": p,
+            "_h": h, "_p": p, "_amb3": amb3,
         })
 
     def get_params(self, lr, lr_net, wd=0):

@@ -61,6 +61,20 @@ def render(viewpoint_camera, pc, pipe=None, bg_color=None, scaling_modifier=1.0,
             "depth": depth, "alpha": alpha, "normal": normal, "radii": radii}
 
 
+_ONES = {}
+
+
+def _ones(like):
+    """Constant extra_attrs column, created once per (device, N) outside any graph capture."""
+    key = (like.device, tuple(like.shape))
+    t = _ONES.get(key)
+    if t is None:
+        if like.is_cuda and torch.cuda.is_current_stream_capturing():
+            return torch.ones_like(like)
+        t = _ONES[key] = torch.ones_like(like)
+    return t
+
+
 def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, scaling_modifier=1.0, frame_idx=None,
                   return_attn=False, personalized=False, align=False, detach_motion=False):
     """Render with the universal (motion_net) and personalised (pc.neural_motion_grid) motion fields."""
@@ -108,9 +122,11 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         opacity = pc.get_opacity
         scales = pc.scaling_activation(pc._scaling + d_scale)
         rotations = pc.rotation_activation(pc._rotation + d_rot)
-    ones = torch.ones_like(opacity)
+    ones = _ones(opacity)
 
     def attn_colors(preds):
+        if preds.get("_amb3") is not None:
+            return preds["_amb3"]
         eye = preds["ambient_eye"]
         return torch.cat([preds["ambient_aud"], eye, torch.zeros_like(eye)], dim=-1)
 

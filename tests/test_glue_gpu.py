@@ -31,9 +31,10 @@ def test_motion_glue_matches_torch():
     ((h_r * wh.double()).sum() + (a_r * wa.double()).sum()).backward()
     th = {k: v.cuda().requires_grad_(True) for k, v in leafs.items()}
     h_h, a_h = motion_glue(th["enc_x"], th["aud"], th["eye"], th["enc_a"], th["enc_e"])
-    ((h_h * wh.cuda()).sum() + (a_h * wa.cuda()).sum()).backward()
+    assert a_h.shape == (N, 3) and float(a_h[:, 2].abs().max()) == 0.0      # (aud, eye, 0)
+    ((h_h * wh.cuda()).sum() + (a_h[:, :2] * wa.cuda()).sum()).backward()
     _close(h_h, h_r, "h_in")
-    _close(a_h, a_r, "amb")
+    _close(a_h[:, :2], a_r, "amb")
     for k in leafs:
         _close(th[k].grad, td[k].grad, "d_" + k, tol=1e-4)
 
