@@ -44,6 +44,28 @@ def algorithmic_bytes(kernel, N, M, R, P, grid_points=0):
     }.get(kernel, 0)
 
 
+PMC_KERNEL = {"preprocess": "preprocess_kernel", "duplicate": "duplicate_kernel", "ranges": "ranges_kernel",
+              "blend_fwd": "blend_forward_kernel", "blend_bwd": "blend_backward_kernel",
+              "preprocess_bwd": "preprocess_backward_kernel"}
+
+
+def pmc_traffic(kernel, n_gaussians, size):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this workload
+    (profiles/r01_pmc_hbm_traffic_c3.json, written by scripts/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE), or None."""
+    if (n_gaussians, size) != (100000, 512) or kernel not in PMC_KERNEL:
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_c3.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    rows = [v for k, v in table.items() if k.startswith(PMC_KERNEL[kernel])]
+    if not rows:
+        return None
+    launches = sum(r["launches"] for r in rows)
+    return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / max(1, launches))
+
+
 def cpu_baseline(n_gaussians, size, sh_degree, budget_s=30.0):
     """Oracle (pure-PyTorch CPU rasterizer) fwd+bwd of the same scene on the host cores."""
     from instag_amd.scene_synth import activated, synthetic_gaussians, toy_cameras
@@ -196,7 +218,7 @@ def main():
             ab = algorithmic_bytes(dom, N, M, R, P, grid_points=N)
             achieved = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, N, size),
                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(kern[dom]["avg_us"], 2),
                         "launches": kern[dom]["launches"], "num_rendered": R}
         value = world * args.steps / elapsed
