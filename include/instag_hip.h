@@ -65,7 +65,7 @@ int instag_grid_total_variation(const float* inputs, const float* embeddings, fl
 /* Tri-plane encoder: the three identically configured 2-D, C=1 grid encoders of a motion field (planes xy, yz, xz;
  * scene/motion_net.py:214-216,244-258) in one pass: xyz [N,3] in [-bound,bound] -> out [N,3L] = cat(enc_xy, enc_yz,
  * enc_xz), including the (x+bound)/(2 bound) mapping (gridencoder/grid.py:149).  Each plane's table ([total_params,1],
- * shared `offsets` [L+1]) must fit 50 KB.  backward: grad [N,3L] -> dxyz [N,3] (written, may be NULL) and the three
+ * shared `offsets` [L+1]) must fit 64 KB.  backward: grad [N,3L] -> dxyz [N,3] (written, may be NULL) and the three
  * table gradients (written, not accumulated; summed over workgroups in a fixed order).  workspace:
  * instag_triplane_backward_workspace_bytes(N, total_params) bytes of scratch. */
 int instag_triplane_forward(const float* xyz, const float* table_xy, const float* table_yz,

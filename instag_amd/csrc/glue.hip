@@ -27,6 +27,7 @@ motion_glue_forward_kernel(GlueDims d, const float* __restrict__ enc_x, const fl
   const int K = d.KX + d.KA + d.KE;
   const size_t total = (size_t)d.N * K;
   // element-parallel part: coalesced write of h_in
+#pragma unroll 4
   for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < total; i += (size_t)gridDim.x * GB) {
     const int r = (int)(i / K), c = (int)(i - (size_t)r * K);
     float v;
@@ -57,6 +58,7 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
   for (int i = threadIdx.x; i < 64; i += GB) s_acc[i] = 0.f;
   __syncthreads();
   const size_t tx = (size_t)d.N * d.KX;
+#pragma unroll 4
   for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < tx; i += (size_t)gridDim.x * GB) {
     const int r = (int)(i / d.KX), c = (int)(i - (size_t)r * d.KX);
     d_enc_x[i] = d_h_in[(size_t)r * K + c];
@@ -68,6 +70,7 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
     const size_t ta = (size_t)d.N * d.KA;
     const bool fixed = (stride % d.KA) == 0;
     float part = 0.f;
+#pragma unroll 4
     for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < ta; i += stride) {
       const int r = (int)(i / d.KA), k = (int)(i - (size_t)r * d.KA);
       const float a = aud[i], gw = d_h_in[(size_t)r * K + d.KX + k];
@@ -82,6 +85,7 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
     const size_t te = (size_t)d.N * d.KE;
     const bool fixed = (stride % d.KE) == 0;
     float part = 0.f;
+#pragma unroll 4
     for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < te; i += stride) {
       const int r = (int)(i / d.KE), k = (int)(i - (size_t)r * d.KE);
       const float pre = eye_pre[i], gw = d_h_in[(size_t)r * K + d.KX + d.KA + k];

@@ -538,8 +538,8 @@ triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
   }
 }
 
-// Backward, stage 1: one point per thread across the three planes.  The three table gradients of the workgroup's
-// points accumulate in LDS (3T floats, float atomics), d/dxyz stays in registers and is written once; the LDS copy
+// Backward, stage 1: plane by plane, the plane's table and the gradient of the workgroup's points live in LDS
+// (2T floats: LDS float atomics for the scatter, LDS reads for d/dxyz); the LDS gradient
 // is then stored to the workgroup's slice of `ws` with plain coalesced stores (no global atomics: with ~400 points
 // per workgroup nearly every cell of every level is touched, so an atomic flush would cost 3T global atomics per
 // workgroup).  Stage 2 sums the slices in a fixed order.
@@ -553,56 +553,62 @@ inline unsigned tp_bwd_blocks(uint32_t N) {
 __global__ void __launch_bounds__(TP_BWD_BLOCK)
 triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]*/, float* __restrict__ dxyz /*[N,3] or null*/,
                          float* __restrict__ ws /*[gridDim.x][3T]*/) {
-  extern __shared__ __align__(16) float s_acc[];      // [3][T]
+  extern __shared__ __align__(16) float s_mem[];      // [T] table of the current plane | [T] its gradient
   __shared__ TpLevel s_lv[TP_MAX_L];
   const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;
   const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
   const uint32_t T = (uint32_t)a.offsets[a.L];
+  float* s_tab = s_mem;
+  float* s_acc = s_mem + T;
   const float inv2b = 1.0f / (2.0f * a.bound);
-  for (uint32_t i = threadIdx.x; i < 3 * T; i += TP_BWD_BLOCK) s_acc[i] = 0.f;
   tp_levels(a, s_lv);
-  __syncthreads();
-  for (uint32_t b = b0 + threadIdx.x; b < b1; b += TP_BWD_BLOCK) {
-    const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
-    float d[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int plane = 0; plane < 3; ++plane) {
+  float* slice = ws + (size_t)blockIdx.x * 3 * T;
+  for (int plane = 0; plane < 3; ++plane) {
+    __syncthreads();                                   // previous plane's slice fully stored
+    const float* __restrict__ tab = a.tables[plane];
+    for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK) { s_tab[i] = tab[i]; s_acc[i] = 0.f; }
+    __syncthreads();
+    for (uint32_t b = b0 + threadIdx.x; b < b1; b += TP_BWD_BLOCK) {
+      const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
       float xw[2];
       plane_coords(plane, p, xw);
       const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
-      if (x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f) continue;
-      const float* __restrict__ g = grad + (size_t)b * 3 * a.L + plane * a.L;
-      const float* __restrict__ tab = a.tables[plane];
-      float* acc = s_acc + plane * T;
       float gx = 0.f, gy = 0.f;
+      if (!(x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f)) {
+        const float* __restrict__ g = grad + (size_t)b * 3 * a.L + plane * a.L;
 #pragma unroll 4
-      for (uint32_t l = 0; l < a.L; ++l) {
-        const TpLevel lv = s_lv[l];
-        const float gl = g[l];
-        const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
-        const float flx = floorf(px), fly = floorf(py);
-        const float fx = px - flx, fy = py - fly;
-        const uint32_t i00 = lv.offset + (uint32_t)flx + (uint32_t)fly * lv.stride;
-        const uint32_t i10 = i00 + 1, i01 = i00 + lv.stride, i11 = i01 + 1;
-        __hip_atomic_fetch_add(&acc[i00], (1.f - fx) * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[i10], fx * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[i01], (1.f - fx) * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(&acc[i11], fx * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (dxyz) {
-          const float v00 = tab[i00], v10 = tab[i10], v01 = tab[i01], v11 = tab[i11];
-          // dy_dx of kernel_grid (gridencoder.cu:201-244) for D=2, linear interpolation
-          gx += gl * lv.scale * ((1.f - fy) * (v10 - v00) + fy * (v11 - v01));
-          gy += gl * lv.scale * ((1.f - fx) * (v01 - v00) + fx * (v11 - v10));
+        for (uint32_t l = 0; l < a.L; ++l) {
+          const TpLevel lv = s_lv[l];
+          const float gl = g[l];
+          const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
+          const float flx = floorf(px), fly = floorf(py);
+          const float fx = px - flx, fy = py - fly;
+          const uint32_t i00 = lv.offset + (uint32_t)flx + (uint32_t)fly * lv.stride;
+          const uint32_t i10 = i00 + 1, i01 = i00 + lv.stride, i11 = i01 + 1;
+          __hip_atomic_fetch_add(&s_acc[i00], (1.f - fx) * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&s_acc[i10], fx * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&s_acc[i01], (1.f - fx) * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_fetch_add(&s_acc[i11], fx * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (dxyz) {
+            const float v00 = s_tab[i00], v10 = s_tab[i10], v01 = s_tab[i01], v11 = s_tab[i11];
+            // dy_dx of kernel_grid (gridencoder.cu:201-244) for D=2, linear interpolation
+            gx += gl * lv.scale * ((1.f - fy) * (v10 - v00) + fy * (v11 - v01));
+            gy += gl * lv.scale * ((1.f - fx) * (v01 - v00) + fx * (v11 - v10));
+          }
         }
       }
-      d[plane == 1 ? 1 : 0] += gx * inv2b;
-      d[plane == 0 ? 1 : 2] += gy * inv2b;
+      if (dxyz) {
+        // the point is owned by this thread in all three planes: plain read-modify-write
+        float* d = dxyz + (size_t)b * 3;
+        gx *= inv2b; gy *= inv2b;
+        if (plane == 0) { d[0] = gx; d[1] = gy; d[2] = 0.f; }
+        else if (plane == 1) { d[1] += gx; d[2] += gy; }
+        else { d[0] += gx; d[2] += gy; }
+      }
     }
-    if (dxyz) { dxyz[3 * (size_t)b] = d[0]; dxyz[3 * (size_t)b + 1] = d[1]; dxyz[3 * (size_t)b + 2] = d[2]; }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK) slice[plane * T + i] = s_acc[i];
   }
-  __syncthreads();
-  float* out = ws + (size_t)blockIdx.x * 3 * T;
-  for (uint32_t i = threadIdx.x; i < 3 * T; i += TP_BWD_BLOCK) out[i] = s_acc[i];
 }
 
 // stage 2: dtab[plane][i] = sum over workgroup slices, fixed order.  32 cells x 8 slice-groups per workgroup.
@@ -663,8 +669,8 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
   INSTAG_REQUIRE(grad && xyz && table_xy && table_yz && table_xz && offsets && dtable_xy && dtable_yz && dtable_xz,
                  "triplane_backward: NULL tensor");
   INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
-  INSTAG_REQUIRE((size_t)3 * total_params * sizeof(float) <= 150 * 1024,
-                 "triplane: the three table gradients must fit 150 KB of LDS");
+  INSTAG_REQUIRE((size_t)2 * total_params * sizeof(float) <= 150 * 1024,
+                 "triplane: a plane's table and its gradient must fit 150 KB of LDS");
   hipStream_t s = (hipStream_t)stream;
   if (N == 0) {
     for (float* d : {dtable_xy, dtable_yz, dtable_xz})
@@ -682,7 +688,7 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
   }
   TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound};
   ProfScope p(K_GRID_BWD, s);
-  triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)3 * total_params * sizeof(float), s>>>(
+  triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)2 * total_params * sizeof(float), s>>>(
       a, grad, dxyz, (float*)workspace);
   INSTAG_CHECK_LAUNCH();
   triplane_reduce_kernel<<<div_up<uint32_t>(3 * total_params, 32), 256, 0, s>>>((const float*)workspace, blocks,

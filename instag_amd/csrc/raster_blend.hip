@@ -162,8 +162,24 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   const size_t pix = (size_t)pyi * c.W + pxi;
 
   const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-  // only the first max(last_contributor) Gaussians of the list reached any pixel of this tile
-  int m = last_contributor;
+  const float T_final = inside ? final_T[pix] : 0.f;
+  float T = T_final;
+  float dpix[NCH];
+  dpix[0] = (inside && dL_dcolor) ? dL_dcolor[pix] : 0.f;
+  dpix[1] = (inside && dL_dcolor) ? dL_dcolor[P + pix] : 0.f;
+  dpix[2] = (inside && dL_dcolor) ? dL_dcolor[2 * P + pix] : 0.f;
+  dpix[3] = (FULL && inside && dL_ddepth) ? dL_ddepth[pix] : 0.f;
+  dpix[4] = (FULL && inside && dL_dnormal) ? dL_dnormal[pix] : 0.f;
+  dpix[5] = (FULL && inside && dL_dnormal) ? dL_dnormal[P + pix] : 0.f;
+  dpix[6] = (FULL && inside && dL_dnormal) ? dL_dnormal[2 * P + pix] : 0.f;
+  dpix[7] = (FULL && inside && dL_dextra) ? dL_dextra[pix] : 0.f;
+  const float dalpha_img = (inside && dL_dalpha_img) ? dL_dalpha_img[pix] : 0.f;
+  bool live = dalpha_img != 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) live = live || dpix[k] != 0.f;
+  // only the first max(last_contributor) Gaussians of the list reached any pixel of this tile; a pixel whose
+  // incoming gradient is exactly zero contributes nothing (a masked loss leaves most tiles of an image untouched)
+  int m = live ? last_contributor : 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
   if (lane == 0) s_max[wave] = m;
@@ -178,18 +194,6 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   }
   if (n <= 0) return;
 
-  const float T_final = inside ? final_T[pix] : 0.f;
-  float T = T_final;
-  float dpix[NCH];
-  dpix[0] = (inside && dL_dcolor) ? dL_dcolor[pix] : 0.f;
-  dpix[1] = (inside && dL_dcolor) ? dL_dcolor[P + pix] : 0.f;
-  dpix[2] = (inside && dL_dcolor) ? dL_dcolor[2 * P + pix] : 0.f;
-  dpix[3] = (FULL && inside && dL_ddepth) ? dL_ddepth[pix] : 0.f;
-  dpix[4] = (FULL && inside && dL_dnormal) ? dL_dnormal[pix] : 0.f;
-  dpix[5] = (FULL && inside && dL_dnormal) ? dL_dnormal[P + pix] : 0.f;
-  dpix[6] = (FULL && inside && dL_dnormal) ? dL_dnormal[2 * P + pix] : 0.f;
-  dpix[7] = (FULL && inside && dL_dextra) ? dL_dextra[pix] : 0.f;
-  const float dalpha_img = (inside && dL_dalpha_img) ? dL_dalpha_img[pix] : 0.f;
   // d(T_final)/d(alpha_i) = -T_final/(1-alpha_i); T_final enters image (+bg) and alpha image (-1)
   const float tail = (c.bg[0] * dpix[0] + c.bg[1] * dpix[1] + c.bg[2] * dpix[2]) - dalpha_img;
 
