@@ -501,6 +501,30 @@ __device__ __forceinline__ void tp_levels(const TriPlaneArgs& a, TpLevel* s_lv) 
   }
 }
 
+// table -> LDS with 16-byte loads, several in flight per thread (a scalar loop with a run-time trip count waits
+// for every load in turn: ~1 us per iteration from L2)
+template <int THREADS, bool ZERO_ACC>
+__device__ __forceinline__ void tp_stage_table(float* __restrict__ s_tab, float* __restrict__ s_acc,
+                                               const float* __restrict__ tab, uint32_t T) {
+  if ((T & 3u) == 0 && (reinterpret_cast<uintptr_t>(tab) & 15) == 0) {
+    const float4* src = reinterpret_cast<const float4*>(tab);
+    float4* dst = reinterpret_cast<float4*>(s_tab);
+    float4* acc = reinterpret_cast<float4*>(s_acc);
+    const uint32_t n4 = T >> 2;
+#pragma unroll 8
+    for (uint32_t i = threadIdx.x; i < n4; i += THREADS) {
+      dst[i] = src[i];
+      if (ZERO_ACC) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+#pragma unroll 8
+    for (uint32_t i = threadIdx.x; i < T; i += THREADS) {
+      s_tab[i] = tab[i];
+      if (ZERO_ACC) s_acc[i] = 0.f;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(GRID_BLOCK)
 triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
   extern __shared__ __align__(16) float s_tab[];
@@ -512,7 +536,7 @@ triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
   tp_levels(a, s_lv);
   for (int plane = 0; plane < 3; ++plane) {
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < T; i += GRID_BLOCK) s_tab[i] = a.tables[plane][i];
+    tp_stage_table<GRID_BLOCK, false>(s_tab, nullptr, a.tables[plane], T);
     __syncthreads();
     for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
       const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
@@ -521,6 +545,7 @@ triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
       const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
       const bool oob = x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f;
       float* o = out + (size_t)b * 3 * a.L + plane * a.L;
+#pragma unroll 4
       for (uint32_t l = 0; l < a.L; ++l) {
         float v = 0.f;
         if (!oob) {
@@ -566,7 +591,7 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
   for (int plane = 0; plane < 3; ++plane) {
     __syncthreads();                                   // previous plane's slice fully stored
     const float* __restrict__ tab = a.tables[plane];
-    for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK) { s_tab[i] = tab[i]; s_acc[i] = 0.f; }
+    tp_stage_table<TP_BWD_BLOCK, true>(s_tab, s_acc, tab, T);
     __syncthreads();
     for (uint32_t b = b0 + threadIdx.x; b < b1; b += TP_BWD_BLOCK) {
       const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
@@ -607,6 +632,7 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
       }
     }
     __syncthreads();
+#pragma unroll 8
     for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK) slice[plane * T + i] = s_acc[i];
   }
 }

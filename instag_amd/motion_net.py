@@ -200,7 +200,7 @@ class _TriPlaneField(nn.Module):
             enc_a, enc_e = self.encode_frame(a, e)
         self._audio_pending = (a, e, enc_a, enc_e, side)
 
-    def _trunk(self, x, a, e, c):
+    def _trunk(self, x, a, e, c, enc_x=None):
         """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim], amb3); amb3 = the [N,3] tensor
         (aud, eye, 0) the two ambient columns are views of (fused path) or None.  (Nothing of a step may be kept
         on the module: a live autograd graph across steps breaks stream capture.)"""
@@ -217,7 +217,8 @@ class _TriPlaneField(nn.Module):
                 side.wait_stream(main_stream)
                 with torch.cuda.stream(side):
                     enc_a, enc_e = self.encode_frame(a, e)
-        enc_x = self.encode_x(x, bound=self.bound)
+        if enc_x is None:
+            enc_x = self.encode_x(x, bound=self.bound)
         if fork:
             aud_ch_att = self.aud_ch_att_net(enc_x)
             main_stream.wait_stream(side)
@@ -299,16 +300,29 @@ class PersonalizedMotionNetwork(_TriPlaneField):
         self.align_net = MLP(self.in_dim, 6, self.hidden_dim, 2)
 
     def forward(self, x, a, e=None, c=None, va=None):
-        enc_x, amb_aud, amb_eye, h, amb3 = self._trunk(x, a, e, c)
+        """Same result dict as the reference.  Only the alignment head (p_xyz, p_scale) is evaluated eagerly: the
+        deformation head (audio branch, attention MLPs, sigma_net) runs on first access of one of its entries,
+        so a caller that renders with ``personalized=False`` (train_face.py warm stage) does not pay for outputs
+        it never reads -- the values, when read, are the same."""
         face = self.args.type == "face"
+        enc_x = self.encode_x(x, bound=self.bound)
         p = self.align_net(enc_x)
+        memo = {}
+
+        def head():
+            if "r" not in memo:
+                memo["r"] = self._trunk(x, a, e, c, enc_x=enc_x)
+            return memo["r"]            # (enc_x, amb_aud, amb_eye, h, amb3)
+
         return LazyOutputs({
-            "d_xyz": lambda: h[..., :3] * 1e-2, "d_rot": h[..., 3:7],
-            "d_opa": h[..., 7:8] if face else None, "d_scale": h[..., 8:11] if face else None,
-            "ambient_aud": amb_aud, "ambient_eye": amb_eye if self.exp_eye else None,
+            "d_xyz": lambda: head()[3][..., :3] * 1e-2, "d_rot": lambda: head()[3][..., 3:7],
+            "d_opa": (lambda: head()[3][..., 7:8]) if face else None,
+            "d_scale": (lambda: head()[3][..., 8:11]) if face else None,
+            "ambient_aud": lambda: head()[1],
+            "ambient_eye": (lambda: head()[2]) if self.exp_eye else None,
             "p_xyz": lambda: p[..., :3] * 1e-2,
             "p_scale": lambda: torch.tanh(p[..., 3:] / 5) * 0.25 + 1,
-            "_h": h, "_p": p, "_amb3": amb3,
+            "_h": lambda: head()[3], "_p": p, "_amb3": lambda: head()[4],
         })
 
     def get_params(self, lr, lr_net, wd=0):

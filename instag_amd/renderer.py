@@ -90,7 +90,8 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     if xyz.is_cuda and hasattr(motion_net, "start_audio"):
         # both networks' audio branches depend only on the frame: start them now, each on its own side stream
         motion_net.start_audio(audio_feat, 1, exp_feat)
-        if (personalized or align) and hasattr(pc.neural_motion_grid, "start_audio"):
+        if personalized and hasattr(pc.neural_motion_grid, "start_audio"):
+            # (with align only, the personalised field's deformation head is never read: motion_net.py)
             pc.neural_motion_grid.start_audio(audio_feat, 2, exp_feat)
     if personalized or align:
         p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat, exp_feat)
@@ -101,7 +102,7 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     motion_preds = motion_net(xyz, audio_feat, exp_feat)
 
     fused = (align and not personalized and not detach_motion and pc.get_xyz.is_cuda
-             and motion_preds.get("_h") is not None and p_motion_preds.get("_p") is not None
+             and motion_preds.get("_h") is not None and dict.get(p_motion_preds, "_p") is not None
              and motion_preds["_h"].shape[-1] == 11)
     if fused:
         # deltas + softplus / normalize / sigmoid in one HIP kernel per pass (instag_amd/glue.py)
