@@ -563,11 +563,15 @@ triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
   }
 }
 
-// Backward, stage 1: plane by plane, the plane's table and the gradient of the workgroup's points live in LDS
-// (2T floats: LDS float atomics for the scatter, LDS reads for d/dxyz); the LDS gradient
-// is then stored to the workgroup's slice of `ws` with plain coalesced stores (no global atomics: with ~400 points
-// per workgroup nearly every cell of every level is touched, so an atomic flush would cost 3T global atomics per
-// workgroup).  Stage 2 sums the slices in a fixed order.
+// Backward, stage 1: plane by plane, the plane's table (T floats) and the gradient of the workgroup's points
+// (T 64-bit fixed-point accumulators) live in LDS.  LDS FLOAT atomics run at roughly one lane at a time on gfx950
+// (measured here: 14.4 M ds_add_f32 cost 80 us, the same number of ds_add_u64 nothing beside the loads), so the
+// scatter adds integers: every contribution is scaled by a per-workgroup power of two chosen from the largest
+// |grad| so that no sum can overflow (resolution <= 2^-40 of that maximum: finer than an fp32 running sum), the
+// total is converted back once.  Integer addition is associative, so the result does not depend on the order of
+// the adds: together with the fixed-order slice reduction of stage 2 the table gradient is bitwise reproducible.
+// The slices are stored with plain coalesced stores (no global atomics: with ~400 points per workgroup nearly
+// every cell of every level is touched, an atomic flush would cost 3T global atomics per workgroup).
 constexpr int TP_BWD_BLOCK = 512;
 constexpr uint32_t TP_BWD_MAX_BLOCKS = 256;
 
@@ -578,20 +582,45 @@ inline unsigned tp_bwd_blocks(uint32_t N) {
 __global__ void __launch_bounds__(TP_BWD_BLOCK)
 triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]*/, float* __restrict__ dxyz /*[N,3] or null*/,
                          float* __restrict__ ws /*[gridDim.x][3T]*/) {
-  extern __shared__ __align__(16) float s_mem[];      // [T] table of the current plane | [T] its gradient
+  extern __shared__ __align__(16) unsigned long long s_mem64[];      // [T] i64 gradient | [T] f32 table of the plane
   __shared__ TpLevel s_lv[TP_MAX_L];
+  __shared__ float s_wmax[TP_BWD_BLOCK / 64];
   const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;
   const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
   const uint32_t T = (uint32_t)a.offsets[a.L];
-  float* s_tab = s_mem;
-  float* s_acc = s_mem + T;
+  unsigned long long* s_acc = s_mem64;
+  float* s_tab = reinterpret_cast<float*>(s_mem64 + T);
   const float inv2b = 1.0f / (2.0f * a.bound);
   tp_levels(a, s_lv);
+  // fixed-point scale of this workgroup: |sum into one cell| <= (#points) * max|grad| < 2^62
+  float gmax = 0.f;
+  for (uint32_t b = b0 + threadIdx.x; b < b1; b += TP_BWD_BLOCK) {
+    const float* __restrict__ g = grad + (size_t)b * 3 * a.L;
+#pragma unroll 4
+    for (uint32_t k = 0; k < 3 * a.L; ++k) gmax = fmaxf(gmax, fabsf(g[k]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = gmax;
+  __syncthreads();
+  gmax = s_wmax[0];
+#pragma unroll
+  for (int w = 1; w < TP_BWD_BLOCK / 64; ++w) gmax = fmaxf(gmax, s_wmax[w]);
+  const bool usable = gmax > 0.f && gmax < INFINITY;      // all-zero (or non-finite) gradients: nothing to scatter
+  int shift = 0;
+  if (usable) {
+    int npts_log2 = 1;
+    while ((1u << npts_log2) < per_block) ++npts_log2;
+    shift = 60 - (ilogbf(gmax) + 1) - npts_log2;
+  }
+  const double to_fixed = ldexp(1.0, shift), to_float = ldexp(1.0, -shift);
   float* slice = ws + (size_t)blockIdx.x * 3 * T;
   for (int plane = 0; plane < 3; ++plane) {
     __syncthreads();                                   // previous plane's slice fully stored
     const float* __restrict__ tab = a.tables[plane];
-    tp_stage_table<TP_BWD_BLOCK, true>(s_tab, s_acc, tab, T);
+    tp_stage_table<TP_BWD_BLOCK, false>(s_tab, nullptr, tab, T);
+#pragma unroll 8
+    for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK) s_acc[i] = 0ull;
     __syncthreads();
     for (uint32_t b = b0 + threadIdx.x; b < b1; b += TP_BWD_BLOCK) {
       const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
@@ -610,10 +639,13 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
           const float fx = px - flx, fy = py - fly;
           const uint32_t i00 = lv.offset + (uint32_t)flx + (uint32_t)fly * lv.stride;
           const uint32_t i10 = i00 + 1, i01 = i00 + lv.stride, i11 = i01 + 1;
-          __hip_atomic_fetch_add(&s_acc[i00], (1.f - fx) * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&s_acc[i10], fx * (1.f - fy) * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&s_acc[i01], (1.f - fx) * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&s_acc[i11], fx * fy * gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (usable) {
+            const double gs = (double)gl * to_fixed;
+            atomicAdd(&s_acc[i00], (unsigned long long)__double2ll_rn((double)((1.f - fx) * (1.f - fy)) * gs));
+            atomicAdd(&s_acc[i10], (unsigned long long)__double2ll_rn((double)(fx * (1.f - fy)) * gs));
+            atomicAdd(&s_acc[i01], (unsigned long long)__double2ll_rn((double)((1.f - fx) * fy) * gs));
+            atomicAdd(&s_acc[i11], (unsigned long long)__double2ll_rn((double)(fx * fy) * gs));
+          }
           if (dxyz) {
             const float v00 = s_tab[i00], v10 = s_tab[i10], v01 = s_tab[i01], v11 = s_tab[i11];
             // dy_dx of kernel_grid (gridencoder.cu:201-244) for D=2, linear interpolation
@@ -633,7 +665,8 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
     }
     __syncthreads();
 #pragma unroll 8
-    for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK) slice[plane * T + i] = s_acc[i];
+    for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK)
+      slice[plane * T + i] = (float)((double)(long long)s_acc[i] * to_float);
   }
 }
 
@@ -695,8 +728,8 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
   INSTAG_REQUIRE(grad && xyz && table_xy && table_yz && table_xz && offsets && dtable_xy && dtable_yz && dtable_xz,
                  "triplane_backward: NULL tensor");
   INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
-  INSTAG_REQUIRE((size_t)2 * total_params * sizeof(float) <= 150 * 1024,
-                 "triplane: a plane's table and its gradient must fit 150 KB of LDS");
+  INSTAG_REQUIRE((size_t)12 * total_params <= 156 * 1024,
+                 "triplane: a plane's table (4 B / entry) and its gradient (8 B / entry) must fit 156 KB of LDS");
   hipStream_t s = (hipStream_t)stream;
   if (N == 0) {
     for (float* d : {dtable_xy, dtable_yz, dtable_xz})
@@ -709,13 +742,12 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
   static bool attr_set = false;
   if (!attr_set) {
     INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(triplane_backward_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     attr_set = true;
   }
   TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound};
   ProfScope p(K_GRID_BWD, s);
-  triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)2 * total_params * sizeof(float), s>>>(
-      a, grad, dxyz, (float*)workspace);
+  triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)12 * total_params, s>>>(a, grad, dxyz, (float*)workspace);
   INSTAG_CHECK_LAUNCH();
   triplane_reduce_kernel<<<div_up<uint32_t>(3 * total_params, 32), 256, 0, s>>>((const float*)workspace, blocks,
                                                                               total_params, dtable_xy, dtable_yz,

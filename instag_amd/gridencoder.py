@@ -193,7 +193,7 @@ def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
                and e.base_resolution == e0.base_resolution and e.per_level_scale == e0.per_level_scale
                and e.gridtype_id == 0 and not e.align_corners and e.interp_id == 0
                and e.embeddings.shape == e0.embeddings.shape and e.embeddings.is_cuda for e in encs)
-    if not (same and e0.num_levels <= 16 and e0.embeddings.shape[0] * 8 <= 150 * 1024):
+    if not (same and e0.num_levels <= 16 and e0.embeddings.shape[0] * 12 <= 156 * 1024):
         return False
     # the fused kernels index every level densely (x + y*(res+1)): no level may be hashed
     for i in range(e0.num_levels):
