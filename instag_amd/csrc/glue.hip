@@ -20,25 +20,43 @@ constexpr int GB = 256;
 // ---- motion glue ----------------------------------------------------------------------------------------------
 struct GlueDims { int N, KX, KA, KE; };   // enc_x width, audio width, eye width; h_in width = KX+KA+KE
 
+// Walks the elements i0, i0 + stride, i0 + 2 stride, ... of a row-major [rows x K] matrix as (row, column) pairs
+// with one division at the start instead of one (64-bit) division per element.
+struct Walk {
+  int r, c, qr, qc, K;
+  __device__ Walk(size_t i0, size_t stride, int K_) : K(K_) {
+    r = (int)(i0 / (size_t)K_); c = (int)(i0 - (size_t)r * K_);
+    qr = (int)(stride / (size_t)K_); qc = (int)(stride - (size_t)qr * K_);
+  }
+  __device__ __forceinline__ void next() {
+    r += qr; c += qc;
+    if (c >= K) { c -= K; ++r; }
+  }
+};
+
 __global__ void __launch_bounds__(GB)
 motion_glue_forward_kernel(GlueDims d, const float* __restrict__ enc_x, const float* __restrict__ aud,
                            const float* __restrict__ eye_pre, const float* __restrict__ enc_a,
                            const float* __restrict__ enc_e, float* __restrict__ h_in, float* __restrict__ amb) {
   const int K = d.KX + d.KA + d.KE;
-  const size_t total = (size_t)d.N * K;
+  const size_t stride = (size_t)gridDim.x * GB, i0 = (size_t)blockIdx.x * GB + threadIdx.x;
   // element-parallel part: coalesced write of h_in
+  {
+    Walk w(i0, stride, K);
 #pragma unroll 4
-  for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < total; i += (size_t)gridDim.x * GB) {
-    const int r = (int)(i / K), c = (int)(i - (size_t)r * K);
-    float v;
-    if (c < d.KX) v = enc_x[(size_t)r * d.KX + c];
-    else if (c < d.KX + d.KA) v = enc_a[c - d.KX] * aud[(size_t)r * d.KA + (c - d.KX)];
-    else v = enc_e[c - d.KX - d.KA] * fmaxf(eye_pre[(size_t)r * d.KE + (c - d.KX - d.KA)], 0.f);
-    h_in[i] = v;
+    for (; w.r < d.N; w.next()) {
+      const int r = w.r, c = w.c;
+      float v;
+      if (c < d.KX) v = enc_x[(size_t)r * d.KX + c];
+      else if (c < d.KX + d.KA) v = enc_a[c - d.KX] * aud[(size_t)r * d.KA + (c - d.KX)];
+      else v = enc_e[c - d.KX - d.KA] * fmaxf(eye_pre[(size_t)r * d.KE + (c - d.KX - d.KA)], 0.f);
+      h_in[(size_t)r * K + c] = v;
+    }
   }
   // row-parallel part: the two norms
   for (int r = blockIdx.x * GB + threadIdx.x; r < d.N; r += gridDim.x * GB) {
     float sa = 0.f, se = 0.f;
+#pragma unroll 8
     for (int k = 0; k < d.KA; ++k) { const float v = aud[(size_t)r * d.KA + k]; sa += v * v; }
     for (int k = 0; k < d.KE; ++k) { const float v = fmaxf(eye_pre[(size_t)r * d.KE + k], 0.f); se += v * v; }
     amb[3 * r] = sqrtf(sa);
@@ -53,53 +71,64 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
                             const float* __restrict__ enc_a, const float* __restrict__ enc_e,
                             const float* __restrict__ amb, float* __restrict__ d_enc_x, float* __restrict__ d_aud,
                             float* __restrict__ d_eye_pre, float* __restrict__ d_enc_a, float* __restrict__ d_enc_e) {
-  __shared__ float s_acc[64];
+  __shared__ float s_part[GB / 64][64];
   const int K = d.KX + d.KA + d.KE;
-  for (int i = threadIdx.x; i < 64; i += GB) s_acc[i] = 0.f;
-  __syncthreads();
-  const size_t tx = (size_t)d.N * d.KX;
-#pragma unroll 4
-  for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < tx; i += (size_t)gridDim.x * GB) {
-    const int r = (int)(i / d.KX), c = (int)(i - (size_t)r * d.KX);
-    d_enc_x[i] = d_h_in[(size_t)r * K + c];
-  }
-  // element-parallel (coalesced) over the audio and eye blocks; the per-column sums of d_enc_a / d_enc_e go
-  // through one register partial per thread when the grid stride keeps a thread on one column, LDS atomics otherwise
-  const size_t stride = (size_t)gridDim.x * GB;
+  const size_t stride = (size_t)gridDim.x * GB, i0 = (size_t)blockIdx.x * GB + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
-    const size_t ta = (size_t)d.N * d.KA;
-    const bool fixed = (stride % d.KA) == 0;
-    float part = 0.f;
+    Walk w(i0, stride, d.KX);
 #pragma unroll 4
-    for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < ta; i += stride) {
-      const int r = (int)(i / d.KA), k = (int)(i - (size_t)r * d.KA);
-      const float a = aud[i], gw = d_h_in[(size_t)r * K + d.KX + k];
+    for (; w.r < d.N; w.next()) d_enc_x[(size_t)w.r * d.KX + w.c] = d_h_in[(size_t)w.r * K + w.c];
+  }
+  // The launcher picks a grid whose stride is a multiple of KA and KE: every thread stays on ONE column of the audio
+  // and of the eye block, the column sums of d_enc_a / d_enc_e are register partials, combined per workgroup in a
+  // fixed order (LDS float atomics are slow on gfx950) and added to the result with one global atomic per column.
+  float pa = 0.f, pe = 0.f;
+  int ca, ce;
+  {
+    Walk w(i0, stride, d.KA);
+    ca = w.c;
+#pragma unroll 4
+    for (; w.r < d.N; w.next()) {
+      const int r = w.r, k = w.c;
+      const float a = aud[(size_t)r * d.KA + k], gw = d_h_in[(size_t)r * K + d.KX + k];
       const float na = amb[3 * r];
       const float ga = (d_amb && na > 0.f) ? d_amb[3 * r] / na : 0.f;
-      d_aud[i] = enc_a[k] * gw + ga * a;
-      if (fixed) part += gw * a; else atomicAdd(&s_acc[k], gw * a);
+      d_aud[(size_t)r * d.KA + k] = enc_a[k] * gw + ga * a;
+      pa += gw * a;
     }
-    if (fixed) atomicAdd(&s_acc[(int)(((size_t)blockIdx.x * GB + threadIdx.x) % d.KA)], part);
   }
   {
-    const size_t te = (size_t)d.N * d.KE;
-    const bool fixed = (stride % d.KE) == 0;
-    float part = 0.f;
+    Walk w(i0, stride, d.KE);
+    ce = w.c;
 #pragma unroll 4
-    for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < te; i += stride) {
-      const int r = (int)(i / d.KE), k = (int)(i - (size_t)r * d.KE);
-      const float pre = eye_pre[i], gw = d_h_in[(size_t)r * K + d.KX + d.KA + k];
+    for (; w.r < d.N; w.next()) {
+      const int r = w.r, k = w.c;
+      const float pre = eye_pre[(size_t)r * d.KE + k], gw = d_h_in[(size_t)r * K + d.KX + d.KA + k];
       const float act = fmaxf(pre, 0.f);
       const float ne = amb[3 * r + 1];
       const float ge = (d_amb && ne > 0.f) ? d_amb[3 * r + 1] / ne : 0.f;
-      d_eye_pre[i] = pre > 0.f ? (enc_e[k] * gw + ge * act) : 0.f;
-      if (fixed) part += gw * act; else atomicAdd(&s_acc[32 + k], gw * act);
+      d_eye_pre[(size_t)r * d.KE + k] = pre > 0.f ? (enc_e[k] * gw + ge * act) : 0.f;
+      pe += gw * act;
     }
-    if (fixed) atomicAdd(&s_acc[32 + (int)(((size_t)blockIdx.x * GB + threadIdx.x) % d.KE)], part);
+  }
+  // column sums: thread t of the workgroup owns column (i0 % KA) resp. (i0 % KE); thread 0..KA-1 / 0..KE-1 gathers
+  s_part[wave][lane] = pa;
+  __syncthreads();
+  if ((int)threadIdx.x < d.KA) {
+    // threads whose audio column equals this one: t with (blockIdx*GB + t) % KA == column of thread threadIdx.x
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < GB; t += d.KA) sum += s_part[t >> 6][t & 63];
+    atomicAdd(&d_enc_a[ca], sum);
   }
   __syncthreads();
-  if ((int)threadIdx.x < d.KA) atomicAdd(&d_enc_a[threadIdx.x], s_acc[threadIdx.x]);
-  if ((int)threadIdx.x < d.KE) atomicAdd(&d_enc_e[threadIdx.x], s_acc[32 + threadIdx.x]);
+  s_part[wave][lane] = pe;
+  __syncthreads();
+  if ((int)threadIdx.x < d.KE) {
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < GB; t += d.KE) sum += s_part[t >> 6][t & 63];
+    atomicAdd(&d_enc_e[ce], sum);
+  }
 }
 
 // ---- deform + activations ---------------------------------------------------------------------------------------
@@ -278,8 +307,7 @@ int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const f
   INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1, "motion_glue: widths out of range");
   if (N == 0) return INSTAG_OK;
   const GlueDims d{N, KX, KA, KE};
-  // a grid whose stride is a multiple of both column counts keeps every thread on one column of d_enc_a / d_enc_e
-  // (register partials instead of an LDS atomic per element)
+  // the in-kernel column sums need every thread to stay on one column: grid stride a multiple of KA and of KE
   auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
   const int ga = KA / gcd(KA, GB), ge = KE / gcd(KE, GB);
   const int unit = ga / gcd(ga, ge) * ge;
