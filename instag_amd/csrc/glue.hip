@@ -65,69 +65,60 @@ motion_glue_forward_kernel(GlueDims d, const float* __restrict__ enc_x, const fl
   }
 }
 
+// One pass over the rows of d_h_in (each 128-B line is fetched once): the thread's column decides whether it copies
+// (enc_x block), scales by enc_a and adds the norm term (audio block) or does the same through the ReLU (eye block).
+// The launcher picks a grid whose stride is a multiple of K = KX+KA+KE, so a thread stays on ONE column: the column
+// sums d_enc_a / d_enc_e are register partials, combined per workgroup in a fixed order (LDS float atomics are slow
+// on gfx950) and added to the result with one global atomic per column and workgroup.
 __global__ void __launch_bounds__(GB)
 motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const float* __restrict__ d_amb,
                             const float* __restrict__ aud, const float* __restrict__ eye_pre,
                             const float* __restrict__ enc_a, const float* __restrict__ enc_e,
                             const float* __restrict__ amb, float* __restrict__ d_enc_x, float* __restrict__ d_aud,
                             float* __restrict__ d_eye_pre, float* __restrict__ d_enc_a, float* __restrict__ d_enc_e) {
-  __shared__ float s_part[GB / 64][64];
+  __shared__ float s_part[GB];
   const int K = d.KX + d.KA + d.KE;
   const size_t stride = (size_t)gridDim.x * GB, i0 = (size_t)blockIdx.x * GB + threadIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  {
-    Walk w(i0, stride, d.KX);
+  Walk w(i0, stride, K);
+  const int c = w.c;                       // constant along the walk (stride % K == 0)
+  float part = 0.f;
+  if (c < d.KX) {
 #pragma unroll 4
-    for (; w.r < d.N; w.next()) d_enc_x[(size_t)w.r * d.KX + w.c] = d_h_in[(size_t)w.r * K + w.c];
-  }
-  // The launcher picks a grid whose stride is a multiple of KA and KE: every thread stays on ONE column of the audio
-  // and of the eye block, the column sums of d_enc_a / d_enc_e are register partials, combined per workgroup in a
-  // fixed order (LDS float atomics are slow on gfx950) and added to the result with one global atomic per column.
-  float pa = 0.f, pe = 0.f;
-  int ca, ce;
-  {
-    Walk w(i0, stride, d.KA);
-    ca = w.c;
+    for (; w.r < d.N; w.next()) d_enc_x[(size_t)w.r * d.KX + c] = d_h_in[(size_t)w.r * K + c];
+  } else if (c < d.KX + d.KA) {
+    const int k = c - d.KX;
+    const float ea = enc_a[k];
 #pragma unroll 4
     for (; w.r < d.N; w.next()) {
-      const int r = w.r, k = w.c;
-      const float a = aud[(size_t)r * d.KA + k], gw = d_h_in[(size_t)r * K + d.KX + k];
+      const int r = w.r;
+      const float a = aud[(size_t)r * d.KA + k], gw = d_h_in[(size_t)r * K + c];
       const float na = amb[3 * r];
       const float ga = (d_amb && na > 0.f) ? d_amb[3 * r] / na : 0.f;
-      d_aud[(size_t)r * d.KA + k] = enc_a[k] * gw + ga * a;
-      pa += gw * a;
+      d_aud[(size_t)r * d.KA + k] = ea * gw + ga * a;
+      part += gw * a;
     }
-  }
-  {
-    Walk w(i0, stride, d.KE);
-    ce = w.c;
+  } else {
+    const int k = c - d.KX - d.KA;
+    const float ee = enc_e[k];
 #pragma unroll 4
     for (; w.r < d.N; w.next()) {
-      const int r = w.r, k = w.c;
-      const float pre = eye_pre[(size_t)r * d.KE + k], gw = d_h_in[(size_t)r * K + d.KX + d.KA + k];
+      const int r = w.r;
+      const float pre = eye_pre[(size_t)r * d.KE + k], gw = d_h_in[(size_t)r * K + c];
       const float act = fmaxf(pre, 0.f);
       const float ne = amb[3 * r + 1];
       const float ge = (d_amb && ne > 0.f) ? d_amb[3 * r + 1] / ne : 0.f;
-      d_eye_pre[(size_t)r * d.KE + k] = pre > 0.f ? (enc_e[k] * gw + ge * act) : 0.f;
-      pe += gw * act;
+      d_eye_pre[(size_t)r * d.KE + k] = pre > 0.f ? (ee * gw + ge * act) : 0.f;
+      part += gw * act;
     }
   }
-  // column sums: thread t of the workgroup owns column (i0 % KA) resp. (i0 % KE); thread 0..KA-1 / 0..KE-1 gathers
-  s_part[wave][lane] = pa;
+  // threads t, t + K, t + 2K, ... of the workgroup share a column
+  s_part[threadIdx.x] = part;
   __syncthreads();
-  if ((int)threadIdx.x < d.KA) {
-    // threads whose audio column equals this one: t with (blockIdx*GB + t) % KA == column of thread threadIdx.x
+  if ((int)threadIdx.x < K && c >= d.KX) {
     float sum = 0.f;
-    for (int t = threadIdx.x; t < GB; t += d.KA) sum += s_part[t >> 6][t & 63];
-    atomicAdd(&d_enc_a[ca], sum);
-  }
-  __syncthreads();
-  s_part[wave][lane] = pe;
-  __syncthreads();
-  if ((int)threadIdx.x < d.KE) {
-    float sum = 0.f;
-    for (int t = threadIdx.x; t < GB; t += d.KE) sum += s_part[t >> 6][t & 63];
-    atomicAdd(&d_enc_e[ce], sum);
+    for (int t = threadIdx.x; t < GB; t += K) sum += s_part[t];
+    if (c < d.KX + d.KA) atomicAdd(&d_enc_a[c - d.KX], sum);
+    else atomicAdd(&d_enc_e[c - d.KX - d.KA], sum);
   }
 }
 
@@ -307,10 +298,10 @@ int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const f
   INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1, "motion_glue: widths out of range");
   if (N == 0) return INSTAG_OK;
   const GlueDims d{N, KX, KA, KE};
-  // the in-kernel column sums need every thread to stay on one column: grid stride a multiple of KA and of KE
+  // every thread must stay on one column of the [N, K] gradient: grid stride a multiple of K
   auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
-  const int ga = KA / gcd(KA, GB), ge = KE / gcd(KE, GB);
-  const int unit = ga / gcd(ga, ge) * ge;
+  const int K = KX + KA + KE;
+  const int unit = K / gcd(K, GB);
   const int blocks = std::max(unit, row_blocks(N * 8) / unit * unit);
   motion_glue_backward_kernel<<<blocks, GB, 0, (hipStream_t)stream>>>(
       d, d_h_in, d_amb, aud, eye_pre, enc_a, enc_e, amb, d_enc_x, d_aud, d_eye_pre, d_enc_a, d_enc_e);

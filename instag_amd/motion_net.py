@@ -189,16 +189,15 @@ class _TriPlaneField(nn.Module):
         return self.encode_audio(a), (self.encode_exp(e) if want_e else None)
 
     def start_audio(self, a, stream_index=0, e=None):
-        """Launch the per-frame branch now, on a side stream; the next forward(x, a, e) with the same `a` picks it
-        up.  Lets the caller overlap the frame branches of several networks with earlier per-Gaussian work."""
+        """Mark the point of the step from which the per-frame branch may run: the next forward(x, a, e) with the
+        same `a` launches it on side stream `stream_index` behind an event recorded HERE, so on the device it
+        overlaps everything the caller enqueues in between, while in the autograd graph it is created late
+        (right before the glue that consumes it) and its backward is therefore scheduled early."""
         if not (a.is_cuda and CONCURRENT_AUDIO):
             return
-        main_stream = torch.cuda.current_stream(a.device)
-        side = _side_stream(a.device, stream_index)
-        side.wait_stream(main_stream)
-        with torch.cuda.stream(side):
-            enc_a, enc_e = self.encode_frame(a, e)
-        self._audio_pending = (a, e, enc_a, enc_e, side)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(a.device))
+        self._audio_pending = (a, e, ev, _side_stream(a.device, stream_index))
 
     def _trunk(self, x, a, e, c, enc_x=None):
         """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim], amb3); amb3 = the [N,3] tensor
@@ -206,31 +205,30 @@ class _TriPlaneField(nn.Module):
         on the module: a live autograd graph across steps breaks stream capture.)"""
         fork = x.is_cuda and CONCURRENT_AUDIO
         pending = self.__dict__.pop("_audio_pending", None)
+        if enc_x is None:
+            enc_x = self.encode_x(x, bound=self.bound)
+        aud_ch_att = self.aud_ch_att_net(enc_x)
+        eye_pre = self.eye_att_net(enc_x) if self.exp_eye else None
         if fork:
-            # the per-frame branch only meets the per-Gaussian branch at the glue: it runs on a second stream
-            # so it overlaps the tri-plane encode and the attention MLPs
+            # the per-frame branch only meets the per-Gaussian branch at the glue: it runs on a second stream,
+            # gated by the early event when the caller announced the frame with start_audio()
             main_stream = torch.cuda.current_stream(x.device)
             if pending is not None and pending[0] is a and pending[1] is e:
-                enc_a, enc_e, side = pending[2], pending[3], pending[4]      # started early by start_audio()
+                side = pending[3]
+                side.wait_event(pending[2])
             else:
                 side = _side_stream(x.device)
                 side.wait_stream(main_stream)
-                with torch.cuda.stream(side):
-                    enc_a, enc_e = self.encode_frame(a, e)
-        if enc_x is None:
-            enc_x = self.encode_x(x, bound=self.bound)
-        if fork:
-            aud_ch_att = self.aud_ch_att_net(enc_x)
+            with torch.cuda.stream(side):
+                enc_a, enc_e = self.encode_frame(a, e)
             main_stream.wait_stream(side)
             enc_a.record_stream(main_stream)
             if enc_e is not None:
                 enc_e.record_stream(main_stream)
         else:
             enc_a, enc_e = self.encode_frame(a, e)
-            aud_ch_att = self.aud_ch_att_net(enc_x)
         if self.exp_eye and c is None and enc_x.is_cuda:
             from . import glue as _glue
-            eye_pre = self.eye_att_net(enc_x)
             if _glue.motion_glue_supported(enc_x, aud_ch_att, eye_pre):
                 # repeat / mul / relu / cat / norm chain as one HIP kernel per pass (instag_amd/glue.py)
                 h_in, amb = _glue.motion_glue(enc_x, aud_ch_att, eye_pre, enc_a, enc_e)
@@ -238,7 +236,7 @@ class _TriPlaneField(nn.Module):
         parts = [enc_x, enc_a.repeat(enc_x.shape[0], 1) * aud_ch_att]
         eye_att = None
         if self.exp_eye:
-            eye_att = torch.relu(self.eye_att_net(enc_x))
+            eye_att = torch.relu(eye_pre)
             parts.append(enc_e * eye_att)
         if c is not None:
             parts.append(c.repeat(enc_x.shape[0], 1))
