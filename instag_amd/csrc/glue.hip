@@ -40,17 +40,23 @@ motion_glue_forward_kernel(GlueDims d, const float* __restrict__ enc_x, const fl
                            const float* __restrict__ enc_e, float* __restrict__ h_in, float* __restrict__ amb) {
   const int K = d.KX + d.KA + d.KE;
   const size_t stride = (size_t)gridDim.x * GB, i0 = (size_t)blockIdx.x * GB + threadIdx.x;
-  // element-parallel part: coalesced write of h_in
+  // element-parallel part: coalesced write of h_in, U rows in flight per thread.  The launcher makes the grid stride
+  // a multiple of K: the thread's column (and therefore its source) is fixed, rows advance by w.qr.
   {
     Walk w(i0, stride, K);
-#pragma unroll 4
-    for (; w.r < d.N; w.next()) {
-      const int r = w.r, c = w.c;
-      float v;
-      if (c < d.KX) v = enc_x[(size_t)r * d.KX + c];
-      else if (c < d.KX + d.KA) v = enc_a[c - d.KX] * aud[(size_t)r * d.KA + (c - d.KX)];
-      else v = enc_e[c - d.KX - d.KA] * fmaxf(eye_pre[(size_t)r * d.KE + (c - d.KX - d.KA)], 0.f);
-      h_in[(size_t)r * K + c] = v;
+    const int c = w.c, dr = w.qr;
+    constexpr int U = 4;
+    const float* src; int ks; float mul = 1.f; bool relu = false;
+    if (c < d.KX) { src = enc_x + c; ks = d.KX; }
+    else if (c < d.KX + d.KA) { src = aud + (c - d.KX); ks = d.KA; mul = enc_a[c - d.KX]; }
+    else { src = eye_pre + (c - d.KX - d.KA); ks = d.KE; mul = enc_e[c - d.KX - d.KA]; relu = true; }
+    for (int r = w.r; r < d.N; r += U * dr) {
+      float v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) v[j] = src[(size_t)min(r + j * dr, d.N - 1) * ks];
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+        if (r + j * dr < d.N) h_in[(size_t)(r + j * dr) * K + c] = mul * (relu ? fmaxf(v[j], 0.f) : v[j]);
     }
   }
   // row-parallel part: the two norms
@@ -80,35 +86,59 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
   const int K = d.KX + d.KA + d.KE;
   const size_t stride = (size_t)gridDim.x * GB, i0 = (size_t)blockIdx.x * GB + threadIdx.x;
   Walk w(i0, stride, K);
-  const int c = w.c;                       // constant along the walk (stride % K == 0)
+  const int c = w.c;                       // constant along the walk (stride % K == 0, so rows advance by w.qr)
+  const int dr = w.qr;
+  constexpr int U = 4;                     // rows in flight per thread (one load per row would be latency-bound)
   float part = 0.f;
   if (c < d.KX) {
-#pragma unroll 4
-    for (; w.r < d.N; w.next()) d_enc_x[(size_t)w.r * d.KX + c] = d_h_in[(size_t)w.r * K + c];
+    for (int r = w.r; r < d.N; r += U * dr) {
+      float v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) v[j] = (r + j * dr < d.N) ? d_h_in[(size_t)(r + j * dr) * K + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < U; ++j)
+        if (r + j * dr < d.N) d_enc_x[(size_t)(r + j * dr) * d.KX + c] = v[j];
+    }
   } else if (c < d.KX + d.KA) {
     const int k = c - d.KX;
     const float ea = enc_a[k];
-#pragma unroll 4
-    for (; w.r < d.N; w.next()) {
-      const int r = w.r;
-      const float a = aud[(size_t)r * d.KA + k], gw = d_h_in[(size_t)r * K + c];
-      const float na = amb[3 * r];
-      const float ga = (d_amb && na > 0.f) ? d_amb[3 * r] / na : 0.f;
-      d_aud[(size_t)r * d.KA + k] = ea * gw + ga * a;
-      part += gw * a;
+    for (int r = w.r; r < d.N; r += U * dr) {
+      float a[U], gw[U], na[U], da[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int rr = min(r + j * dr, d.N - 1);
+        a[j] = aud[(size_t)rr * d.KA + k]; gw[j] = d_h_in[(size_t)rr * K + c];
+        na[j] = amb[3 * rr]; da[j] = d_amb ? d_amb[3 * rr] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        if (r + j * dr < d.N) {
+          const float ga = na[j] > 0.f ? da[j] / na[j] : 0.f;
+          d_aud[(size_t)(r + j * dr) * d.KA + k] = ea * gw[j] + ga * a[j];
+          part += gw[j] * a[j];
+        }
+      }
     }
   } else {
     const int k = c - d.KX - d.KA;
     const float ee = enc_e[k];
-#pragma unroll 4
-    for (; w.r < d.N; w.next()) {
-      const int r = w.r;
-      const float pre = eye_pre[(size_t)r * d.KE + k], gw = d_h_in[(size_t)r * K + c];
-      const float act = fmaxf(pre, 0.f);
-      const float ne = amb[3 * r + 1];
-      const float ge = (d_amb && ne > 0.f) ? d_amb[3 * r + 1] / ne : 0.f;
-      d_eye_pre[(size_t)r * d.KE + k] = pre > 0.f ? (ee * gw + ge * act) : 0.f;
-      part += gw * act;
+    for (int r = w.r; r < d.N; r += U * dr) {
+      float pre[U], gw[U], ne[U], de[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int rr = min(r + j * dr, d.N - 1);
+        pre[j] = eye_pre[(size_t)rr * d.KE + k]; gw[j] = d_h_in[(size_t)rr * K + c];
+        ne[j] = amb[3 * rr + 1]; de[j] = d_amb ? d_amb[3 * rr + 1] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        if (r + j * dr < d.N) {
+          const float act = fmaxf(pre[j], 0.f);
+          const float ge = ne[j] > 0.f ? de[j] / ne[j] : 0.f;
+          d_eye_pre[(size_t)(r + j * dr) * d.KE + k] = pre[j] > 0.f ? (ee * gw[j] + ge * act) : 0.f;
+          part += gw[j] * act;
+        }
+      }
     }
   }
   // threads t, t + K, t + 2K, ... of the workgroup share a column
@@ -283,8 +313,12 @@ int instag_motion_glue_forward(const float* enc_x, const float* aud, const float
   INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1, "motion_glue: widths out of range");
   if (N == 0) return INSTAG_OK;
   const GlueDims d{N, KX, KA, KE};
-  motion_glue_forward_kernel<<<row_blocks(N * 8), GB, 0, (hipStream_t)stream>>>(d, enc_x, aud, eye_pre, enc_a, enc_e,
-                                                                                h_in, amb);
+  // every thread stays on one column of h_in: grid stride a multiple of K
+  auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+  const int K = KX + KA + KE;
+  const int unit = K / gcd(K, GB);
+  const int blocks = std::max(unit, row_blocks(N * 8) / unit * unit);
+  motion_glue_forward_kernel<<<blocks, GB, 0, (hipStream_t)stream>>>(d, enc_x, aud, eye_pre, enc_a, enc_e, h_in, amb);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
