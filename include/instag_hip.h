@@ -216,12 +216,24 @@ size_t instag_linear_weight_grad_workspace_bytes(int32_t N, int32_t O, int32_t K
 int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void* workspace,
                               size_t workspace_bytes, int32_t N, int32_t O, int32_t K,
                               instag_stream_t stream);
+/* Several weight gradients in one launch (all with the same N): workspace = sum over jobs of
+ * instag_linear_weight_grad_workspace_bytes rounded up to 256 B.  At most 16 jobs. */
+typedef struct {
+  const float* dz; /* [N,O] */
+  const float* in; /* [N,K] */
+  float* dw;       /* [O,K] (written) */
+  int32_t N, O, K;
+} instag_wgrad_job;
+int instag_linear_weight_grad_batched(const instag_wgrad_job* jobs, int32_t n_jobs, void* workspace,
+                                      size_t workspace_bytes, instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused per-Gaussian glue (csrc/glue.hip).
  *  motion_glue  (scene/motion_net.py:291-306, :679-692): h_in [N,KX+KA+KE] = cat(enc_x, enc_a*aud, enc_e*relu(eye_pre)),
- *               amb [N,3] = (||aud||, ||relu(eye_pre)||, 0); backward returns d_enc_x, d_aud, d_eye_pre and accumulates
- *               d_enc_a [KA], d_enc_e [KE] (zero-filled by the caller).  KA <= 32, KE <= 8.
+ *               amb [N,3] = (||aud||, ||relu(eye_pre)||, 0); backward returns d_enc_x, d_aud, d_eye_pre and
+ *               col_partials [instag_motion_glue_backward_num_partials][KA+KE]: per-workgroup partial sums of
+ *               (d_enc_a | d_enc_e), to be summed over rows by the caller in a fixed order.  KA <= 32, KE <= 8,
+ *               KX+KA+KE <= 256.
  *  deform_activate (gaussian_renderer/__init__.py:200-235, personalized=False, align=True): h [N,11] = UMF head output,
  *               p [N,6] = PMF align head output -> means3D, scales, rotations, opacity.
  *  motion_l1_reg (train_face.py:510-514): mean|h[:, :3]*1e-2| + mean|h[:,3:7]| + mean|h[:,7:8]| + mean|h[:,8:11]| +
@@ -230,9 +242,10 @@ int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void*
 int instag_motion_glue_forward(const float* enc_x, const float* aud, const float* eye_pre, const float* enc_a,
                                const float* enc_e, float* h_in, float* amb, int32_t N, int32_t KX, int32_t KA,
                                int32_t KE, instag_stream_t stream);
+int instag_motion_glue_backward_num_partials(int32_t N, int32_t KX, int32_t KA, int32_t KE);
 int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const float* aud, const float* eye_pre,
                                 const float* enc_a, const float* enc_e, const float* amb, float* d_enc_x,
-                                float* d_aud, float* d_eye_pre, float* d_enc_a, float* d_enc_e, int32_t N,
+                                float* d_aud, float* d_eye_pre, float* col_partials, int32_t N,
                                 int32_t KX, int32_t KA, int32_t KE, instag_stream_t stream);
 int instag_deform_activate_forward(const float* xyz, const float* scaling, const float* rotation,
                                    const float* opacity, const float* h, const float* p, float* means3D,

@@ -29,6 +29,11 @@ class FaceLossCfg(C.Structure):
                 ("w_attn_hair", f32), ("w_attn_lips", f32), ("w_extra", f32)]
 
 
+class WgradJob(C.Structure):
+    """struct instag_wgrad_job (include/instag_hip.h)."""
+    _fields_ = [("dz", vp), ("inp", vp), ("dw", vp), ("N", i32), ("O", i32), ("K", i32)]
+
+
 class RasterArgs(C.Structure):
     """struct instag_raster_args (include/instag_hip.h)."""
     _fields_ = [
@@ -74,10 +79,12 @@ _PROTOS = {
                                              vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "instag_mlp_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "instag_linear_weight_grad_batched": (C.c_int, [vp, i32, vp, sz, vp]),
     "instag_linear_weight_grad_workspace_bytes": (sz, [i32, i32, i32]),
     "instag_linear_weight_grad": (C.c_int, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "instag_motion_glue_forward": (C.c_int, [vp] * 7 + [i32] * 4 + [vp]),
-    "instag_motion_glue_backward": (C.c_int, [vp] * 12 + [i32] * 4 + [vp]),
+    "instag_motion_glue_backward_num_partials": (C.c_int, [i32, i32, i32, i32]),
+    "instag_motion_glue_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "instag_deform_activate_forward": (C.c_int, [vp] * 10 + [i32, vp]),
     "instag_deform_activate_backward": (C.c_int, [vp] * 15 + [i32, vp]),
     "instag_motion_l1_reg_num_partials": (C.c_int, [i32]),

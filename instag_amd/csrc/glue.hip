@@ -75,13 +75,13 @@ motion_glue_forward_kernel(GlueDims d, const float* __restrict__ enc_x, const fl
 // (enc_x block), scales by enc_a and adds the norm term (audio block) or does the same through the ReLU (eye block).
 // The launcher picks a grid whose stride is a multiple of K = KX+KA+KE, so a thread stays on ONE column: the column
 // sums d_enc_a / d_enc_e are register partials, combined per workgroup in a fixed order (LDS float atomics are slow
-// on gfx950) and added to the result with one global atomic per column and workgroup.
+// on gfx950) and written as one row of per-workgroup partial sums (no global atomics: bitwise reproducible).
 __global__ void __launch_bounds__(GB)
 motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const float* __restrict__ d_amb,
                             const float* __restrict__ aud, const float* __restrict__ eye_pre,
                             const float* __restrict__ enc_a, const float* __restrict__ enc_e,
                             const float* __restrict__ amb, float* __restrict__ d_enc_x, float* __restrict__ d_aud,
-                            float* __restrict__ d_eye_pre, float* __restrict__ d_enc_a, float* __restrict__ d_enc_e) {
+                            float* __restrict__ d_eye_pre, float* __restrict__ col_partials) {
   __shared__ float s_part[GB];
   const int K = d.KX + d.KA + d.KE;
   const size_t stride = (size_t)gridDim.x * GB, i0 = (size_t)blockIdx.x * GB + threadIdx.x;
@@ -147,8 +147,8 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
   if ((int)threadIdx.x < K && c >= d.KX) {
     float sum = 0.f;
     for (int t = threadIdx.x; t < GB; t += K) sum += s_part[t];
-    if (c < d.KX + d.KA) atomicAdd(&d_enc_a[c - d.KX], sum);
-    else atomicAdd(&d_enc_e[c - d.KX - d.KA], sum);
+    // per-workgroup partial sums [gridDim.x][KA + KE]; the caller adds them up in a fixed order (deterministic)
+    col_partials[(size_t)blockIdx.x * (d.KA + d.KE) + (c - d.KX)] = sum;
   }
 }
 
@@ -323,22 +323,31 @@ int instag_motion_glue_forward(const float* enc_x, const float* aud, const float
   return INSTAG_OK;
 }
 
-int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const float* aud, const float* eye_pre,
-                                const float* enc_a, const float* enc_e, const float* amb, float* d_enc_x,
-                                float* d_aud, float* d_eye_pre, float* d_enc_a, float* d_enc_e, int32_t N,
-                                int32_t KX, int32_t KA, int32_t KE, instag_stream_t stream) {
-  INSTAG_REQUIRE(d_h_in && aud && eye_pre && enc_a && enc_e && amb && d_enc_x && d_aud && d_eye_pre && d_enc_a && d_enc_e,
-                 "motion_glue_backward: NULL tensor");
-  INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1, "motion_glue: widths out of range");
-  if (N == 0) return INSTAG_OK;
-  const GlueDims d{N, KX, KA, KE};
-  // every thread must stay on one column of the [N, K] gradient: grid stride a multiple of K
+static int glue_bwd_blocks(int N, int KX, int KA, int KE) {
+  // every thread must stay on one column of the [N, K] gradient: grid stride a multiple of K; a workgroup must
+  // cover every column (GB >= K) so that each row of the partial sums is fully written
   auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
   const int K = KX + KA + KE;
   const int unit = K / gcd(K, GB);
-  const int blocks = std::max(unit, row_blocks(N * 8) / unit * unit);
-  motion_glue_backward_kernel<<<blocks, GB, 0, (hipStream_t)stream>>>(
-      d, d_h_in, d_amb, aud, eye_pre, enc_a, enc_e, amb, d_enc_x, d_aud, d_eye_pre, d_enc_a, d_enc_e);
+  return std::max(unit, row_blocks(N * 8) / unit * unit);
+}
+
+int instag_motion_glue_backward_num_partials(int32_t N, int32_t KX, int32_t KA, int32_t KE) {
+  return glue_bwd_blocks(N, KX, KA, KE);
+}
+
+int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const float* aud, const float* eye_pre,
+                                const float* enc_a, const float* enc_e, const float* amb, float* d_enc_x,
+                                float* d_aud, float* d_eye_pre, float* col_partials, int32_t N,
+                                int32_t KX, int32_t KA, int32_t KE, instag_stream_t stream) {
+  INSTAG_REQUIRE(d_h_in && aud && eye_pre && enc_a && enc_e && amb && d_enc_x && d_aud && d_eye_pre && col_partials,
+                 "motion_glue_backward: NULL tensor");
+  INSTAG_REQUIRE(KA >= 1 && KA <= 32 && KE >= 1 && KE <= 8 && KX >= 1 && KX + KA + KE <= GB,
+                 "motion_glue: widths out of range");
+  if (N == 0) return INSTAG_OK;
+  const GlueDims d{N, KX, KA, KE};
+  motion_glue_backward_kernel<<<glue_bwd_blocks(N, KX, KA, KE), GB, 0, (hipStream_t)stream>>>(
+      d, d_h_in, d_amb, aud, eye_pre, enc_a, enc_e, amb, d_enc_x, d_aud, d_eye_pre, col_partials);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

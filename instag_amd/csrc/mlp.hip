@@ -270,14 +270,13 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
 
 // ---- dW[o][k] = sum_rows dZ[row][o] * In[row][k] ---------------------------------------------------
 template <int OB, int KB>
-__global__ void __launch_bounds__(MLP_BLOCK)
-weight_grad_kernel(const float* __restrict__ dZ, const float* __restrict__ In, int N, int O, int K,
-                   float* __restrict__ partial) {
-  __shared__ float s_acc[OB * KB * 1024];
+__device__ __forceinline__ void weight_grad_body(const float* __restrict__ dZ, const float* __restrict__ In, int N, int O,
+                                                 int K, float* __restrict__ partial, float* s_acc, int block,
+                                                 int nblocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
-  const int nwaves = gridDim.x * 4;
+  const int nwaves = nblocks * 4;
   const int per_wave = (((N + nwaves - 1) / nwaves) + 1) & ~1;       // even number of rows per wave
-  const int gw = blockIdx.x * 4 + wave;
+  const int gw = block * 4 + wave;
   const long w0 = (long)gw * per_wave;
   const long w1 = min((long)N, w0 + per_wave);
   f32x16 acc[OB][KB];
@@ -328,13 +327,61 @@ weight_grad_kernel(const float* __restrict__ dZ, const float* __restrict__ In, i
     __syncthreads();
   }
   // partial[block][o][k] for o < O, k < K
-  float* dst = partial + (size_t)blockIdx.x * O * K;
+  float* dst = partial + (size_t)block * O * K;
   for (int idx = threadIdx.x; idx < OB * KB * 1024; idx += MLP_BLOCK) {
     const int ln = idx & 63, i = (idx >> 6) & 15, tb = idx >> 10;
     const int t = tb / KB, b = tb - t * KB;
     const int o = 32 * t + feat(i, ln >> 5), k = 32 * b + (ln & 31);
     if (o < O && k < K) dst[o * K + k] = s_acc[idx];
   }
+}
+
+template <int OB, int KB>
+__global__ void __launch_bounds__(MLP_BLOCK)
+weight_grad_kernel(const float* __restrict__ dZ, const float* __restrict__ In, int N, int O, int K,
+                   float* __restrict__ partial) {
+  __shared__ float s_acc[OB * KB * 1024];
+  weight_grad_body<OB, KB>(dZ, In, N, O, K, partial, s_acc, blockIdx.x, gridDim.x);
+}
+
+// Several weight-gradient GEMMs in ONE launch (blockIdx.y = job): a train step has nine of them (three MLPs of the
+// universal field, one of the personalised field), each too small to fill the chip on its own and none needed before
+// the optimizer runs.
+constexpr int WG_MAX_JOBS = 16;
+struct WgJob { const float* dz; const float* in; float* partial; float* dw; int N, O, K, pad; };
+struct WgBatch { WgJob j[WG_MAX_JOBS]; };
+
+__global__ void __launch_bounds__(MLP_BLOCK)
+weight_grad_batched_kernel(WgBatch b) {
+  __shared__ float s_acc[2 * 3 * 1024];
+  const WgJob job = b.j[blockIdx.y];
+  const int ob = (job.O + 31) / 32, kb = (job.K + 31) / 32;
+  if (ob == 1 && kb == 1) weight_grad_body<1, 1>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
+  else if (ob == 1 && kb == 2) weight_grad_body<1, 2>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
+  else if (ob == 1 && kb == 3) weight_grad_body<1, 3>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
+  else if (ob == 2 && kb == 1) weight_grad_body<2, 1>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
+  else if (ob == 2 && kb == 2) weight_grad_body<2, 2>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
+  else weight_grad_body<2, 3>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
+}
+
+__global__ void __launch_bounds__(256)
+weight_grad_reduce_batched_kernel(WgBatch b, int nparts) {
+  __shared__ float s_part[4][64];
+  const WgJob job = b.j[blockIdx.y];
+  const int count = job.O * job.K;
+  if ((int)blockIdx.x * 64 >= count) return;
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
+  float s = 0.f;
+  if (i < count) {
+    const int per = (nparts + 3) / 4;
+    const int p0 = g * per, p1 = min(nparts, p0 + per);
+#pragma unroll 8
+    for (int p = p0; p < p1; ++p) s += job.partial[(size_t)p * count + i];
+  }
+  s_part[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < count) job.dw[i] = ((s_part[0][e] + s_part[1][e]) + s_part[2][e]) + s_part[3][e];
 }
 
 // dW[i] = sum_p partial[p][i]: 64 elements x 4 partial-groups per workgroup, fixed summation order
@@ -498,6 +545,35 @@ int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void*
   if (ob == 2 && kb == 1) return run_wg<2, 1>(dz, in, N, O, K, part, dw, s);
   if (ob == 2 && kb == 2) return run_wg<2, 2>(dz, in, N, O, K, part, dw, s);
   return run_wg<2, 3>(dz, in, N, O, K, part, dw, s);
+}
+
+int instag_linear_weight_grad_batched(const instag_wgrad_job* jobs, int32_t n_jobs, void* workspace,
+                                      size_t workspace_bytes, instag_stream_t stream) {
+  INSTAG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= WG_MAX_JOBS, "linear_weight_grad_batched: 1..16 jobs");
+  WgBatch b;
+  size_t off = 0;
+  int N0 = jobs[0].N, max_count = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const instag_wgrad_job& q = jobs[i];
+    INSTAG_REQUIRE(q.dz && q.in && q.dw, "linear_weight_grad_batched: NULL tensor");
+    INSTAG_REQUIRE(q.O >= 1 && q.O <= 64 && q.K >= 1 && q.K <= 96, "linear_weight_grad: need O <= 64 and K <= 96");
+    INSTAG_REQUIRE(q.N == N0 && q.N >= 1, "linear_weight_grad_batched: all jobs must have the same N >= 1");
+    b.j[i] = WgJob{q.dz, q.in, (float*)((char*)workspace + off), q.dw, q.N, q.O, q.K, 0};
+    off += (instag_linear_weight_grad_workspace_bytes(q.N, q.O, q.K) + 255) / 256 * 256;
+    max_count = std::max(max_count, q.O * q.K);
+  }
+  if (workspace == nullptr || workspace_bytes < off) {
+    set_error("linear_weight_grad_batched: workspace too small");
+    return INSTAG_E_SPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = wg_blocks(N0);
+  ProfScope p(K_MLP_WGRAD, s);
+  weight_grad_batched_kernel<<<dim3(blocks, n_jobs), MLP_BLOCK, 0, s>>>(b);
+  INSTAG_CHECK_LAUNCH();
+  weight_grad_reduce_batched_kernel<<<dim3((max_count + 63) / 64, n_jobs), 256, 0, s>>>(b, blocks);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,78 @@
+"""Weight gradients of the fused MLPs, collected during ``loss.backward()`` and computed afterwards in ONE launch.
+
+Only the optimizer reads a weight gradient; the rest of the backward pass needs the input gradient.  A train step has
+nine such GEMMs (three MLPs of the universal field, one of the personalised field), each too small to fill the chip.
+
+    with deferred_grads(device):
+        loss.backward()            # instag_amd.mlp queues (dZ, input, weight) instead of launching
+    # on exit: one instag_linear_weight_grad_batched call on the current stream, results accumulated into weight.grad
+
+Autograd receives ``None`` for those weights (it would otherwise copy or add a still-unwritten buffer), so the block
+itself performs ``w.grad = dw`` / ``w.grad += dw``.  Outside a block nothing is queued and gradients flow through
+autograd as usual.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+_STATE = {"active": False, "jobs": []}
+MAX_JOBS = 16
+
+
+def active() -> bool:
+    return _STATE["active"]
+
+
+def defer_weight_grad(dz, inp, weight):
+    """Queue dW = dz^T @ inp for the leaf parameter ``weight`` ([O,K]); dz [N,O], inp [N,K] contiguous fp32."""
+    _STATE["jobs"].append((dz, inp, weight))
+
+
+def _flush(jobs):
+    L = _lib.lib()
+    by_n = {}
+    for job in jobs:
+        by_n.setdefault((job[0].device, job[0].shape[0]), []).append(job)
+    for (dev, N), group in by_n.items():
+        for start in range(0, len(group), MAX_JOBS):
+            chunk = group[start:start + MAX_JOBS]
+            arr = (_lib.WgradJob * len(chunk))()
+            dws, total = [], 0
+            for i, (dz, inp, w) in enumerate(chunk):
+                O, K = dz.shape[1], inp.shape[1]
+                dw = torch.empty(O, K, dtype=torch.float32, device=dev)
+                dws.append(dw)
+                arr[i] = _lib.WgradJob(dz.data_ptr(), inp.data_ptr(), dw.data_ptr(), N, O, K)
+                total += (L.instag_linear_weight_grad_workspace_bytes(N, O, K) + 255) // 256 * 256
+            ws = torch.empty(total, dtype=torch.uint8, device=dev)
+            check(L.instag_linear_weight_grad_batched(arr, len(chunk), ptr(ws), total, _lib.current_stream()),
+                  "linear_weight_grad_batched")
+            for (dz, inp, w), dw in zip(chunk, dws):
+                dw = dw.reshape(w.shape).to(w.dtype)
+                w.grad = dw if w.grad is None else w.grad.add_(dw)
+
+
+class deferred_grads:
+    def __init__(self, device):
+        self.device = None if device is None else torch.device(device)
+        self.on = self.device is not None and self.device.type == "cuda"
+
+    def __enter__(self):
+        self.prev = _STATE["active"]
+        if self.on:
+            _STATE["active"] = True
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _STATE["active"] = self.prev
+        if not self.on or self.prev:
+            return False
+        jobs, _STATE["jobs"] = _STATE["jobs"], []
+        if exc_type is None and jobs:
+            _flush(jobs)
+        return False

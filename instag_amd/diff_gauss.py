@@ -242,29 +242,32 @@ class _RasterizeGaussians(torch.autograd.Function):
         want = dict(means3D=need[0], means2D=need[1], shs=need[2], colors=need[3], opacities=need[4],
                     scales=need[5], rotations=need[6], cov3D=need[7], extra=need[8])
         d_aux = m2d_aux = None
-        side = None
-        if st.aux is not None and g_aux is not None and (need[10] or need[1]):
-            # the aux image only shares the forward state with the main images: its backward runs beside theirs
-            dev = st.geom.device
-            main = torch.cuda.current_stream(dev)
-            key = (dev.type, dev.index)
-            side = _AUX_STREAMS.get(key)
-            if side is None:
-                side = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                d_aux, m2d_aux = rasterize_aux_backward(st, g_aux, need[10], need[1])
-            for t in (g_aux, d_aux, m2d_aux):
-                if t is not None:
-                    t.record_stream(side)
+        aux_needed = st.aux is not None and g_aux is not None and (need[10] or need[1])
+        dev = st.geom.device
+        if aux_needed:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
         main_grads = any(g is not None for g in (g_color, g_depth, g_normal, g_alpha, g_extra))
         if main_grads:
             g = rasterize_backward(st, g_color, g_depth, g_normal, g_alpha, g_extra, want)
         else:
             g = dict(means3D=None, means2D=None, shs=None, colors=None, opacities=None, scales=None, rotations=None,
                      cov3D=None, extra=None)
-        if side is not None:
-            torch.cuda.current_stream(st.geom.device).wait_stream(side)
+        if aux_needed:
+            # the aux image only shares the forward state with the main images: its backward runs beside theirs,
+            # enqueued AFTER the main one so that in a captured step the main chain keeps its graph branch
+            main = torch.cuda.current_stream(dev)
+            key = (dev.type, dev.index)
+            side = _AUX_STREAMS.get(key)
+            if side is None:
+                side = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                d_aux, m2d_aux = rasterize_aux_backward(st, g_aux, need[10], need[1])
+            for t in (g_aux, d_aux, m2d_aux):
+                if t is not None:
+                    t.record_stream(side)
+            main.wait_stream(side)
             if m2d_aux is not None:
                 g["means2D"] = m2d_aux if g["means2D"] is None else g["means2D"].add_(m2d_aux)
         op_shape, ex_shape = ctx.shapes

@@ -46,11 +46,13 @@ class _MotionGlue(torch.autograd.Function):
         d_enc_x = torch.empty(N, KX, dtype=torch.float32, device=dev)
         d_aud = torch.empty(N, KA, dtype=torch.float32, device=dev)
         d_eye = torch.empty(N, KE, dtype=torch.float32, device=dev)
-        d_vec = torch.zeros(KA + KE, dtype=torch.float32, device=dev)
+        parts = torch.empty(L.instag_motion_glue_backward_num_partials(N, KX, KA, KE), KA + KE,
+                            dtype=torch.float32, device=dev)
         check(L.instag_motion_glue_backward(ptr(d_h_in), ptr(d_amb), ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e),
-                                            ptr(amb), ptr(d_enc_x), ptr(d_aud), ptr(d_eye), ptr(d_vec[:KA]),
-                                            ptr(d_vec[KA:]), N, KX, KA, KE, _lib.current_stream()),
+                                            ptr(amb), ptr(d_enc_x), ptr(d_aud), ptr(d_eye), ptr(parts),
+                                            N, KX, KA, KE, _lib.current_stream()),
               "motion_glue_backward")
+        d_vec = parts.sum(dim=0)          # fixed-order column sums of the per-workgroup partials
         return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:]
 
 
@@ -60,7 +62,8 @@ def motion_glue(enc_x, aud, eye_pre, enc_a, enc_e):
 
 
 def motion_glue_supported(enc_x, aud, eye_pre) -> bool:
-    return enc_x.is_cuda and aud.shape[1] <= 32 and eye_pre.shape[1] <= 8
+    return (enc_x.is_cuda and aud.shape[1] <= 32 and eye_pre.shape[1] <= 8
+            and enc_x.shape[1] + aud.shape[1] + eye_pre.shape[1] <= 256)
 
 
 class _DeformActivate(torch.autograd.Function):

@@ -12,65 +12,14 @@ from . import _lib
 from ._lib import check, ptr
 
 
-# Weight gradients are only needed by the optimizer, the input gradient by the rest of the backward pass.  With
-# ``set_async_weight_grads(True)`` the weight-gradient kernels of every fused MLP go to one side stream and overlap
-# the remaining backward chain; the caller MUST call ``join_weight_grads()`` before it reads any ``weight.grad``
-# (FaceTrainer does, before the gradient exchange / optimizer steps).  Off by default: a plain drop-in user gets
-# gradients that are ordered on the current stream.
-_ASYNC = {"enabled": False, "streams": {}}
-
-
-def set_async_weight_grads(enabled: bool):
-    _ASYNC["enabled"] = bool(enabled)
-
-
-class async_weight_grads:
-    """``with async_weight_grads(device): loss.backward()`` -- defers the weight-gradient kernels inside the block and
-    joins them with the current stream on exit."""
-
-    def __init__(self, device):
-        self.device = device
-        self.active = device is not None and torch.device(device).type == "cuda"
-
-    def __enter__(self):
-        self.prev = _ASYNC["enabled"]
-        if self.active:
-            _ASYNC["enabled"] = True
-        return self
-
-    def __exit__(self, *exc):
-        _ASYNC["enabled"] = self.prev
-        if self.active:
-            join_weight_grads(torch.device(self.device))
-        return False
-
-
-def _wgrad_stream(device):
-    key = (device.type, device.index)
-    st = _ASYNC["streams"].get(key)
-    if st is None:
-        st = _ASYNC["streams"][key] = torch.cuda.Stream(device=device)
-    return st
-
-
-def join_weight_grads(device=None):
-    """Make the current stream wait for every deferred weight-gradient kernel."""
-    for (typ, idx), st in _ASYNC["streams"].items():
-        if device is None or (device.type, device.index) == (typ, idx):
-            torch.cuda.current_stream(torch.device(typ, idx)).wait_stream(st)
-
-
 def supported(dim_in, dim_hidden, dim_out, num_layers) -> bool:
     return num_layers in (2, 3) and 1 <= dim_in <= 96 and 1 <= dim_hidden <= 64 and 1 <= dim_out <= 32
 
 
-def _weight_grad(L, dz, inp, O, K, stream):
-    N = dz.shape[0]
-    dw = torch.empty(O, K, dtype=torch.float32, device=dz.device)
-    ws = torch.empty(L.instag_linear_weight_grad_workspace_bytes(N, O, K), dtype=torch.uint8, device=dz.device)
-    check(L.instag_linear_weight_grad(ptr(dz), ptr(inp), ptr(dw), ptr(ws), ws.numel(), N, O, K, stream),
-          "linear_weight_grad")
-    return dw
+def _weight_grad(L, dz, inp, dw, ws):
+    N, (O, K) = dz.shape[0], dw.shape
+    check(L.instag_linear_weight_grad(ptr(dz), ptr(inp), ptr(dw), ptr(ws), ws.numel(), N, O, K,
+                                      _lib.current_stream()), "linear_weight_grad")
 
 
 class _FusedMLP(torch.autograd.Function):
@@ -91,6 +40,7 @@ class _FusedMLP(torch.autograd.Function):
         check(L.instag_mlp_forward(ptr(x), ptr(w1c), ptr(w2c), ptr(w3c), ptr(y), ptr(a1), ptr(a2), N, K0, H, O, NL,
                                    _lib.current_stream()), "mlp_forward")
         ctx.save_for_backward(x, w1c, w2c, w3c, a1, a2)
+        ctx.weights = (w1, w2, w3)          # the caller's tensors (leaf parameters in the deferred-gradient mode)
         ctx.dims = (N, K0, H, O, NL)
         return y
 
@@ -107,30 +57,29 @@ class _FusedMLP(torch.autograd.Function):
         dx = torch.empty(N, K0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         check(L.instag_mlp_backward(ptr(dy), ptr(a1), ptr(a2), ptr(w1), ptr(w2), ptr(w3), ptr(dz1), ptr(dz2), ptr(dx),
                                     N, K0, H, O, NL, stream), "mlp_backward")
-        def weight_grads(stream):
-            dw1 = _weight_grad(L, dz1, x, H, K0, stream) if ctx.needs_input_grad[1] else None
-            if NL == 3:
-                dw2 = _weight_grad(L, dz2, a1, H, H, stream) if ctx.needs_input_grad[2] else None
-                dw3 = _weight_grad(L, dy, a2, O, H, stream) if ctx.needs_input_grad[3] else None
-            else:
-                dw2 = _weight_grad(L, dy, a1, O, H, stream) if ctx.needs_input_grad[2] else None
-                dw3 = None
-            return dw1, dw2, dw3
+        # weight gradients: only the optimizer reads them.  Inside a ``deferred_grads`` block (instag_amd/deferred.py)
+        # they are queued and computed after the rest of the backward pass in one batched launch
+        from . import deferred
+        layers = [(dz1, x, 1, (H, K0))]
+        layers += [(dz2, a1, 2, (H, H)), (dy, a2, 3, (O, H))] if NL == 3 else [(dy, a1, 2, (O, H))]
+        layers = [(dz, inp, idx, shp) for dz, inp, idx, shp in layers if ctx.needs_input_grad[idx]]
 
-        if _ASYNC["enabled"]:
-            main = torch.cuda.current_stream(dev)
-            side = _wgrad_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dw1, dw2, dw3 = weight_grads(_lib.current_stream())
-            for t in (dz1, dz2, dy, x, a1, a2):
-                if t is not None:
-                    t.record_stream(side)
-            for t in (dw1, dw2, dw3):
-                if t is not None:
-                    t.record_stream(main)
-        else:
-            dw1, dw2, dw3 = weight_grads(stream)
+        def compute():
+            out = {}
+            for dz, inp, idx, shp in layers:
+                dw = torch.empty(*shp, dtype=torch.float32, device=dev)
+                ws = torch.empty(L.instag_linear_weight_grad_workspace_bytes(N, shp[0], shp[1]), dtype=torch.uint8,
+                                 device=dev)
+                _weight_grad(L, dz, inp, dw, ws)
+                out[idx] = dw
+            return out
+
+        if deferred.active() and all(w is None or w.is_leaf for w in ctx.weights):
+            for dz, inp, idx, shp in layers:
+                deferred.defer_weight_grad(dz, inp, ctx.weights[idx - 1])
+            return dx, None, None, None
+        dws = compute()
+        dw1, dw2, dw3 = dws.get(1), dws.get(2), dws.get(3)
         return dx, dw1, dw2, dw3
 
 

@@ -214,9 +214,9 @@ class FaceTrainer:
         pkg = render_motion(frame, self.g, self.motion_net, None, self.bg, return_attn=True, personalized=False,
                             align=True)
         loss, Ll1 = self.loss_fn(frame, pkg, warm=True)
-        from .mlp import async_weight_grads
-        with async_weight_grads(self.device if self.on_gpu else None):
-            loss.backward()       # weight-gradient kernels of the fused MLPs run beside the rest of the backward
+        from .deferred import deferred_grads
+        with deferred_grads(self.device if self.on_gpu else None):
+            loss.backward()       # the MLPs' weight gradients are batched into one launch at the end (deferred.py)
         return pkg, loss, Ll1
 
     @torch.no_grad()
