@@ -7,6 +7,9 @@ nine such GEMMs (three MLPs of the universal field, one of the personalised fiel
         loss.backward()            # instag_amd.mlp queues (dZ, input, weight) instead of launching
     # on exit: one instag_linear_weight_grad_batched call on the current stream, results accumulated into weight.grad
 
+The block also lets the rasterizer's auxiliary-image backward run past the end of the rasterizer's own backward
+(``diff_gauss.DEFER_AUX_JOIN``): the glue operator that consumes those gradients joins it, the block's exit at the latest.
+
 Autograd receives ``None`` for those weights (it would otherwise copy or add a still-unwritten buffer), so the block
 itself performs ``w.grad = dw`` / ``w.grad += dw``.  Outside a block nothing is queued and gradients flow through
 autograd as usual.
@@ -66,10 +69,17 @@ class deferred_grads:
         self.prev = _STATE["active"]
         if self.on:
             _STATE["active"] = True
+            from . import diff_gauss
+            self.prev_aux = diff_gauss.DEFER_AUX_JOIN
+            diff_gauss.DEFER_AUX_JOIN = True       # joined by the glue operator, at the latest on exit below
         return self
 
     def __exit__(self, exc_type, exc, tb):
         _STATE["active"] = self.prev
+        if self.on:
+            from . import diff_gauss
+            diff_gauss.DEFER_AUX_JOIN = self.prev_aux
+            diff_gauss.join_pending_aux(final=True)
         if not self.on or self.prev:
             return False
         jobs, _STATE["jobs"] = _STATE["jobs"], []

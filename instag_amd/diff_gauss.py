@@ -165,6 +165,22 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
 
 
 _AUX_STREAMS = {}
+DEFER_AUX_JOIN = False        # see _RasterizeGaussians.backward; only a caller that joins explicitly may set this
+_PENDING_AUX = []
+
+
+def join_pending_aux(final: bool = False):
+    """Make the current stream wait for every outstanding aux-image backward.  ``final=True`` (after the backward pass
+    has finished) also adds the aux image's means2D contribution to ``means2D.grad`` and forgets the entries."""
+    for entry in _PENDING_AUX:
+        if not entry["joined"]:
+            torch.cuda.current_stream(entry["dev"]).wait_stream(entry["side"])
+            entry["joined"] = True
+    if final:
+        while _PENDING_AUX:
+            entry = _PENDING_AUX.pop()
+            leaf, m2d_aux = entry["leaf"], entry["m2d_aux"]
+            leaf.grad = m2d_aux if leaf.grad is None else leaf.grad.add_(m2d_aux)
 
 
 def rasterize_aux_backward(st: "_State", g_aux, want_colors=True, want_means2D=True, stream=None):
@@ -232,6 +248,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         outs, st = rasterize_forward(raster_settings, m3, shs, col, op, sc, ro, cov, ex, aux)
         ctx.state = st
         ctx.shapes = (opacities.shape, None if extra_attrs is None else extra_attrs.shape)
+        ctx.means2D_leaf = means2D if (means2D is not None and means2D.is_leaf and means2D.requires_grad) else None
         ctx.mark_non_differentiable(outs[4])
         return outs
 
@@ -267,9 +284,19 @@ class _RasterizeGaussians(torch.autograd.Function):
             for t in (g_aux, d_aux, m2d_aux):
                 if t is not None:
                     t.record_stream(side)
-            main.wait_stream(side)
-            if m2d_aux is not None:
-                g["means2D"] = m2d_aux if g["means2D"] is None else g["means2D"].add_(m2d_aux)
+            if DEFER_AUX_JOIN and (m2d_aux is None or ctx.means2D_leaf is not None):
+                # The caller promised to call join_pending_aux() before it touches the aux gradients (the trainer
+                # does, in the glue operator that consumes them) and join_pending_aux(final=True) after backward:
+                # the main chain does not wait for the aux image's backward here, and the aux image's means2D
+                # contribution is added to means2D.grad at the final join.
+                if m2d_aux is not None:
+                    _PENDING_AUX.append(dict(dev=dev, side=side, leaf=ctx.means2D_leaf, m2d_aux=m2d_aux, joined=False))
+                else:
+                    main.wait_stream(side)
+            else:
+                main.wait_stream(side)
+                if m2d_aux is not None:
+                    g["means2D"] = m2d_aux if g["means2D"] is None else g["means2D"].add_(m2d_aux)
         op_shape, ex_shape = ctx.shapes
         g_op = None if g["opacities"] is None else g["opacities"].reshape(op_shape)
         g_ex = None if g["extra"] is None else g["extra"].reshape(ex_shape)

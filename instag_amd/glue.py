@@ -36,6 +36,11 @@ class _MotionGlue(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_h_in, d_amb):
         L = _lib.lib()
+        if d_amb is not None:
+            # amb doubles as the attention colours of the rasterizer's auxiliary image, whose backward may still be
+            # running on its side stream (diff_gauss.DEFER_AUX_JOIN)
+            from . import diff_gauss
+            diff_gauss.join_pending_aux()
         aud, eye_pre, enc_a, enc_e, amb = ctx.saved_tensors
         N, KX, KA, KE = ctx.dims
         dev = aud.device

@@ -294,3 +294,36 @@ def test_aux_colors_match_second_pass():
         assert gr is not None and gf is not None, k
         scale = max(float(gr.abs().max()), 1e-6)
         assert float((gr - gf).abs().max()) <= 2e-5 * scale, (k, float((gr - gf).abs().max()), scale)
+
+
+def test_deferred_aux_join_keeps_means2d_gradient():
+    """Inside deferred_grads() the aux image's backward outlives the rasterizer's backward; all gradients unchanged."""
+    from instag_amd.deferred import deferred_grads
+    from instag_amd.diff_gauss import GaussianRasterizer
+    N, size = 2000, 64
+    a, sd = make_scene(N, size, sh_degree=1, seed=3)
+    settings = hip_settings(sd)
+    g = torch.Generator().manual_seed(4)
+    aux0 = torch.rand(N, 3, generator=g).cuda()
+    w_img, w_aux = torch.randn(3, size, size, generator=g).cuda(), torch.randn(3, size, size, generator=g).cuda()
+    ones = torch.ones(N, 1, device="cuda")
+
+    def run(deferred):
+        d = {k: a[k].cuda().clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        d["aux"] = aux0.clone().requires_grad_(True)
+        d["m2d"] = torch.zeros(N, 3, device="cuda", requires_grad=True)
+        outs = GaussianRasterizer(settings)(means3D=d["means3D"], means2D=d["m2d"], shs=d["shs"],
+                                            opacities=d["opacities"], scales=d["scales"], rotations=d["rotations"],
+                                            extra_attrs=ones, aux_colors=d["aux"])
+        loss = (outs[0] * w_img).sum() + (outs[6] * w_aux).sum()
+        if deferred:
+            with deferred_grads("cuda"):
+                loss.backward()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return {k: v.grad.clone() for k, v in d.items()}
+
+    ref, got = run(False), run(True)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
