@@ -329,7 +329,7 @@ static int glue_bwd_blocks(int N, int KX, int KA, int KE) {
   auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
   const int K = KX + KA + KE;
   const int unit = K / gcd(K, GB);
-  return std::max(unit, row_blocks(N * 8) / unit * unit);
+  return std::max(unit, std::min(1024, row_blocks(N * 8)) / unit * unit);
 }
 
 int instag_motion_glue_backward_num_partials(int32_t N, int32_t KX, int32_t KA, int32_t KE) {

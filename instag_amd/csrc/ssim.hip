@@ -267,19 +267,21 @@ face_loss_forward_kernel(FaceCfg cfg, FaceIn in, float* __restrict__ maps, float
 }
 
 // out[0] loss, out[1] L1, out[2] SSIM, out[3] 1 / max(#hair pixels, 1), out[4] 1 / lips-rect area (0 when empty)
-__global__ void __launch_bounds__(256)
+// eight waves, one per partial-sum array (fixed summation order inside a wave: lane-strided, then a butterfly)
+__global__ void __launch_bounds__(512)
 face_loss_finalize_kernel(FaceCfg cfg, const float* __restrict__ part, int tiles, const int32_t* __restrict__ lips,
                           const float* __restrict__ extra, float* __restrict__ out) {
-  __shared__ float s_red[4];
   __shared__ float s_sum[8];
-  for (int k = 0; k < 8; ++k) {
+  {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* p = k < 2 ? part + (size_t)k * 3 * tiles : part + (size_t)6 * tiles + (size_t)(k - 2) * tiles;
     const int n = k < 2 ? 3 * tiles : tiles;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) acc += p[i];
-    const float t = block_sum_256(acc, s_red);
-    __syncthreads();
-    if (threadIdx.x == 0) s_sum[k] = t;
+#pragma unroll 8
+    for (int i = lane; i < n; i += 64) acc += p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) s_sum[k] = acc;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -431,7 +433,7 @@ int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image
     face_loss_forward_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(c, in, maps, partials);
     INSTAG_CHECK_LAUNCH();
   }
-  face_loss_finalize_kernel<<<1, 256, 0, (hipStream_t)stream>>>(c, partials, (int)(grid.x * grid.y), lips_rect, extra,
+  face_loss_finalize_kernel<<<1, 512, 0, (hipStream_t)stream>>>(c, partials, (int)(grid.x * grid.y), lips_rect, extra,
                                                               out);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;

@@ -51,8 +51,11 @@ class MultiTensorAdam:
                     else:
                         p.grad.zero_()
 
+    def _state_of(self, p):
+        return self.state[p]
+
     def _ensure_state(self, p):
-        st = self.state[p]
+        st = self._state_of(p)
         if "exp_avg" not in st:
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
@@ -100,12 +103,12 @@ class MultiTensorAdam:
             # per-tensor step counters follow their parameter's state across re-layouts (densify / prune)
             steps = torch.zeros(len(tensors), dtype=torch.float32, device=dev)
             for i, t in enumerate(tensors):
-                prev = self.state[t[0]].get("step")
+                prev = self._state_of(t[0]).get("step")
                 if prev is not None:
                     steps[i:i + 1].copy_(prev.reshape(1))
             self._step = steps
             for i, t in enumerate(tensors):
-                self.state[t[0]]["step"] = steps[i:i + 1]
+                self._state_of(t[0])["step"] = steps[i:i + 1]
             self._dev, self._layout_key = dev, key
             self.set_lrs()
         tarr = self._tensors_host.numpy().view(_TENSOR_DT)
@@ -120,3 +123,40 @@ class MultiTensorAdam:
     def invalidate(self):
         """Call after replacing parameters / state tensors (densify, prune)."""
         self._layout_key = None
+
+
+class CombinedAdam(MultiTensorAdam):
+    """One launch for several MultiTensorAdam optimizers (the reference steps ``gaussians.optimizer`` and
+    ``motion_optimizer`` back to back, train_face.py:781-788).  The member optimizers keep their own ``param_groups``
+    and ``state`` (densify / prune / lr schedules keep working on them); this object only steps them together."""
+
+    def __init__(self, optimizers):
+        self.optimizers = list(optimizers)
+        self._dev = None
+        self._step = None
+        self._layout_key = None
+
+    @property
+    def param_groups(self):
+        return [g for o in self.optimizers for g in o.param_groups]
+
+    @property
+    def state(self):
+        raise AttributeError("CombinedAdam has no state of its own: use the member optimizers")
+
+    def _state_of(self, p):
+        for o in self.optimizers:
+            for g in o.param_groups:
+                for q in g["params"]:
+                    if q is p:
+                        return o.state[p]
+        raise KeyError("parameter does not belong to a member optimizer")
+
+    def zero_grad(self, set_to_none: bool = True):
+        for o in self.optimizers:
+            o.zero_grad(set_to_none)
+
+    def invalidate(self):
+        self._layout_key = None
+        for o in self.optimizers:
+            o.invalidate()

@@ -172,7 +172,9 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         if personalized:
             p_rendered_attn = attn_pass(p_motion_preds)
 
-    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+    from .motion_net import LazyOutputs
+    return LazyOutputs({"render": image, "viewspace_points": screenspace_points,
+            "visibility_filter": lambda: radii > 0,      # one launch, only when somebody reads it
             "depth": depth, "alpha": alpha, "normal": normal, "radii": radii, "motion": motion_preds,
             "p_motion": p_motion_preds if personalized or align else None, "attn": rendered_attn,
-            "p_attn": p_rendered_attn}
+            "p_attn": p_rendered_attn})

@@ -167,6 +167,19 @@ class FaceTrainer:
         else:
             self.motion_optimizer = torch.optim.AdamW(groups, lr=5e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
         self.g.training_setup(self.opt, fused=self.on_gpu)
+        self._combined = None
+        if self.on_gpu:
+            from .optim import CombinedAdam, MultiTensorAdam
+            if isinstance(self.g.optimizer, MultiTensorAdam):
+                # one launch steps both optimizers (train_face.py:781-788 steps them back to back)
+                self._combined = CombinedAdam([self.motion_optimizer, self.g.optimizer])
+
+    def _step_optimizers(self):
+        if self._combined is not None:
+            self._combined.step()
+        else:
+            self.motion_optimizer.step()
+            self.g.optimizer.step()
 
     def _motion_lr_factor(self, it):
         warm_step, iters = 3000, self.opt.iterations
@@ -178,7 +191,7 @@ class FaceTrainer:
         for grp, base in zip(self.motion_optimizer.param_groups, self._motion_base_lr):
             grp["lr"] = base * f
         self.g.update_learning_rate(it)
-        for opt_ in (self.motion_optimizer, self.g.optimizer):
+        for opt_ in ((self._combined,) if self._combined is not None else (self.motion_optimizer, self.g.optimizer)):
             if hasattr(opt_, "set_lrs"):
                 opt_.set_lrs()          # one small copy into the device-side learning-rate table
 
@@ -216,7 +229,14 @@ class FaceTrainer:
         loss, Ll1 = self.loss_fn(frame, pkg, warm=True)
         from .deferred import deferred_grads
         with deferred_grads(self.device if self.on_gpu else None):
-            loss.backward()       # the MLPs' weight gradients are batched into one launch at the end (deferred.py)
+            # the MLPs' weight gradients are batched into one launch at the end (deferred.py); the root gradient is
+            # a cached constant (no fill launch per step)
+            if self.on_gpu:
+                if getattr(self, "_one", None) is None:
+                    self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+                loss.backward(gradient=self._one)
+            else:
+                loss.backward()
         return pkg, loss, Ll1
 
     @torch.no_grad()
@@ -227,8 +247,7 @@ class FaceTrainer:
                 and pkg["radii"].dtype == torch.int32 and vs_grad.is_contiguous():
             from .glue import densify_stats
             densify_stats(vs_grad, pkg["radii"], g.max_radii2D, g.xyz_gradient_accum, g.denom)
-            self.motion_optimizer.step()
-            g.optimizer.step()
+            self._step_optimizers()
             return
         vis = pkg["visibility_filter"]
         radii = pkg["radii"].to(self.g.max_radii2D.dtype)
@@ -242,8 +261,7 @@ class FaceTrainer:
         self.g.max_radii2D.copy_(torch.max(self.g.max_radii2D, rmax))
         self.g.xyz_gradient_accum.add_(norm)
         self.g.denom.add_(cnt)
-        self.motion_optimizer.step()
-        self.g.optimizer.step()
+        self._step_optimizers()
 
     def _zero_grad(self):
         self.motion_optimizer.zero_grad(set_to_none=True)
@@ -365,8 +383,7 @@ class GraphedStep:
                     t.g.max_radii2D.copy_(torch.max(t.g.max_radii2D, self._rmax))
                     t.g.xyz_gradient_accum.add_(norm)
                     t.g.denom.add_(cnt)
-                    t.motion_optimizer.step()
-                    t.g.optimizer.step()
+                    t._step_optimizers()
                     t._zero_grad()
         self.loss, self.l1 = loss, l1
         self.capacity = cap
