@@ -18,6 +18,7 @@
 namespace instag {
 namespace {
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 constexpr int BLOCK = 256;
 constexpr int NCH = 8;  // r g b depth nx ny nz extra
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
@@ -48,10 +49,13 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   bool done = !inside;
   float T = 1.0f;
   uint32_t last_contributor = 0;
-  float acc[NCH];
+  // channel accumulators as float pairs: the eight FMAs per Gaussian become four v_pk_fma_f32 (the record keeps
+  // (r,g) (b,depth) (nx,ny) (nz,extra) in adjacent registers)
+  f32x2 acc2[NCH / 2];
 #pragma unroll
-  for (int k = 0; k < NCH; ++k) acc[k] = 0.f;
-  float xacc[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < NCH / 2; ++k) acc2[k] = f32x2{0.f, 0.f};
+  f32x2 xacc2 = {0.f, 0.f};
+  float xacc_b = 0.f;
 
   // the records of batch i+1 are fetched while batch i is being blended
   float4 nrec0 = make_float4(0.f, 0.f, 0.f, 0.f), nrec1 = nrec0, nrec2 = nrec0, nrec3 = nrec0;
@@ -93,13 +97,21 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
       done = done || stop;
       const bool take = hit && !stop;
       const float w = take ? alpha * T : 0.f;
-      acc[0] += b.z * w; acc[1] += b.w * w; acc[2] += cc.x * w; acc[3] += cc.y * w;
-      acc[4] += cc.z * w; acc[5] += cc.w * w; acc[6] += dd.x * w; acc[7] += dd.y * w;
-      if (AUX) { xacc[0] += s_aux[j][0] * w; xacc[1] += s_aux[j][1] * w; xacc[2] += s_aux[j][2] * w; }
+      const f32x2 w2 = {w, w};
+      acc2[0] = __builtin_elementwise_fma(f32x2{b.z, b.w}, w2, acc2[0]);
+      acc2[1] = __builtin_elementwise_fma(f32x2{cc.x, cc.y}, w2, acc2[1]);
+      acc2[2] = __builtin_elementwise_fma(f32x2{cc.z, cc.w}, w2, acc2[2]);
+      acc2[3] = __builtin_elementwise_fma(f32x2{dd.x, dd.y}, w2, acc2[3]);
+      if (AUX) {
+        xacc2 = __builtin_elementwise_fma(f32x2{s_aux[j][0], s_aux[j][1]}, w2, xacc2);
+        xacc_b += s_aux[j][2] * w;
+      }
       T = take ? test_T : T;
       last_contributor = take ? (uint32_t)(i * BLOCK + j + 1) : last_contributor;
     }
   }
+  const float acc[NCH] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
+  const float xacc[3] = {xacc2.x, xacc2.y, xacc_b};
   if (inside) {
     const size_t P = (size_t)c.H * c.W;
     const size_t pix = (size_t)pyi * c.W + pxi;

@@ -327,3 +327,89 @@ def test_deferred_aux_join_keeps_means2d_gradient():
     ref, got = run(False), run(True)
     for k in ref:
         assert torch.equal(ref[k], got[k]), k
+
+
+FULL = [
+    pytest.param(50000, 512, 1, id="C2-50k-512-sh1"),
+    pytest.param(100000, 512, 1, id="C3-100k-512-sh1"),
+    pytest.param(300000, 1024, 3, id="C5-300k-1024-sh3"),
+]
+
+
+@pytest.mark.parametrize("n,size,deg", FULL)
+def test_full_size_properties(n, size, deg):
+    """BASELINE.json's full-size configurations through size-independent properties (no oracle at these sizes):
+    sorted (tile, depth) keys and consistent tile ranges; compositing identity under a background change;
+    extra(=1) == alpha; bitwise reproducible backward; gradients linear in the upstream image gradient;
+    sync-free capacity mode == two-stage mode."""
+    from instag_amd import diff_gauss
+    from instag_amd.diff_gauss import GaussianRasterizer, rasterize_forward
+    a, settings = make_scene(n, size, sh_degree=deg, seed=2)
+    g = {k: v.cuda() for k, v in a.items()}
+    gen = torch.Generator().manual_seed(7)
+    w1, w2 = torch.randn(3, size, size, generator=gen).cuda(), torch.randn(3, size, size, generator=gen).cuda()
+
+    def run(bg, w):
+        st = dict(settings)
+        st["bg"] = torch.tensor(bg)
+        leaves = {k: g[k].clone().requires_grad_(True) for k in ("means3D", "shs", "opacities", "scales", "rotations")}
+        m2 = torch.zeros(n, 3, device="cuda", requires_grad=True)
+        outs = GaussianRasterizer(hip_settings(st))(
+            means3D=leaves["means3D"], means2D=m2, shs=leaves["shs"], opacities=leaves["opacities"],
+            scales=leaves["scales"], rotations=leaves["rotations"], extra_attrs=g["extra"])
+        (outs[0] * w).sum().backward()
+        leaves["means2D"] = m2
+        return outs, {k: v.grad for k, v in leaves.items()}
+
+    o0, g1 = run((0.0, 1.0, 0.0), w1)
+    R = diff_gauss.LAST_STATS["num_rendered"]
+    assert R > n                                                       # the scene is not degenerate
+    o1, _ = run((1.0, 0.0, 1.0), w1)
+    (i0, d0, n0, a0, r0, e0), (i1, d1, n1, a1, r1, e1) = o0, o1
+    assert torch.equal(a0, a1) and torch.equal(d0, d1) and torch.equal(r0, r1) and torch.equal(n0, n1)
+    dbg = torch.tensor([1.0, -1.0, 1.0], device="cuda")[:, None, None]
+    assert float(((i1 - i0) - (1 - a0) * dbg).abs().max()) <= 2e-6
+    assert float((e0 - a0).abs().max()) <= 2e-6
+    assert float(a0.min()) >= 0.0 and float(a0.max()) <= 1.0 and bool(torch.isfinite(i0).all())
+
+    # reproducible, and linear in the upstream gradient
+    _, g1b = run((0.0, 1.0, 0.0), w1)
+    for k in g1:
+        assert torch.equal(g1[k], g1b[k]), k
+    _, g2 = run((0.0, 1.0, 0.0), w2)
+    _, g12 = run((0.0, 1.0, 0.0), w1 + w2)
+    for k in g1:
+        ref = g1[k] + g2[k]
+        scale = max(float(ref.abs().max()), 1e-12)
+        assert float((g12[k] - ref).abs().max()) <= 2e-4 * scale, k
+        assert bool(torch.isfinite(g12[k]).all()), k
+
+    # binning state: keys sorted by (tile, depth), ranges partition the list
+    st = hip_settings(settings)
+    with torch.no_grad():
+        _, state = rasterize_forward(st, g["means3D"], g["shs"], None, g["opacities"], g["scales"], g["rotations"],
+                                     None, g["extra"])
+    dbgx = diff_gauss.debug_export(state)
+    keys = dbgx["keys"]
+    assert dbgx["R"] == R and bool((keys[1:] >= keys[:-1]).all())
+    rng = dbgx["ranges"].long()
+    nonempty = rng[:, 1] > rng[:, 0]
+    assert int((rng[nonempty, 1] - rng[nonempty, 0]).sum()) == R
+    tiles_of_keys = (keys >> 32)
+    starts = rng[nonempty, 0]
+    assert bool((tiles_of_keys[starts] == torch.nonzero(nonempty).flatten()).all())
+
+    # capacity mode
+    plan = diff_gauss.CapacityPlan([int(R * 1.2) + 64], "cuda")
+    diff_gauss.set_capacity_plan(plan)
+    try:
+        plan.begin_step()
+        oc, gc = run((0.0, 1.0, 0.0), w1)
+        torch.cuda.synchronize()
+    finally:
+        diff_gauss.set_capacity_plan(None)
+    assert plan.needed() == [R] and not plan.overflowed()
+    for x, y in zip(oc, o0):
+        assert torch.equal(x, y)
+    for k in g1:
+        assert torch.equal(gc[k], g1[k]), k
