@@ -268,6 +268,13 @@ int instag_densify_stats(const float* viewspace_grad, const int32_t* radii, floa
                          float* denom, int32_t N, instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * `simple_knn._C.distCUDA2` provider (scene/gaussian_model.py:20,246; the package itself is an absent third-party
+ * submodule): out[i] = mean of the squared distances from point i to its three nearest OTHER points
+ * (over min(3, N-1) neighbours when the cloud is smaller; 0 for a single point).  points [N,3], out [N].
+ * ------------------------------------------------------------------------------------------ */
+int instag_knn3_mean_dist2(const float* points, float* out, int32_t N, instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Per-frame conditioning codes of one motion network, one workgroup per pass (csrc/audio.hip):
  *   enc_a [dim_aud] = AudioAttNet(AudioNet(a))             scene/motion_net.py:29-64, :67-99
  *   enc_e [6]       = cat(exp_encode_net(e[:5]), e[5:6])   scene/motion_net.py:152-173 (MLP 5->16->5, bias-free)

@@ -40,6 +40,7 @@ SOURCES = {
     "glue.hip": [],
     "adam.hip": [],
     "audio.hip": [],
+    "knn.hip": [],
 }
 
 

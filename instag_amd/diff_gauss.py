@@ -165,6 +165,7 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
 
 
 _AUX_STREAMS = {}
+_AUX_EVENTS = {}
 DEFER_AUX_JOIN = False        # see _RasterizeGaussians.backward; only a caller that joins explicitly may set this
 _PENDING_AUX = []
 
@@ -262,7 +263,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         aux_needed = st.aux is not None and g_aux is not None and (need[10] or need[1])
         dev = st.geom.device
         if aux_needed:
-            ready = torch.cuda.Event()
+            ready = _AUX_EVENTS.get((dev.type, dev.index))       # reused: no event is created / destroyed per step
+            if ready is None:
+                ready = _AUX_EVENTS[(dev.type, dev.index)] = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(dev))
         main_grads = any(g is not None for g in (g_color, g_depth, g_normal, g_alpha, g_extra))
         if main_grads:

@@ -4,7 +4,7 @@ densification statistics and densify / prune.
 Counterpart of /root/reference/scene/gaussian_model.py (only what the hot path touches):
   activations            :43-51   softplus scale, sigmoid opacity, normalised rotation
   getters                :168-196
-  create_from_pcd        :206-335 (random-cloud init; 3-NN scale init replaced by an explicit scale)
+  create_from_pcd        :206-335 (3-NN scale init through simple_knn._C.distCUDA2; create_random = synthetic cloud)
   training_setup         :349-403 7 per-Gaussian Adam groups (eps 1e-15) + PMF groups
   update_learning_rate   :421-427 with utils/general_utils.py get_expon_lr_func
   prune / cat / densify  :563-681
@@ -141,6 +141,25 @@ class GaussianModel:
                    for k, v in vals.items()}
         self.max_radii2D = torch.zeros(n, device=device)
         return self
+
+    def create_from_pcd(self, points, colors, spatial_lr_scale: float, device="cuda"):
+        """Initialise from a point cloud like scene/gaussian_model.py:206-335: SH DC = RGB2SH(colour), opacity 0.1,
+        identity rotation, raw scale = log(sqrt(mean squared distance to the 3 nearest neighbours)) clamped at 1e-7
+        (``simple_knn._C.distCUDA2`` :246-259).  points [N,3], colors [N,3] in [0,1] (tensors or arrays)."""
+        from simple_knn._C import distCUDA2
+        pts = torch.as_tensor(points, dtype=torch.float32).to(device)
+        col = torch.as_tensor(colors, dtype=torch.float32).to(device)
+        n = pts.shape[0]
+        M = (self.max_sh_degree + 1) ** 2
+        dist2 = torch.clamp_min(distCUDA2(pts), 0.0000001)
+        rot = torch.zeros(n, 4, device=device)
+        rot[:, 0] = 1
+        raw = dict(xyz=pts, scaling=torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3), rotation=rot,
+                   opacity=inverse_sigmoid(0.1 * torch.ones(n, 1, device=device)),
+                   features_dc=((col - 0.5) / 0.28209479177387814)[:, None, :],          # utils/sh_utils.py RGB2SH
+                   features_rest=torch.zeros(n, M - 1, 3, device=device))
+        self.spatial_lr_scale = spatial_lr_scale
+        return self.load_raw(raw, device)
 
     def create_random(self, n, device, spatial_lr_scale=1.0, seed=0, init_scale=0.004):
         """Random cloud in [-0.1,0.1]^3 like scene/dataset_readers.py:353 + create_from_pcd :206-335."""

@@ -195,7 +195,9 @@ class _TriPlaneField(nn.Module):
         (right before the glue that consumes it) and its backward is therefore scheduled early."""
         if not (a.is_cuda and CONCURRENT_AUDIO):
             return
-        ev = torch.cuda.Event()
+        ev = self.__dict__.get("_audio_event")      # one reusable event per network (no create / destroy per step:
+        if ev is None:                              # destroying an event while a stream capture is open aborts)
+            ev = self.__dict__["_audio_event"] = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(a.device))
         self._audio_pending = (a, e, ev, _side_stream(a.device, stream_index))
 

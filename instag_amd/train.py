@@ -307,6 +307,23 @@ class FaceTrainer:
         return self._graph
 
 
+class _no_gc:
+    """No cyclic garbage collection inside a stream-capture window: a collection there would release device tensors
+    (and events) of earlier steps while the capture is open, which intermittently aborts on ROCm 7.2."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 class GraphedStep:
     def __init__(self, trainer: FaceTrainer, example: Frame, headroom: float, warmup_steps: int,
                  split_for_allreduce: Optional[bool] = None):
@@ -352,7 +369,7 @@ class GraphedStep:
         self.graph_b = None
         self.plan.begin_step()
         if not self.split:
-            with torch.cuda.graph(self.graph_a):
+            with _no_gc(), torch.cuda.graph(self.graph_a):
                 pkg, loss, l1 = t._forward_backward(self.static)
                 t._stats_and_optimizers(pkg, False)
                 t._zero_grad()
@@ -360,7 +377,7 @@ class GraphedStep:
             # window intermittently crash hipStreamEndCapture)
             del pkg
         else:
-            with torch.cuda.graph(self.graph_a):
+            with _no_gc(), torch.cuda.graph(self.graph_a):
                 pkg, loss, l1 = t._forward_backward(self.static)
                 vis = pkg["visibility_filter"]
                 vs_grad = pkg["viewspace_points"].grad
@@ -374,7 +391,7 @@ class GraphedStep:
             del pkg
             self._n_grad = sum(p.numel() for p in self._params)
             self.graph_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_b):
+            with _no_gc(), torch.cuda.graph(self.graph_b):
                 with torch.no_grad():
                     scatter_grad_bucket(self._params, self._bucket[:self._n_grad])
                     n = self._norm.numel()

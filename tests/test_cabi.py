@@ -55,3 +55,5 @@ def test_drop_in_package_names_import():
                                   log2_hashmap_size=17, desired_resolution=38.4)
     assert enc.output_dim == 12 and tuple(enc.embeddings.shape) == (9464, 1)
     assert shencoder.SHEncoder(3, 4).output_dim == 16
+    from simple_knn._C import distCUDA2
+    assert callable(distCUDA2)

@@ -208,3 +208,33 @@ def test_densify_stats_matches_torch():
     densify_stats(vs.cuda(), radii.cuda(), mr_h, acc_h, den_h)
     assert torch.equal(mr_h.cpu(), mr_r) and torch.equal(den_h.cpu(), den_r)
     _close(acc_h, acc_r, "grad_accum", tol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 257, 5000])
+def test_dist_cuda2_matches_bruteforce(n):
+    """simple_knn._C.distCUDA2: mean squared distance to the 3 nearest other points (fp64 brute force on the CPU)."""
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(n)
+    pts = torch.rand(n, 3, generator=g) * 0.2 - 0.1
+    if n >= 257:
+        pts[5] = pts[9]                      # duplicate points: distance 0 to each other
+    d = torch.cdist(pts.double(), pts.double()) ** 2
+    d.fill_diagonal_(float("inf"))
+    k = min(3, n - 1)
+    ref = d.topk(k, largest=False).values.mean(dim=1) if k > 0 else torch.zeros(n, dtype=torch.float64)
+    got = distCUDA2(pts.cuda()).cpu().double()
+    assert got.shape == (n,)
+    assert float((got - ref).abs().max()) <= 1e-6 * max(float(ref.abs().max()), 1e-12) + 1e-12
+
+
+def test_create_from_pcd_uses_knn_scales():
+    from instag_amd.gaussian_model import GaussianModel
+    g = torch.Generator().manual_seed(0)
+    pts, col = torch.rand(500, 3, generator=g) * 0.2 - 0.1, torch.rand(500, 3, generator=g)
+    gm = GaussianModel(1).create_from_pcd(pts, col, spatial_lr_scale=1.0)
+    d = torch.cdist(pts.double(), pts.double()) ** 2
+    d.fill_diagonal_(float("inf"))
+    ref = torch.log(torch.sqrt(d.topk(3, largest=False).values.mean(1).clamp_min(1e-7)))
+    assert float((gm._scaling[:, 0].detach().cpu().double() - ref).abs().max()) < 1e-5
+    assert gm.get_xyz.shape == (500, 3) and gm.get_features.shape == (500, 4, 3)
+    assert float((gm.get_features[:, 0].detach().cpu() * 0.28209479177387814 + 0.5 - col).abs().max()) < 1e-6
