@@ -3,7 +3,7 @@
 Counterpart of /root/reference/scene/motion_net.py (same module / parameter names so reference
 ``state_dict``s load unchanged):
   AudioAttNet :29-64, AudioNet :67-99, MLP :152-173,
-  MotionNetwork (UMF) :176-345, PersonalizedMotionNetwork (PMF) :562-748.
+  MotionNetwork (UMF) :176-345, MouthMotionNetwork :346-478, PersonalizedMotionNetwork (PMF) :562-748.
 The tri-plane grid encoders are ``instag_amd.gridencoder.GridEncoder`` (HIP); ``encoder_cls`` lets
 the CPU tests inject the oracle encoder.  The per-Gaussian MLP chains (B = N rows) run as fused
 f32-MFMA HIP kernels through ``instag_amd.mlp``.
@@ -347,3 +347,69 @@ class PersonalizedMotionNetwork(_TriPlaneField):
             params.append({"params": self.exp_encode_net.parameters(), "name": "neural_exp_encode_net",
                            "lr": lr_net, "weight_decay": wd})
         return params
+
+
+class MouthMotionNetwork(nn.Module):
+    """Motion field of the mouth branch (scene/motion_net.py:346-478): tri-plane encoders with base resolution 64
+    (46,600 entries per plane: too large for the one-pass LDS tri-plane kernel, so the three generic
+    ``GridEncoder`` calls run), sigma_net 71->32->32->7 on the concatenation of position code, audio code and the
+    3-element jaw-movement feature, scaler_net 39->16->16->1 gating the displacement."""
+
+    def __init__(self, audio_dim=32, ind_dim=0, args=None, encoder_cls=None):
+        super().__init__()
+        encoder_cls = encoder_cls or _default_encoder_cls()
+        self.audio_in_dim = audio_in_dim(args.audio_extractor)
+        self.bound = 0.15
+        self.individual_dim = ind_dim
+        if ind_dim > 0:
+            self.individual_codes = nn.Parameter(torch.randn(10000, ind_dim) * 0.1)
+        self.audio_dim = audio_dim
+        if args.audio_extractor == "ave":
+            raise NotImplementedError("the 'ave' audio extractor is outside the accelerated path")
+        self.audio_net = AudioNet(self.audio_in_dim, audio_dim)
+        self.audio_att_net = AudioAttNet(audio_dim)
+        self.num_levels, self.level_dim = 12, 1
+        enc = dict(input_dim=2, num_levels=self.num_levels, level_dim=self.level_dim, base_resolution=64,
+                   log2_hashmap_size=17, desired_resolution=384 * self.bound, gridtype="hash", align_corners=False)
+        self.encoder_xy, self.encoder_yz, self.encoder_xz = encoder_cls(**enc), encoder_cls(**enc), encoder_cls(**enc)
+        self.in_dim_xy = self.in_dim_yz = self.in_dim_xz = self.encoder_xy.output_dim
+        self.in_dim = 3 * self.encoder_xy.output_dim
+        self.num_layers, self.hidden_dim, self.out_dim, self.move_dim = 3, 32, 7, 3
+        self.sigma_net = MLP(self.in_dim + audio_dim + ind_dim + self.move_dim, self.out_dim, self.hidden_dim,
+                             self.num_layers)
+        self.scaler_net = MLP(self.in_dim + self.move_dim, 1, 16, 3)
+        self.aud_ch_att_net = MLP(self.in_dim, audio_dim, 32, 2)     # present in the reference, unused in forward
+
+    encode_x = _TriPlaneField.encode_x
+
+    def encode_audio(self, a):
+        if a is None:
+            return None
+        return self.audio_att_net(self.audio_net(a).unsqueeze(0))
+
+    def forward(self, x, a, move):
+        enc_x = self.encode_x(x, bound=self.bound)
+        enc_a = self.encode_audio(a)
+        n = enc_x.shape[0]
+        move = move.repeat(n, 1)
+        h = self.sigma_net(torch.cat([enc_x, enc_a.repeat(n, 1), move], dim=-1))
+        h_s = self.scaler_net(torch.cat([enc_x, move], dim=-1))
+        # d_xyz = h[:, :3] * 1e-2 with x and z divided by 5 (motion_net.py:446-450), without the in-place edits
+        d_xyz = h[..., :3] * h.new_tensor([1e-2 / 5, 1e-2, 1e-2 / 5])
+        return {"d_xyz": d_xyz * torch.sigmoid(h_s) * 2, "d_rot": h[..., 3:]}
+
+    def get_params(self, lr, lr_net, wd=0):
+        params = [
+            {"params": self.audio_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.encoder_xy.parameters(), "lr": lr},
+            {"params": self.encoder_yz.parameters(), "lr": lr},
+            {"params": self.encoder_xz.parameters(), "lr": lr},
+            {"params": self.sigma_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.scaler_net.parameters(), "lr": lr_net, "weight_decay": wd},
+            {"params": self.audio_att_net.parameters(), "lr": lr_net * 5, "weight_decay": 0.0001},
+        ]
+        if self.individual_dim > 0:
+            params.append({"params": self.individual_codes, "lr": lr_net, "weight_decay": wd})
+        params.append({"params": self.aud_ch_att_net.parameters(), "lr": lr_net, "weight_decay": wd})
+        return params
+

@@ -178,3 +178,46 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             "depth": depth, "alpha": alpha, "normal": normal, "radii": radii, "motion": motion_preds,
             "p_motion": p_motion_preds if personalized or align else None, "attn": rendered_attn,
             "p_attn": p_rendered_attn})
+
+
+def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_net_face, pipe=None, bg_color=None,
+                            scaling_modifier=1.0, frame_idx=None, return_attn=False, personalized=False, align=False,
+                            k=10, inference=False):
+    """Mouth branch (gaussian_renderer/__init__.py:302-435): the mouth field is conditioned on a 3-element jaw
+    movement feature derived (without gradient) from the k-th largest / smallest vertical displacement the FACE
+    field predicts for the face Gaussians with a neutral expression."""
+    screenspace_points = _screenspace_points(pc)
+    rasterizer = GaussianRasterizer(_settings(viewpoint_camera, pc, bg_color, scaling_modifier,
+                                              getattr(pipe, "debug", False)))
+    dev = pc.get_xyz.device
+    audio_feat = viewpoint_camera.talking_dict["auds"].to(dev, non_blocking=True)
+    xyz = pc.get_xyz
+    p_motion_preds = None
+    if personalized or align:
+        p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat)
+    if align:
+        xyz = xyz + p_motion_preds["p_xyz"]
+    if not inference:
+        exp_feat = torch.zeros_like(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
+        motion_preds_face = motion_net_face(pc_face.get_xyz, audio_feat, exp_feat)
+    else:
+        motion_preds_face = motion_net_face.cache
+    with torch.no_grad():
+        dy = motion_preds_face["d_xyz"][..., 1]
+        motion_max = dy.topk(k, 0, True, True).values[-1]
+        motion_min = dy.topk(k, 0, False, True).values[-1]
+        move_feat = torch.stack([motion_max, motion_min, motion_max - motion_min]).reshape(1, 3) * 1e2
+    motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
+    d_xyz = motion_preds["d_xyz"]
+    if personalized:
+        d_xyz = d_xyz + p_motion_preds["d_xyz"]
+    means3D = pc.get_xyz + d_xyz
+    opacity = pc.get_opacity
+    image, depth, normal, alpha, radii, extra = rasterizer(
+        means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
+        scales=pc.get_scaling, rotations=pc.rotation_activation(pc._rotation), cov3Ds_precomp=None,
+        extra_attrs=_ones(opacity))
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "depth": depth,
+            "alpha": alpha, "radii": radii, "motion": motion_preds,
+            "p_motion": p_motion_preds if personalized or align else None}
+

@@ -168,6 +168,40 @@ def motion_nets():
     np.savez_compressed(f"{HERE}/g5_motion_nets.npz", **res)
 
 
+def mouth_nets():
+    """G7: the reference's MouthMotionNetwork and the mouth-type PMF forward on CPU (oracle grid encoder injected)."""
+    import types
+    from argparse import Namespace
+    sys.path.insert(0, ROOT)
+    from oracle import grid_torch
+    fake = types.ModuleType("gridencoder")
+    fake.GridEncoder = grid_torch.GridEncoder
+    sys.modules["gridencoder"] = fake
+    sys.path.insert(0, REF)
+    mn = _load(f"{REF}/scene/motion_net.py", "ref_motion_net_mouth")
+    sys.path.remove(REF)
+    torch.manual_seed(31)
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand(192, 3, generator=g) * 0.2 - 0.1
+    a = torch.randn(8, 29, 16, generator=g)
+    move = torch.randn(1, 3, generator=g)
+    res = dict(x=x.numpy(), a=a.numpy(), move=move.numpy())
+    args = Namespace(audio_extractor="deepspeech", type="mouth")
+    for tag, net, call in (("mouth", mn.MouthMotionNetwork(args=args), lambda n: n(x, a, move)),
+                           ("pmf_mouth", mn.PersonalizedMotionNetwork(args=args), lambda n: n(x, a))):
+        with torch.no_grad():
+            for n_, p_ in net.named_parameters():
+                if n_.endswith("embeddings"):        # fp16-representable values: stored as fp16 without loss
+                    p_.copy_((torch.randn(p_.shape, generator=g) * 0.1).half().float())
+        out = call(net)
+        for k_, v_ in net.state_dict().items():
+            res[f"{tag}.sd.{k_}"] = v_.numpy().astype(np.float16 if k_.endswith("embeddings") else v_.numpy().dtype)
+        for k_, v_ in out.items():
+            if v_ is not None:
+                res[f"{tag}.out.{k_}"] = v_.detach().numpy()
+    np.savez_compressed(f"{HERE}/g7_mouth_nets.npz", **res)
+
+
 if __name__ == "__main__":
     cameras()
     eval_sh()
@@ -175,4 +209,5 @@ if __name__ == "__main__":
     lr_schedule()
     sh_encoder_table()
     motion_nets()
+    mouth_nets()
     print("golden fixtures written to", HERE)

@@ -238,3 +238,47 @@ def test_create_from_pcd_uses_knn_scales():
     assert float((gm._scaling[:, 0].detach().cpu().double() - ref).abs().max()) < 1e-5
     assert gm.get_xyz.shape == (500, 3) and gm.get_features.shape == (500, 4, 3)
     assert float((gm.get_features[:, 0].detach().cpu() * 0.28209479177387814 + 0.5 - col).abs().max()) < 1e-6
+
+
+def test_mouth_branch_gpu_matches_cpu_modules():
+    """MouthMotionNetwork on the device (HIP grid encoders + fused MLPs) == the same module on the CPU with the oracle
+    grid encoder; render_motion_mouth_con runs end to end and reaches every mouth parameter with a gradient."""
+    import copy
+    from types import SimpleNamespace
+    from instag_amd.gaussian_model import GaussianModel
+    from instag_amd.motion_net import MotionNetwork, MouthMotionNetwork, PersonalizedMotionNetwork
+    from instag_amd.renderer import render_motion_mouth_con
+    from instag_amd.scene_synth import synthetic_frame, toy_cameras
+    from instag_amd.train import make_frame
+    from oracle.grid_torch import GridEncoder as CpuGrid
+    torch.manual_seed(5)
+    args = SimpleNamespace(audio_extractor="deepspeech", type="mouth")
+    cpu = MouthMotionNetwork(args=args, encoder_cls=CpuGrid)
+    with torch.no_grad():
+        for n_, p_ in cpu.named_parameters():
+            if n_.endswith("embeddings"):
+                p_.copy_(torch.randn(p_.shape) * 0.1)
+    dev = MouthMotionNetwork(args=args).cuda()
+    dev.load_state_dict(cpu.state_dict())
+    x = torch.rand(4000, 3) * 0.2 - 0.1
+    a, move = torch.randn(8, 29, 16), torch.tensor([[0.3, -0.2, 0.5]])
+    oc, od = cpu(x, a, move), dev(x.cuda(), a.cuda(), move.cuda())
+    for k in oc:
+        _close(od[k], oc[k], k, tol=2e-5)
+
+    # end to end: face model + face field feed the jaw-movement feature, mouth model is rendered
+    size = 96
+    frame = make_frame(toy_cameras(size)[0].to("cuda"), synthetic_frame(size, 0, "cuda"))
+    face_args = SimpleNamespace(audio_extractor="deepspeech", type="face")
+    pc_face = GaussianModel(1).create_random(1500, "cuda", seed=1)
+    face_net = MotionNetwork(args=face_args).cuda()
+    pc = GaussianModel(1, PersonalizedMotionNetwork(args=args).cuda()).create_random(800, "cuda", seed=2)
+    bg = torch.tensor([0.0, 0.0, 0.0], device="cuda")
+    pkg = render_motion_mouth_con(frame, pc, dev, pc_face, face_net, None, bg, align=True, k=10)
+    assert pkg["render"].shape == (3, size, size) and bool(torch.isfinite(pkg["render"]).all())
+    (pkg["render"].sum() + pkg["alpha"].sum()).backward()
+    for n_, p_ in list(dev.named_parameters()):
+        if not n_.startswith("aud_ch_att_net"):          # unused by the reference's forward as well
+            assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n_
+    assert pc._xyz.grad is not None and float(pc._xyz.grad.abs().max()) > 0
+    assert all(p_.grad is None for p_ in face_net.parameters())          # the movement feature carries no gradient

@@ -150,6 +150,29 @@ def test_motion_nets_match_reference(golden_dir):
             assert float((out[k].detach() - ref).abs().max()) <= 1e-6 + 1e-5 * float(ref.abs().max()), (tag, k)
 
 
+def test_mouth_nets_match_reference(golden_dir):
+    """MouthMotionNetwork and the mouth-type PMF == the reference's modules on the same weights (golden G7)."""
+    from argparse import Namespace
+    from instag_amd.motion_net import MouthMotionNetwork, PersonalizedMotionNetwork
+    from oracle.grid_torch import GridEncoder
+    g = np.load(f"{golden_dir}/g7_mouth_nets.npz")
+    x, a, move = (torch.from_numpy(g[k]) for k in ("x", "a", "move"))
+    args = Namespace(audio_extractor="deepspeech", type="mouth")
+    for tag, net, call in (("mouth", MouthMotionNetwork(args=args, encoder_cls=GridEncoder), lambda n: n(x, a, move)),
+                           ("pmf_mouth", PersonalizedMotionNetwork(args=args, encoder_cls=GridEncoder),
+                            lambda n: n(x, a))):
+        sd = {k[len(tag) + 4:]: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k])
+              for k in g.files if k.startswith(f"{tag}.sd.")}
+        net.load_state_dict(sd, strict=True)
+        out = call(net)
+        keys = [k[len(tag) + 5:] for k in g.files if k.startswith(f"{tag}.out.")]
+        assert keys
+        for k in keys:
+            ref = torch.from_numpy(g[f"{tag}.out.{k}"])
+            assert out[k].shape == ref.shape
+            assert float((out[k].detach() - ref).abs().max()) <= 1e-6 + 1e-5 * float(ref.abs().max()), (tag, k)
+
+
 def test_rasterizer_oracle_properties():
     """Compositing identity and visibility conventions of the oracle itself (C1: 2k Gaussians, 128x128)."""
     from tests.helpers import make_scene, oracle_settings
