@@ -221,3 +221,21 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
             "alpha": alpha, "radii": radii, "motion": motion_preds,
             "p_motion": p_motion_preds if personalized or align else None}
 
+
+def render_fuse(viewpoint_camera, pc, motion_net, pc_mouth, motion_net_mouth, pipe=None, bg_color=None,
+                scene_background=None, personalized=False, inference=False, k=10):
+    """Face + mouth composition of the fuse stage: train_fuse_con.py:102-121 (training: both passes carry gradients
+    and were rendered over ``bg_color``, which is taken out again) / synthesize_fuse.py:46-66 (inference: the mouth
+    field reads the face field's cached motion).  ``scene_background`` [3,H,W] in [0,1] is what shows through both.
+    -> dict(image, face=<render_motion pkg>, mouth=<render_motion_mouth_con pkg>)."""
+    face = render_motion(viewpoint_camera, pc, motion_net, pipe, bg_color, personalized=personalized, align=True)
+    mouth = render_motion_mouth_con(viewpoint_camera, pc_mouth, motion_net_mouth, pc, motion_net, pipe, bg_color,
+                                    personalized=personalized, align=True, k=k, inference=inference)
+    alpha, alpha_mouth = face["alpha"], mouth["alpha"]
+    bg3 = bg_color[:, None, None]
+    if scene_background is None:
+        scene_background = torch.zeros_like(face["render"])
+    mouth_image = mouth["render"] - bg3 * (1.0 - alpha_mouth) + scene_background * (1.0 - alpha_mouth)
+    image = face["render"] - bg3 * (1.0 - alpha) + mouth_image * (1.0 - alpha)
+    return {"image": image, "mouth_image": mouth_image, "face": face, "mouth": mouth}
+

@@ -282,3 +282,14 @@ def test_mouth_branch_gpu_matches_cpu_modules():
             assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n_
     assert pc._xyz.grad is not None and float(pc._xyz.grad.abs().max()) > 0
     assert all(p_.grad is None for p_ in face_net.parameters())          # the movement feature carries no gradient
+
+    # fuse stage: face over mouth over the scene background; with a zero bg_color it is plain "over" compositing
+    from instag_amd.renderer import render_fuse
+    pc_face.neural_motion_grid = PersonalizedMotionNetwork(args=face_args).cuda()
+    scene_bg = torch.rand(3, size, size, device="cuda")
+    out = render_fuse(frame, pc_face, face_net, pc, dev, None, bg, scene_background=scene_bg)
+    fa, ma = out["face"]["alpha"], out["mouth"]["alpha"]
+    expect = out["face"]["render"] + (out["mouth"]["render"] + scene_bg * (1 - ma)) * (1 - fa)
+    assert float((out["image"] - expect).abs().max()) <= 1e-6
+    out["image"].sum().backward()
+    assert any(p_.grad is not None for p_ in face_net.parameters())
