@@ -379,6 +379,8 @@ class MouthMotionNetwork(nn.Module):
                              self.num_layers)
         self.scaler_net = MLP(self.in_dim + self.move_dim, 1, 16, 3)
         self.aud_ch_att_net = MLP(self.in_dim, audio_dim, 32, 2)     # present in the reference, unused in forward
+        # d_xyz = h[:, :3] * 1e-2 with x and z divided by 5 (motion_net.py:446-450); not part of the state_dict
+        self.register_buffer("_xyz_scale", torch.tensor([1e-2 / 5, 1e-2, 1e-2 / 5]), persistent=False)
 
     encode_x = _TriPlaneField.encode_x
 
@@ -394,8 +396,7 @@ class MouthMotionNetwork(nn.Module):
         move = move.repeat(n, 1)
         h = self.sigma_net(torch.cat([enc_x, enc_a.repeat(n, 1), move], dim=-1))
         h_s = self.scaler_net(torch.cat([enc_x, move], dim=-1))
-        # d_xyz = h[:, :3] * 1e-2 with x and z divided by 5 (motion_net.py:446-450), without the in-place edits
-        d_xyz = h[..., :3] * h.new_tensor([1e-2 / 5, 1e-2, 1e-2 / 5])
+        d_xyz = h[..., :3] * self._xyz_scale           # the reference's in-place edits as one multiply
         return {"d_xyz": d_xyz * torch.sigmoid(h_s) * 2, "d_rot": h[..., 3:]}
 
     def get_params(self, lr, lr_net, wd=0):

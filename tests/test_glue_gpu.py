@@ -293,3 +293,35 @@ def test_mouth_branch_gpu_matches_cpu_modules():
     assert float((out["image"] - expect).abs().max()) <= 1e-6
     out["image"].sum().backward()
     assert any(p_.grad is not None for p_ in face_net.parameters())
+
+
+def test_fuse_renderer_graph_matches_eager():
+    """Inference path: the captured forward-only frame == the eager one, frame after frame."""
+    from types import SimpleNamespace
+    from instag_amd import diff_gauss
+    from instag_amd.gaussian_model import GaussianModel
+    from instag_amd.infer import FuseRenderer
+    from instag_amd.motion_net import MotionNetwork, MouthMotionNetwork, PersonalizedMotionNetwork
+    from instag_amd.scene_synth import synthetic_frame, toy_cameras
+    from instag_amd.train import make_frame
+    torch.manual_seed(9)
+    size = 96
+    face_args = SimpleNamespace(audio_extractor="deepspeech", type="face")
+    mouth_args = SimpleNamespace(audio_extractor="deepspeech", type="mouth")
+    pc = GaussianModel(1, PersonalizedMotionNetwork(args=face_args).cuda()).create_random(3000, "cuda", seed=1)
+    pcm = GaussianModel(1, PersonalizedMotionNetwork(args=mouth_args).cuda()).create_random(800, "cuda", seed=2)
+    net, netm = MotionNetwork(args=face_args).cuda(), MouthMotionNetwork(args=mouth_args).cuda()
+    cams = toy_cameras(size)
+    frames = [make_frame(cams[i].to("cuda"), synthetic_frame(size, i, "cuda")) for i in range(3)]
+    bg = torch.zeros(3, device="cuda")
+    r = FuseRenderer(pc, net, pcm, netm, bg)
+    try:
+        eager = [r.render(f).clone() for f in frames]
+        r.enable_graph(frames[0])
+        for f, e in zip(frames, eager):
+            got = r.render(f)
+            assert not r.check_overflow()
+            assert torch.equal(got, e)
+    finally:
+        r.close()
+        diff_gauss.set_capacity_plan(None)
