@@ -366,7 +366,7 @@ grid_tv_kernel(const float* __restrict__ inputs, const float* __restrict__ grid,
 
 inline unsigned fwd_blocks(uint32_t B) { return (unsigned)std::min<uint32_t>(div_up<uint32_t>(B, GRID_BLOCK), 2048u); }
 inline unsigned bwd_blocks(uint32_t B) {
-  static const unsigned cap = getenv("INSTAG_GRID_BWD_BLOCKS") ? (unsigned)atoi(getenv("INSTAG_GRID_BWD_BLOCKS")) : 256u;
+  constexpr unsigned cap = 256u;      // one workgroup per CU: the LDS-private table copy is flushed once per workgroup
   return (unsigned)std::min<uint32_t>(div_up<uint32_t>(B, GRID_BLOCK), cap);
 }
 

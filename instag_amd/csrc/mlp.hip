@@ -406,9 +406,7 @@ inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256))
 
 // Two workgroups per CU, each staging the weights once and walking a strided list of 32-row tiles.
 inline int mlp_blocks(int ntiles) {
-  int b = 512;
-  if (const char* e = getenv("INSTAG_MLP_BLOCKS")) b = std::max(1, atoi(e));
-  return std::max(1, std::min(b, (ntiles + 3) / 4));
+  return std::max(1, std::min(512, (ntiles + 3) / 4));
 }
 
 template <int KB0, int HB, int NL>

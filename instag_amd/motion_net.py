@@ -387,6 +387,10 @@ class MouthMotionNetwork(nn.Module):
     def encode_audio(self, a):
         if a is None:
             return None
+        if a.is_cuda:
+            from . import audio as _audio
+            if _audio.supported(self, a, None):
+                return _audio.frame_codes(self, a, None)[0]       # AudioNet + AudioAttNet in one workgroup
         return self.audio_att_net(self.audio_net(a).unsqueeze(0))
 
     def forward(self, x, a, move):
