@@ -218,10 +218,12 @@ grid_forward_kernel(const float* __restrict__ inputs, const float* __restrict__ 
   }
 }
 
+// LDS: the accumulators are 64-bit fixed-point integers (LDS float atomics run about one lane at a time on gfx950,
+// integer ones at full rate; see the tri-plane kernel below) scaled by `to_fixed`; otherwise global float atomics.
 template <uint32_t D, uint32_t C, bool LDS>
-__device__ __forceinline__ void scatter_level(float* acc, const LevelGeom& lg, const float x[D],
-                                              uint32_t gridtype, bool align_corners, uint32_t interp,
-                                              const float g[C]) {
+__device__ __forceinline__ void scatter_level(float* acc, unsigned long long* acc_fixed, double to_fixed,
+                                              const LevelGeom& lg, const float x[D], uint32_t gridtype,
+                                              bool align_corners, uint32_t interp, const float g[C]) {
   float pos[D], pos_deriv[D];
   uint32_t pos_grid[D];
   locate<D>(x, lg.scale, align_corners, interp, pos, pos_deriv, pos_grid);
@@ -237,11 +239,19 @@ __device__ __forceinline__ void scatter_level(float* acc, const LevelGeom& lg, c
     const uint32_t index = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pg) * C;
 #pragma unroll
     for (uint32_t ch = 0; ch < C; ++ch) {
-      const float v = w * g[ch];
-      if (LDS) __hip_atomic_fetch_add(&acc[index + ch], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      else atomicAdd(&acc[index + ch], v);
+      if (LDS) atomicAdd(&acc_fixed[index + ch], (unsigned long long)__double2ll_rn((double)w * (double)g[ch] * to_fixed));
+      else atomicAdd(&acc[index + ch], w * g[ch]);
     }
   }
+}
+
+constexpr uint32_t LDS_BWD_ENTRIES = 16384;      // 128 KB of 64-bit accumulators: one workgroup per CU
+
+__device__ __forceinline__ uint32_t group_end_bwd(const int32_t* __restrict__ offsets, uint32_t level, uint32_t L, uint32_t C) {
+  const uint32_t base = (uint32_t)offsets[level];
+  uint32_t lend = level;
+  while (lend < L && ((uint32_t)offsets[lend + 1] - base) * C <= LDS_BWD_ENTRIES) ++lend;
+  return lend;
 }
 
 template <uint32_t D, uint32_t C>
@@ -250,10 +260,31 @@ grid_backward_kernel(const float* __restrict__ grad, const float* __restrict__ i
                      const int32_t* __restrict__ offsets, float* __restrict__ grad_grid, uint32_t B, uint32_t L,
                      float S, uint32_t H, const float* __restrict__ dy_dx, float* __restrict__ grad_inputs,
                      uint32_t gridtype, bool align_corners, uint32_t interp) {
-  extern __shared__ __align__(16) float s_acc[];
+  extern __shared__ __align__(16) unsigned long long s_acc[];
+  __shared__ float s_wmax[GRID_BLOCK / 64];
   const uint32_t per_block = (B + gridDim.x - 1) / gridDim.x;
   const uint32_t b0 = blockIdx.x * per_block;
   const uint32_t b1 = min(B, b0 + per_block);
+
+  // fixed-point scale of this workgroup: |sum into one entry| <= (#points) * max|grad| < 2^62
+  float gmax = 0.f;
+  for (uint32_t l = 0; l < L; ++l)
+    for (uint32_t i = b0 * C + threadIdx.x; i < b1 * C; i += GRID_BLOCK) gmax = fmaxf(gmax, fabsf(grad[(size_t)l * B * C + i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = gmax;
+  __syncthreads();
+  gmax = s_wmax[0];
+#pragma unroll
+  for (int w = 1; w < GRID_BLOCK / 64; ++w) gmax = fmaxf(gmax, s_wmax[w]);
+  const bool usable = gmax > 0.f && gmax < INFINITY;
+  int shift = 0;
+  if (usable) {
+    int npts_log2 = 1;
+    while ((1u << npts_log2) < per_block) ++npts_log2;
+    shift = 60 - (ilogbf(gmax) + 1) - npts_log2;
+  }
+  const double to_fixed = ldexp(1.0, shift), to_float = ldexp(1.0, -shift);
 
   // fused kernel_input_backward: grad_inputs[b,d] += sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]
   if (dy_dx && grad_inputs) {
@@ -276,7 +307,7 @@ grid_backward_kernel(const float* __restrict__ grad, const float* __restrict__ i
 
   uint32_t level = 0;
   while (level < L) {
-    const uint32_t lend = group_end(offsets, level, L, C);
+    const uint32_t lend = usable ? group_end_bwd(offsets, level, L, C) : level;
     if (lend == level) {
       const LevelGeom lg = level_geom(offsets, level, S, H);
       float* acc = grad_grid + (size_t)(uint32_t)offsets[level] * C;
@@ -286,7 +317,7 @@ grid_backward_kernel(const float* __restrict__ grad, const float* __restrict__ i
         float g[C];
 #pragma unroll
         for (uint32_t ch = 0; ch < C; ++ch) g[ch] = grad[(size_t)level * B * C + (size_t)b * C + ch];
-        scatter_level<D, C, false>(acc, lg, x, gridtype, align_corners, interp, g);
+        scatter_level<D, C, false>(acc, nullptr, 0.0, lg, x, gridtype, align_corners, interp, g);
       }
       ++level;
       continue;
@@ -294,7 +325,7 @@ grid_backward_kernel(const float* __restrict__ grad, const float* __restrict__ i
     const uint32_t base = (uint32_t)offsets[level];
     const uint32_t n = ((uint32_t)offsets[lend] - base) * C;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += GRID_BLOCK) s_acc[i] = 0.f;
+    for (uint32_t i = threadIdx.x; i < n; i += GRID_BLOCK) s_acc[i] = 0ull;
     __syncthreads();
     for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
       float x[D];
@@ -304,13 +335,14 @@ grid_backward_kernel(const float* __restrict__ grad, const float* __restrict__ i
         float g[C];
 #pragma unroll
         for (uint32_t ch = 0; ch < C; ++ch) g[ch] = grad[(size_t)l * B * C + (size_t)b * C + ch];
-        scatter_level<D, C, true>(s_acc + ((uint32_t)offsets[l] - base) * C, lg, x, gridtype, align_corners, interp, g);
+        scatter_level<D, C, true>(nullptr, s_acc + ((uint32_t)offsets[l] - base) * C, to_fixed, lg, x, gridtype,
+                                  align_corners, interp, g);
       }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n; i += GRID_BLOCK) {
-      const float v = s_acc[i];
-      if (v != 0.f) atomicAdd(&grad_grid[(size_t)base * C + i], v);
+      const long long a = (long long)s_acc[i];
+      if (a != 0) atomicAdd(&grad_grid[(size_t)base * C + i], (float)((double)a * to_float));
     }
     level = lend;
   }
@@ -385,7 +417,14 @@ int run_backward(const float* grad, const float* inputs, const int32_t* offsets,
                  uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs, uint32_t gridtype,
                  bool align, uint32_t interp, hipStream_t s) {
   ProfScope p(K_GRID_BWD, s);
-  grid_backward_kernel<D, C><<<bwd_blocks(B), GRID_BLOCK, LDS_BUDGET_FLOATS * sizeof(float), s>>>(
+  static bool attr_set = false;       // per <D, C> instantiation
+  if (!attr_set) {
+    INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_backward_kernel<D, C>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(LDS_BWD_ENTRIES * sizeof(unsigned long long))));
+    attr_set = true;
+  }
+  grid_backward_kernel<D, C><<<bwd_blocks(B), GRID_BLOCK, LDS_BWD_ENTRIES * sizeof(unsigned long long), s>>>(
       grad, inputs, offsets, grad_emb, B, L, S, H, dy_dx, grad_inputs, gridtype, align, interp);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
