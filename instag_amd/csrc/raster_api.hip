@@ -200,7 +200,6 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   const Camera c = make_camera(a);
   const int tiles = c.grid_x * c.grid_y;
   int32_t* ranges = (int32_t*)(ib + IL.ranges);
-  INSTAG_CHECK_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(int32_t), s));
   uint32_t* keys_u = (uint32_t*)(bb + BL.keys_unsorted);
   uint32_t* vals_u = (uint32_t*)(bb + BL.vals_unsorted);
   uint32_t* keys = (uint32_t*)(bb + BL.keys);
@@ -208,12 +207,12 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   uint32_t* gid_u = (uint32_t*)(bb + BL.gid_unsorted);
   uint32_t* point_list = (uint32_t*)(bb + BL.point_list);
   if (R > 0 && a->N > 0) {
-    if (pad) INSTAG_CHECK_HIP(hipMemsetAsync(keys_u, 0xFF, (size_t)R * sizeof(uint32_t), s));
+    // the duplicate kernel also clears the tile ranges and (capacity mode) pads the unused key slots
     if (int e = launch_duplicate(c, (float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.order),
                                  (const uint32_t*)(gb + GL.tt_sorted),
                                  (const uint32_t*)(gb + GL.point_offsets), (const uint32_t*)(gb + GL.flags),
                                  (const float*)(gb + GL.cull_thr), keys_u,
-                                 vals_u, gid_u, (uint32_t)R, s)) return e;
+                                 vals_u, gid_u, (uint32_t)R, pad, ranges, s)) return e;
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;
     {
@@ -223,6 +222,8 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
                                                  tile_bits > 0 ? tile_bits : 1, s));
     }
     if (int e = launch_ranges(R, keys, vals, gid_u, point_list, ranges, (uint32_t)tiles, s)) return e;
+  } else {
+    INSTAG_CHECK_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(int32_t), s));
   }
   return launch_blend_forward(c, ranges, point_list, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
                               (float*)(ib + IL.final_T), out_color, out_depth, out_normal, out_alpha,

@@ -22,7 +22,8 @@ int launch_export_keys(int64_t R, const uint32_t* tile_keys, const uint32_t* poi
                        uint64_t* keys64, hipStream_t s);
 int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order, const uint32_t* tt_sorted,
                      const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint32_t* keys,
-                     uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, hipStream_t s);
+                     uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, bool pad, int32_t* ranges,
+                     hipStream_t s);
 int launch_ranges(int64_t R, const uint32_t* keys_sorted, const uint32_t* slots_sorted, const uint32_t* gid_unsorted,
                   uint32_t* point_list, int32_t* ranges, uint32_t ntiles, hipStream_t s);
 int launch_status(int N, const uint32_t* point_offsets, uint32_t capacity, int32_t* status, hipStream_t s);

@@ -240,8 +240,16 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
                  const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ point_offsets,
                  const uint32_t* __restrict__ flags, const float* __restrict__ cull_thr,
                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ gid_unsorted,
-                 uint32_t capacity) {
+                 uint32_t capacity, uint32_t pad_to, int32_t* __restrict__ ranges, uint32_t nranges) {
   const int i = blockIdx.x * 256 + threadIdx.x;      // rank in depth order
+  // housekeeping that used to be two memsets: unused instance slots get all-ones keys (they sort last and own no
+  // tile range), the tile ranges start out empty
+  {
+    const uint32_t total = gridDim.x * 256u;
+    const uint32_t used = min(point_offsets[N - 1], capacity);
+    for (uint32_t k = used + (uint32_t)i; k < pad_to; k += total) keys[k] = 0xFFFFFFFFu;
+    for (uint32_t k = (uint32_t)i; k < nranges; k += total) ranges[k] = 0;
+  }
   if (i >= N) return;
   const uint32_t tt = tt_sorted[i];
   if (tt == 0) return;
@@ -342,11 +350,13 @@ int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d
 
 int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order, const uint32_t* tt_sorted,
                      const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint32_t* keys,
-                     uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, hipStream_t s) {
+                     uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, bool pad, int32_t* ranges,
+                     hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_DUPLICATE, s);
   duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, order, tt_sorted, point_offsets, flags,
-                                                     cull_thr, keys, vals, gid_unsorted, capacity);
+                                                     cull_thr, keys, vals, gid_unsorted, capacity, pad ? capacity : 0u,
+                                                     ranges, (uint32_t)(2 * c.grid_x * c.grid_y));
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -38,12 +38,9 @@ def _settings(cam, pc, bg_color, scaling_modifier, debug=False):
 
 
 def _screenspace_points(pc):
-    pts = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
-    try:
-        pts.retain_grad()
-    except Exception:
-        pass
-    return pts
+    # gradient carrier of the screen-space means (gaussian_renderer/__init__.py:47-52 builds it as zeros + 0 with
+    # retain_grad(); a leaf receives the same .grad and saves a launch)
+    return torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True)
 
 
 def render(viewpoint_camera, pc, pipe=None, bg_color=None, scaling_modifier=1.0, override_color=None):
