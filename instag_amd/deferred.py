@@ -23,8 +23,30 @@ import torch
 from . import _lib
 from ._lib import check, ptr
 
-_STATE = {"active": False, "jobs": []}
+_STATE = {"active": False, "jobs": [], "streams": {}, "forked": set()}
 MAX_JOBS = 16
+
+
+def flush_async(device):
+    """Launch the weight gradients queued so far NOW, on a side stream behind the current stream's tail, and keep
+    going: called by the trainer at a point of the backward pass where most jobs are queued and a long chain that
+    does not depend on them is about to start (the personalised field's backward).  The block's exit joins."""
+    if not _STATE["active"] or not _STATE["jobs"]:
+        return
+    device = torch.device(device)
+    jobs, _STATE["jobs"] = _STATE["jobs"], []
+    key = (device.type, device.index)
+    side = _STATE["streams"].get(key)
+    if side is None:
+        side = _STATE["streams"][key] = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        _flush(jobs)
+    for dz, inp, _ in jobs:
+        dz.record_stream(side)
+        inp.record_stream(side)
+    _STATE["forked"].add(key)
 
 
 def active() -> bool:
@@ -85,4 +107,7 @@ class deferred_grads:
         jobs, _STATE["jobs"] = _STATE["jobs"], []
         if exc_type is None and jobs:
             _flush(jobs)
+        for typ, idx in _STATE["forked"]:
+            torch.cuda.current_stream(torch.device(typ, idx)).wait_stream(_STATE["streams"][(typ, idx)])
+        _STATE["forked"] = set()
         return False

@@ -96,6 +96,11 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         p_raw = p_motion_preds.get("_p")
         # xyz + p_xyz with p_xyz = p[:, :3] * 1e-2 as one launch
         xyz = torch.add(xyz, p_raw[..., :3], alpha=1e-2) if p_raw is not None else xyz + p_motion_preds["p_xyz"]
+        if xyz.is_cuda and xyz.requires_grad:
+            # backward reaches this point when the universal field is done and the personalised field's chain is
+            # about to start: the weight gradients queued so far can run beside it (instag_amd/deferred.py)
+            from . import deferred
+            xyz.register_hook(lambda g, dev=dev: deferred.flush_async(dev))
     motion_preds = motion_net(xyz, audio_feat, exp_feat)
 
     fused = (align and not personalized and not detach_motion and pc.get_xyz.is_cuda
