@@ -115,12 +115,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # rehearsal knobs (several ranks on ONE card over gloo); the driver's runs use neither
+    if os.environ.get("INSTAG_BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["INSTAG_BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("INSTAG_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from instag_amd import _lib, diff_gauss
     from instag_amd.scene_synth import synthetic_frame, toy_cameras

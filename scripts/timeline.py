@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Print one step's kernel timeline from a rocprofv3 kernel trace: start offset, duration, queue, name.
-    python scripts/timeline.py <dir> <step index (counted by pairs of adam_step launches)>"""
+    python scripts/timeline.py <dir> <step index (counted by adam_step launches)>"""
 import csv, glob, re, sys
 d = sys.argv[1]; step = int(sys.argv[2])
 f = glob.glob(f'{d}/*/*_kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-ends = [i for i, r in enumerate(rows) if 'adam_step_kernel' in r['Kernel_Name']]
-a = ends[2 * step - 1] + 1 if step > 0 else 0
-b = ends[2 * step + 1] + 1
+ends = [i for i, r in enumerate(rows) if 'adam_step_kernel' in r['Kernel_Name']]      # one launch per step
+a = ends[step - 1] + 1 if step > 0 else 0
+b = ends[step] + 1
 sub = rows[a:b]
 t0 = int(sub[0]['Start_Timestamp'])
 def short(n):
