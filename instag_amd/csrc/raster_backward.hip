@@ -44,6 +44,7 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
     const uint32_t tt = tiles_touched[g];
     const uint32_t off = __float_as_uint(rec2d[(size_t)g * REC_FLOATS + R_OFFSET]);
     const float4* rows = reinterpret_cast<const float4*>(inst_grad + (size_t)off * REC_FLOATS);
+#pragma unroll 4      // several 64-B rows in flight per thread (the rows of a Gaussian are contiguous)
     for (uint32_t t = 0; t < tt; ++t) {
       const float4 q0 = rows[4 * t + 0], q1 = rows[4 * t + 1], q2 = rows[4 * t + 2], q3 = rows[4 * t + 3];
       gs[0] += q0.x; gs[1] += q0.y; gs[2] += q0.z; gs[3] += q0.w;
@@ -293,6 +294,7 @@ aux_backward_reduce_kernel(Camera c, const float* __restrict__ rec2d, const uint
     const uint32_t off = __float_as_uint(rec2d[(size_t)g * REC_FLOATS + R_OFFSET]);
     if ((uint64_t)off + tt <= (uint64_t)capacity) {
       const float4* rows = reinterpret_cast<const float4*>(inst_grad + (size_t)off * REC_FLOATS);
+#pragma unroll 4
       for (uint32_t t = 0; t < tt; ++t) {
         const float4 q0 = rows[4 * t + 0], q1 = rows[4 * t + 1], q2 = rows[4 * t + 2];
         gx += q0.x; gy += q0.y;
