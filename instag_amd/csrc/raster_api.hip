@@ -92,9 +92,11 @@ BinningLayout binning_layout(int64_t R) {
   L.vals = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.gid_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.point_list = o; o = align_up(o + r * sizeof(uint32_t), 256);
-  size_t tmp = 0;
+  size_t tmp = 0, tmp_keys = 0;
   (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                   (uint32_t*)nullptr, r, 0, 32);
+  (void)rocprim::radix_sort_keys(nullptr, tmp_keys, (uint32_t*)nullptr, (uint32_t*)nullptr, r, 0, 32);
+  tmp = std::max(tmp, tmp_keys);
   L.sort_temp = o; L.sort_temp_bytes = tmp; o = align_up(o + tmp, 256);
   L.total = o;
   return L;
@@ -206,22 +208,28 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   uint32_t* vals = (uint32_t*)(bb + BL.vals);
   uint32_t* gid_u = (uint32_t*)(bb + BL.gid_unsorted);
   uint32_t* point_list = (uint32_t*)(bb + BL.point_list);
+  const bool packed = use_packed_keys(R, tiles);
   if (R > 0 && a->N > 0) {
     // the duplicate kernel also clears the tile ranges and (capacity mode) pads the unused key slots
     if (int e = launch_duplicate(c, (float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.order),
                                  (const uint32_t*)(gb + GL.tt_sorted),
                                  (const uint32_t*)(gb + GL.point_offsets), (const uint32_t*)(gb + GL.flags),
                                  (const float*)(gb + GL.cull_thr), keys_u,
-                                 vals_u, gid_u, (uint32_t)R, pad, ranges, s)) return e;
+                                 vals_u, gid_u, (uint32_t)R, pad, ranges, packed, s)) return e;
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;
     {
       ProfScope p(K_SORT, s);
       size_t tmp = BL.sort_temp_bytes;
-      INSTAG_CHECK_HIP(rocprim::radix_sort_pairs(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0,
-                                                 tile_bits > 0 ? tile_bits : 1, s));
+      const int bits = tile_bits > 0 ? tile_bits : 1;
+      if (packed)
+        INSTAG_CHECK_HIP(rocprim::radix_sort_keys(bb + BL.sort_temp, tmp, keys_u, keys, (size_t)R, PACK_SHIFT,
+                                                  PACK_SHIFT + bits, s));
+      else
+        INSTAG_CHECK_HIP(rocprim::radix_sort_pairs(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0,
+                                                   bits, s));
     }
-    if (int e = launch_ranges(R, keys, vals, gid_u, point_list, ranges, (uint32_t)tiles, s)) return e;
+    if (int e = launch_ranges(R, keys, vals, gid_u, point_list, ranges, (uint32_t)tiles, packed, s)) return e;
   } else {
     INSTAG_CHECK_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(int32_t), s));
   }
@@ -355,7 +363,8 @@ int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* 
     if (binning_bytes < BL.total) { set_error("binning buffer too small"); return INSTAG_E_SPACE; }
     if (keys_sorted) {
       if (int e = launch_export_keys(R, (const uint32_t*)(bb + BL.keys), (const uint32_t*)(bb + BL.point_list),
-                                     (const float*)(gb + GL.rec2d), keys_sorted, s)) return e;
+                                     (const float*)(gb + GL.rec2d), keys_sorted,
+                                     use_packed_keys(R, (int)tiles), s)) return e;
     }
     INSTAG_CHECK_HIP(cp(point_list, bb + BL.point_list, (size_t)R * 4));
   }

@@ -240,7 +240,7 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
                  const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ point_offsets,
                  const uint32_t* __restrict__ flags, const float* __restrict__ cull_thr,
                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ gid_unsorted,
-                 uint32_t capacity, uint32_t pad_to, int32_t* __restrict__ ranges, uint32_t nranges) {
+                 uint32_t capacity, uint32_t pad_to, int32_t* __restrict__ ranges, uint32_t nranges, int packed) {
   const int i = blockIdx.x * 256 + threadIdx.x;      // rank in depth order
   // housekeeping that used to be two memsets: unused instance slots get all-ones keys (they sort last and own no
   // tile range), the tile ranges start out empty
@@ -265,8 +265,13 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
   for (int y = rminy; y < rminy + rh; ++y) {
     for (int x = rminx; x < rminx + rw; ++x) {
       if (!tile_kept(px, py, A, B, C, thr, x, y)) continue;
-      keys[off] = (uint32_t)(y * grid_x + x);
-      vals[off] = off;
+      const uint32_t tile = (uint32_t)(y * grid_x + x);
+      if (packed) {
+        keys[off] = (tile << PACK_SHIFT) | off;          // key-only sort: the slot rides in the low bits
+      } else {
+        keys[off] = tile;
+        vals[off] = off;
+      }
       gid_unsorted[off] = g;
       ++off;
     }
@@ -283,26 +288,34 @@ gather_counts_kernel(int N, const uint32_t* __restrict__ tiles_touched, const ui
 // debug / parity: the 64-bit (tile<<32 | depth bits) key of every sorted instance
 __global__ void __launch_bounds__(256)
 export_keys_kernel(int64_t R, const uint32_t* __restrict__ tile_keys, const uint32_t* __restrict__ point_list,
-                   const float* __restrict__ rec2d, uint64_t* __restrict__ keys64) {
+                   const float* __restrict__ rec2d, uint64_t* __restrict__ keys64, int packed) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
   const uint32_t depth_bits = __float_as_uint(rec2d[(size_t)point_list[i] * REC_FLOATS + R_DEPTH]);
-  keys64[i] = ((uint64_t)tile_keys[i] << 32) | depth_bits;
+  const uint32_t tile = packed ? tile_keys[i] >> PACK_SHIFT : tile_keys[i];
+  keys64[i] = ((uint64_t)tile << 32) | depth_bits;
 }
 
 __global__ void __launch_bounds__(256)
-ranges_kernel(int64_t R, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ slots_sorted,
+ranges_kernel(int64_t R, const uint32_t* __restrict__ keys, uint32_t* __restrict__ slots_sorted,
               const uint32_t* __restrict__ gid_unsorted, uint32_t* __restrict__ point_list,
-              int32_t* __restrict__ ranges, uint32_t ntiles) {
+              int32_t* __restrict__ ranges, uint32_t ntiles, int packed) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= R) return;
-  if (keys[i] < ntiles) point_list[i] = gid_unsorted[slots_sorted[i]];
   // tile ids >= ntiles are the all-ones padding keys of capacity mode: they sort last and own no range
-  const uint32_t tile = keys[i];
+  auto tile_of = [&](uint32_t k) { return packed ? (k == 0xFFFFFFFFu ? 0xFFFFFFFFu : k >> PACK_SHIFT) : k; };
+  const uint32_t key = keys[i];
+  const uint32_t tile = tile_of(key);
+  if (tile < ntiles) {
+    uint32_t slot;
+    if (packed) { slot = key & ((1u << PACK_SHIFT) - 1u); slots_sorted[i] = slot; }
+    else slot = slots_sorted[i];
+    point_list[i] = gid_unsorted[slot];
+  }
   if (i == 0) {
     if (tile < ntiles) ranges[2 * tile] = 0;
   } else {
-    const uint32_t prev = keys[i - 1];
+    const uint32_t prev = tile_of(keys[i - 1]);
     if (prev != tile) {
       if (prev < ntiles) ranges[2 * prev + 1] = (int32_t)i;
       if (tile < ntiles) ranges[2 * tile] = (int32_t)i;
@@ -351,12 +364,12 @@ int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d
 int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order, const uint32_t* tt_sorted,
                      const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint32_t* keys,
                      uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, bool pad, int32_t* ranges,
-                     hipStream_t s) {
+                     bool packed, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_DUPLICATE, s);
   duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, order, tt_sorted, point_offsets, flags,
                                                      cull_thr, keys, vals, gid_unsorted, capacity, pad ? capacity : 0u,
-                                                     ranges, (uint32_t)(2 * c.grid_x * c.grid_y));
+                                                     ranges, (uint32_t)(2 * c.grid_x * c.grid_y), packed ? 1 : 0);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -369,19 +382,20 @@ int launch_gather_counts(int N, const uint32_t* tiles_touched, const uint32_t* o
 }
 
 int launch_export_keys(int64_t R, const uint32_t* tile_keys, const uint32_t* point_list, const float* rec2d,
-                       uint64_t* keys64, hipStream_t s) {
+                       uint64_t* keys64, bool packed, hipStream_t s) {
   if (R == 0) return INSTAG_OK;
-  export_keys_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, tile_keys, point_list, rec2d, keys64);
+  export_keys_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, tile_keys, point_list, rec2d, keys64,
+                                                                       packed ? 1 : 0);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
-int launch_ranges(int64_t R, const uint32_t* keys_sorted, const uint32_t* slots_sorted, const uint32_t* gid_unsorted,
-                  uint32_t* point_list, int32_t* ranges, uint32_t ntiles, hipStream_t s) {
+int launch_ranges(int64_t R, const uint32_t* keys_sorted, uint32_t* slots_sorted, const uint32_t* gid_unsorted,
+                  uint32_t* point_list, int32_t* ranges, uint32_t ntiles, bool packed, hipStream_t s) {
   if (R == 0) return INSTAG_OK;
   ProfScope p(K_RANGES, s);
   ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, keys_sorted, slots_sorted, gid_unsorted,
-                                                                  point_list, ranges, ntiles);
+                                                                  point_list, ranges, ntiles, packed ? 1 : 0);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
