@@ -247,15 +247,20 @@ int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const f
                                 const float* enc_a, const float* enc_e, const float* amb, float* d_enc_x,
                                 float* d_aud, float* d_eye_pre, float* col_partials, int32_t N,
                                 int32_t KX, int32_t KA, int32_t KE, instag_stream_t stream);
+/* reg_partials (may be NULL): instag_deform_activate_num_reg_partials(N) per-workgroup partial sums of
+ * reg_weight * motion_l1_reg(h, p) (same terms as instag_motion_l1_reg_*), to be added up by the consumer, e.g. as the
+ * `extra` array of instag_face_loss_forward.  backward: g_reg (device scalar, may be NULL) is the upstream gradient of
+ * that sum; its sign terms are added into d_h / d_p. */
+int instag_deform_activate_num_reg_partials(int32_t N);
 int instag_deform_activate_forward(const float* xyz, const float* scaling, const float* rotation,
                                    const float* opacity, const float* h, const float* p, float* means3D,
-                                   float* scales, float* rotations, float* opac, int32_t N,
-                                   instag_stream_t stream);
+                                   float* scales, float* rotations, float* opac, float* reg_partials,
+                                   float reg_weight, int32_t N, instag_stream_t stream);
 int instag_deform_activate_backward(const float* scaling, const float* rotation, const float* opacity,
                                     const float* h, const float* p, const float* g_means, const float* g_scales,
                                     const float* g_rots, const float* g_opac, float* d_xyz, float* d_scaling,
-                                    float* d_rotation, float* d_opacity, float* d_h, float* d_p, int32_t N,
-                                    instag_stream_t stream);
+                                    float* d_rotation, float* d_opacity, float* d_h, float* d_p, const float* g_reg,
+                                    float reg_weight, int32_t N, instag_stream_t stream);
 int instag_motion_l1_reg_num_partials(int32_t N);
 int instag_motion_l1_reg_forward(const float* h, const float* p, float* partial, int32_t N,
                                  instag_stream_t stream);
@@ -320,7 +325,8 @@ int instag_l1_ssim_backward(const float* img1, const float* img2, const float* m
  *        + w_alpha (mean((1-alpha) head) + mean(alpha ~head))                      [FLAG_ALPHA]
  *        + w_attn_hair (mean(attn[1][hair]) + mean(attn[0][hair]))                 [FLAG_HAIR_ATTN]
  *        + w_attn_lips mean(attn[1, r0:r1, c0:c1])   lips_rect = (r0, r1, c0, c1)  [FLAG_LIPS]
- *        + w_extra * extra[0]                        (extra: optional device scalar, e.g. motion_l1_reg)
+ *        + w_extra * sum(extra[0:n_extra])           (extra: optional device array of partial sums, e.g. the
+ *                                                     regulariser partials of instag_deform_activate_forward)
  * image, gt, attn [3,H,W]; alpha [1,H,W]; masks [H,W] bytes (0 / non-zero); bg [3]; lips_rect int32[4] on the
  * device (it changes per frame under graph replay).  An empty hair mask contributes 0 (the reference
  * yields NaN there).  forward writes maps [3,3,H,W] (SSIM derivative maps), partials
@@ -341,7 +347,8 @@ int64_t instag_face_loss_num_partials(int32_t H, int32_t W);
 int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
                              const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
                              const float* bg, const float* alpha, const float* attn, const int32_t* lips_rect,
-                             const float* extra, float* maps, float* partials, float* out, instag_stream_t stream);
+                             const float* extra, int32_t n_extra, float* maps, float* partials, float* out,
+                             instag_stream_t stream);
 int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
                               const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
                               const float* bg, const int32_t* lips_rect, const float* maps, const float* out,

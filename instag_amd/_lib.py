@@ -85,8 +85,9 @@ _PROTOS = {
     "instag_motion_glue_forward": (C.c_int, [vp] * 7 + [i32] * 4 + [vp]),
     "instag_motion_glue_backward_num_partials": (C.c_int, [i32, i32, i32, i32]),
     "instag_motion_glue_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "instag_deform_activate_forward": (C.c_int, [vp] * 10 + [i32, vp]),
-    "instag_deform_activate_backward": (C.c_int, [vp] * 15 + [i32, vp]),
+    "instag_deform_activate_num_reg_partials": (C.c_int, [i32]),
+    "instag_deform_activate_forward": (C.c_int, [vp] * 11 + [f32, i32, vp]),
+    "instag_deform_activate_backward": (C.c_int, [vp] * 16 + [f32, i32, vp]),
     "instag_motion_l1_reg_num_partials": (C.c_int, [i32]),
     "instag_motion_l1_reg_forward": (C.c_int, [vp, vp, vp, i32, vp]),
     "instag_motion_l1_reg_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
@@ -99,7 +100,7 @@ _PROTOS = {
     "instag_l1_ssim_forward": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "instag_l1_ssim_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "instag_face_loss_num_partials": (C.c_int64, [i32, i32]),
-    "instag_face_loss_forward": (C.c_int, [vp] * 15),
+    "instag_face_loss_forward": (C.c_int, [vp] * 11 + [i32] + [vp] * 4),
     "instag_face_loss_backward": (C.c_int, [vp] * 16),
     "instag_adam_chunk_elems": (C.c_int, []),
     "instag_adam_step": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp]),

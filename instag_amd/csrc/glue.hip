@@ -153,6 +153,7 @@ motion_glue_backward_kernel(GlueDims d, const float* __restrict__ d_h_in, const 
 }
 
 // ---- deform + activations ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(__expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -161,24 +162,41 @@ deform_activate_forward_kernel(int N, const float* __restrict__ xyz, const float
                                const float* __restrict__ rotation, const float* __restrict__ opacity,
                                const float* __restrict__ h /*[N,11]*/, const float* __restrict__ p /*[N,6]*/,
                                float* __restrict__ means3D, float* __restrict__ scales, float* __restrict__ rots,
-                               float* __restrict__ opac) {
+                               float* __restrict__ opac, float* __restrict__ reg_partials, float reg_weight) {
+  __shared__ float s_red[GB / 64];
   const int r = blockIdx.x * GB + threadIdx.x;
-  if (r >= N) return;
-  const float* hr = h + (size_t)r * 11;
-  const float* pr = p + (size_t)r * 6;
+  float reg = 0.f;
+  if (r < N) {
+    const float* hr = h + (size_t)r * 11;
+    const float* pr = p + (size_t)r * 6;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float ps = tanhf(pr[3 + k] * 0.2f) * 0.25f + 1.0f;
-    means3D[3 * r + k] = xyz[3 * r + k] + (hr[k] * 1e-2f) * ps;
-    scales[3 * r + k] = softplus_f(scaling[3 * r + k] + hr[8 + k]);
+    for (int k = 0; k < 3; ++k) {
+      const float ps = tanhf(pr[3 + k] * 0.2f) * 0.25f + 1.0f;
+      means3D[3 * r + k] = xyz[3 * r + k] + (hr[k] * 1e-2f) * ps;
+      scales[3 * r + k] = softplus_f(scaling[3 * r + k] + hr[8 + k]);
+    }
+    float q[4], n2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { q[k] = rotation[4 * r + k] + hr[3 + k]; n2 += q[k] * q[k]; }
+    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rots[4 * r + k] = q[k] * inv;
+    opac[r] = sigmoid_f(opacity[r]);
+    if (reg_partials) {
+      // the motion regulariser of train_face.py:510-514 rides along (same terms as motion_l1_reg below)
+      const float w_xyz = 1e-2f / (3.f * N), w_rot = 1.f / (4.f * N), w_opa = 1.f / (float)N, w_sc = 1.f / (3.f * N);
+      reg = w_xyz * (fabsf(hr[0]) + fabsf(hr[1]) + fabsf(hr[2])) + w_rot * (fabsf(hr[3]) + fabsf(hr[4]) + fabsf(hr[5]) + fabsf(hr[6]))
+          + w_opa * fabsf(hr[7]) + w_sc * (fabsf(hr[8]) + fabsf(hr[9]) + fabsf(hr[10]))
+          + w_xyz * (fabsf(pr[0]) + fabsf(pr[1]) + fabsf(pr[2]));
+    }
   }
-  float q[4], n2 = 0.f;
+  if (reg_partials) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { q[k] = rotation[4 * r + k] + hr[3 + k]; n2 += q[k] * q[k]; }
-  const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) rots[4 * r + k] = q[k] * inv;
-  opac[r] = sigmoid_f(opacity[r]);
+    for (int o = 32; o > 0; o >>= 1) reg += __shfl_xor(reg, o);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = reg;
+    __syncthreads();
+    if (threadIdx.x == 0) reg_partials[blockIdx.x] = reg_weight * (((s_red[0] + s_red[1]) + s_red[2]) + s_red[3]);
+  }
 }
 
 __global__ void __launch_bounds__(GB)
@@ -188,7 +206,8 @@ deform_activate_backward_kernel(int N, const float* __restrict__ scaling, const 
                                 const float* __restrict__ g_scales, const float* __restrict__ g_rots,
                                 const float* __restrict__ g_opac, float* __restrict__ d_xyz,
                                 float* __restrict__ d_scaling, float* __restrict__ d_rotation,
-                                float* __restrict__ d_opacity, float* __restrict__ d_h, float* __restrict__ d_p) {
+                                float* __restrict__ d_opacity, float* __restrict__ d_h, float* __restrict__ d_p,
+                                const float* __restrict__ g_reg, float reg_weight) {
   const int r = blockIdx.x * GB + threadIdx.x;
   if (r >= N) return;
   const float* hr = h + (size_t)r * 11;
@@ -231,6 +250,15 @@ deform_activate_backward_kernel(int N, const float* __restrict__ scaling, const 
   }
   const float so = sigmoid_f(opacity[r]);
   d_opacity[r] = (g_opac ? g_opac[r] : 0.f) * so * (1.f - so);
+  if (g_reg) {
+    const float go = g_reg[0] * reg_weight;
+    const float w_xyz = go * 1e-2f / (3.f * N), w_rot = go / (4.f * N), w_opa = go / (float)N, w_sc = go / (3.f * N);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { dh[k] += w_xyz * sgn(hr[k]); dh[8 + k] += w_sc * sgn(hr[8 + k]); dp[k] += w_xyz * sgn(pr[k]); }
+#pragma unroll
+    for (int k = 3; k < 7; ++k) dh[k] += w_rot * sgn(hr[k]);
+    dh[7] += w_opa * sgn(hr[7]);
+  }
 #pragma unroll
   for (int k = 0; k < 11; ++k) d_h[(size_t)r * 11 + k] = dh[k];
 #pragma unroll
@@ -259,8 +287,6 @@ motion_l1_reg_forward_kernel(int N, const float* __restrict__ h, const float* __
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
 }
-
-__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
 __global__ void __launch_bounds__(GB)
 motion_l1_reg_backward_kernel(int N, const float* __restrict__ h, const float* __restrict__ p,
@@ -354,12 +380,13 @@ int instag_motion_glue_backward(const float* d_h_in, const float* d_amb, const f
 
 int instag_deform_activate_forward(const float* xyz, const float* scaling, const float* rotation,
                                    const float* opacity, const float* h, const float* p, float* means3D,
-                                   float* scales, float* rotations, float* opac, int32_t N, instag_stream_t stream) {
+                                   float* scales, float* rotations, float* opac, float* reg_partials,
+                                   float reg_weight, int32_t N, instag_stream_t stream) {
   INSTAG_REQUIRE(xyz && scaling && rotation && opacity && h && p && means3D && scales && rotations && opac,
                  "deform_activate_forward: NULL tensor");
   if (N == 0) return INSTAG_OK;
-  deform_activate_forward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, xyz, scaling, rotation, opacity,
-                                                                                    h, p, means3D, scales, rotations, opac);
+  deform_activate_forward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(
+      N, xyz, scaling, rotation, opacity, h, p, means3D, scales, rotations, opac, reg_partials, reg_weight);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -367,16 +394,19 @@ int instag_deform_activate_forward(const float* xyz, const float* scaling, const
 int instag_deform_activate_backward(const float* scaling, const float* rotation, const float* opacity, const float* h,
                                     const float* p, const float* g_means, const float* g_scales, const float* g_rots,
                                     const float* g_opac, float* d_xyz, float* d_scaling, float* d_rotation,
-                                    float* d_opacity, float* d_h, float* d_p, int32_t N, instag_stream_t stream) {
+                                    float* d_opacity, float* d_h, float* d_p, const float* g_reg, float reg_weight,
+                                    int32_t N, instag_stream_t stream) {
   INSTAG_REQUIRE(scaling && rotation && opacity && h && p && d_xyz && d_scaling && d_rotation && d_opacity && d_h && d_p,
                  "deform_activate_backward: NULL tensor");
   if (N == 0) return INSTAG_OK;
   deform_activate_backward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(
       N, scaling, rotation, opacity, h, p, g_means, g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation, d_opacity,
-      d_h, d_p);
+      d_h, d_p, g_reg, reg_weight);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
+
+int instag_deform_activate_num_reg_partials(int32_t N) { return (N + GB - 1) / GB; }
 
 int instag_motion_l1_reg_num_partials(int32_t N) { return std::max(1, std::min(256, (N + GB - 1) / GB)); }
 

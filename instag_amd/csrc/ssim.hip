@@ -270,8 +270,8 @@ face_loss_forward_kernel(FaceCfg cfg, FaceIn in, float* __restrict__ maps, float
 // eight waves, one per partial-sum array (fixed summation order inside a wave: lane-strided, then a butterfly)
 __global__ void __launch_bounds__(512)
 face_loss_finalize_kernel(FaceCfg cfg, const float* __restrict__ part, int tiles, const int32_t* __restrict__ lips,
-                          const float* __restrict__ extra, float* __restrict__ out) {
-  __shared__ float s_sum[8];
+                          const float* __restrict__ extra, int n_extra, float* __restrict__ out) {
+  __shared__ float s_sum[9];
   {
     const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* p = k < 2 ? part + (size_t)k * 3 * tiles : part + (size_t)6 * tiles + (size_t)(k - 2) * tiles;
@@ -282,6 +282,13 @@ face_loss_finalize_kernel(FaceCfg cfg, const float* __restrict__ part, int tiles
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) s_sum[k] = acc;
+    if (k == 7) {                       // the shortest array's wave also adds up the `extra` terms
+      float e = 0.f;
+      for (int i = lane; i < n_extra; i += 64) e += extra[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+      if (lane == 0) s_sum[8] = e;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -298,7 +305,7 @@ face_loss_finalize_kernel(FaceCfg cfg, const float* __restrict__ part, int tiles
       inv_area = area > 0.f ? 1.f / area : 0.f;
       loss += cfg.w_lips * s_sum[7] * inv_area;
     }
-    if (extra) loss += cfg.w_extra * extra[0];
+    if (extra) loss += cfg.w_extra * s_sum[8];
     out[0] = loss; out[1] = l1; out[2] = ssim; out[3] = inv_cnt; out[4] = inv_area;
   }
 }
@@ -418,7 +425,8 @@ int64_t instag_face_loss_num_partials(int32_t H, int32_t W) {
 int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
                              const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
                              const float* bg, const float* alpha, const float* attn, const int32_t* lips_rect,
-                             const float* extra, float* maps, float* partials, float* out, instag_stream_t stream) {
+                             const float* extra, int32_t n_extra, float* maps, float* partials, float* out,
+                             instag_stream_t stream) {
   FaceCfg c;
   if (int rc = face_cfg(cfg, &c)) return rc;
   INSTAG_REQUIRE(image && gt && face_mask && hair_mask && mouth_mask && bg && maps && partials && out,
@@ -426,6 +434,7 @@ int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image
   INSTAG_REQUIRE(!(c.flags & F_ALPHA) || alpha, "face_loss_forward: alpha term without alpha");
   INSTAG_REQUIRE(!(c.flags & (F_HAIR_ATTN | F_LIPS)) || attn, "face_loss_forward: attention term without attn");
   INSTAG_REQUIRE(!(c.flags & F_LIPS) || lips_rect, "face_loss_forward: lips term without lips_rect");
+  INSTAG_REQUIRE(extra == nullptr || n_extra >= 1, "face_loss_forward: n_extra must be >= 1");
   const FaceIn in{image, gt, face_mask, hair_mask, mouth_mask, bg, alpha, attn, lips_rect, extra};
   dim3 grid((c.W + TS - 1) / TS, (c.H + TS - 1) / TS, 3);
   {
@@ -434,7 +443,7 @@ int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image
     INSTAG_CHECK_LAUNCH();
   }
   face_loss_finalize_kernel<<<1, 512, 0, (hipStream_t)stream>>>(c, partials, (int)(grid.x * grid.y), lips_rect, extra,
-                                                              out);
+                                                              extra ? n_extra : 0, out);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -73,8 +73,9 @@ def motion_glue_supported(enc_x, aud, eye_pre) -> bool:
 
 class _DeformActivate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, scaling, rotation, opacity, h, p):
+    def forward(ctx, xyz, scaling, rotation, opacity, h, p, reg_weight):
         L = _lib.lib()
+        ctx.set_materialize_grads(False)
         xyz, scaling, rotation, opacity, h, p = (_c(t) for t in (xyz, scaling, rotation, opacity, h, p))
         N = xyz.shape[0]
         dev = xyz.device
@@ -82,19 +83,28 @@ class _DeformActivate(torch.autograd.Function):
         scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
         rots = torch.empty(N, 4, dtype=torch.float32, device=dev)
         opac = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        reg = None
+        if reg_weight is not None:
+            reg = torch.empty(L.instag_deform_activate_num_reg_partials(N), dtype=torch.float32, device=dev)
         check(L.instag_deform_activate_forward(ptr(xyz), ptr(scaling), ptr(rotation), ptr(opacity), ptr(h), ptr(p),
-                                               ptr(means3D), ptr(scales), ptr(rots), ptr(opac), N,
+                                               ptr(means3D), ptr(scales), ptr(rots), ptr(opac), ptr(reg),
+                                               0.0 if reg_weight is None else float(reg_weight), N,
                                                _lib.current_stream()), "deform_activate_forward")
         ctx.save_for_backward(scaling, rotation, opacity, h, p)
-        return means3D, scales, rots, opac
+        ctx.reg_weight = reg_weight
+        if reg is None:
+            return means3D, scales, rots, opac
+        return means3D, scales, rots, opac, reg
 
     @staticmethod
-    def backward(ctx, g_means, g_scales, g_rots, g_opac):
+    def backward(ctx, g_means, g_scales, g_rots, g_opac, g_reg=None):
         L = _lib.lib()
         scaling, rotation, opacity, h, p = ctx.saved_tensors
         N = scaling.shape[0]
         dev = scaling.device
         gs = [None if g is None else _c(g) for g in (g_means, g_scales, g_rots, g_opac)]
+        # every partial sum of the regulariser feeds the same scalar: its upstream gradient is one number
+        g_reg1 = None if g_reg is None else g_reg.reshape(-1)[:1].contiguous().float()
         d_xyz = torch.empty(N, 3, dtype=torch.float32, device=dev)
         d_scaling = torch.empty(N, 3, dtype=torch.float32, device=dev)
         d_rot = torch.empty(N, 4, dtype=torch.float32, device=dev)
@@ -103,14 +113,18 @@ class _DeformActivate(torch.autograd.Function):
         d_p = torch.empty(N, 6, dtype=torch.float32, device=dev)
         check(L.instag_deform_activate_backward(ptr(scaling), ptr(rotation), ptr(opacity), ptr(h), ptr(p), ptr(gs[0]),
                                                 ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(d_xyz), ptr(d_scaling),
-                                                ptr(d_rot), ptr(d_op), ptr(d_h), ptr(d_p), N, _lib.current_stream()),
+                                                ptr(d_rot), ptr(d_op), ptr(d_h), ptr(d_p), ptr(g_reg1),
+                                                0.0 if ctx.reg_weight is None else float(ctx.reg_weight), N,
+                                                _lib.current_stream()),
               "deform_activate_backward")
-        return d_xyz, d_scaling, d_rot, d_op, d_h, d_p
+        return d_xyz, d_scaling, d_rot, d_op, d_h, d_p, None
 
 
-def deform_activate(xyz, scaling, rotation, opacity, h, p):
-    """means3D, scales, rotations, opacity for render_motion(personalized=False, align=True)."""
-    return _DeformActivate.apply(xyz, scaling, rotation, opacity, h, p)
+def deform_activate(xyz, scaling, rotation, opacity, h, p, reg_weight=None):
+    """means3D, scales, rotations, opacity for render_motion(personalized=False, align=True).  With ``reg_weight`` a
+    fifth output holds per-workgroup partial sums of reg_weight * motion_l1_reg(h, p) (train_face.py:510-514): feed it
+    to ``losses.face_loss(extra=..., w_extra=1.0)``; its gradient comes back through this operator's backward."""
+    return _DeformActivate.apply(xyz, scaling, rotation, opacity, h, p, reg_weight)
 
 
 class _MotionL1Reg(torch.autograd.Function):

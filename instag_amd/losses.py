@@ -116,7 +116,7 @@ def face_loss_torch(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None,
     Ll1 = l1_loss(image, gt_white)
     loss = Ll1 + lambda_dssim * (1.0 - ssim(image, gt_white))
     if extra is not None:
-        loss = loss + w_extra * extra
+        loss = loss + w_extra * extra.sum()
     if alpha is not None:
         hm = head.to(alpha.dtype)
         loss = loss + w_alpha * (((1 - alpha) * hm).mean() + (alpha * (1 - hm)).mean())
@@ -151,16 +151,18 @@ class _FusedFaceLoss(torch.autograd.Function):
         gt, bg = gt.contiguous().float(), bg.contiguous().float()
         alpha = None if alpha is None else alpha.contiguous().float()
         attn = None if attn is None else attn.contiguous().float()
-        extra = None if extra is None else extra.reshape(1).contiguous().float()
+        extra_shape = None if extra is None else tuple(extra.shape)
+        extra = None if extra is None else extra.reshape(-1).contiguous().float()
         lips_rect = None if lips_rect is None else lips_rect.contiguous().to(torch.int32)
         maps = torch.empty(3, 3, H, W, dtype=torch.float32, device=dev)
         parts = torch.empty(L.instag_face_loss_num_partials(H, W), dtype=torch.float32, device=dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
         check(L.instag_face_loss_forward(C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask), ptr(hair_mask),
                                          ptr(mouth_mask), ptr(bg), ptr(alpha), ptr(attn), ptr(lips_rect), ptr(extra),
-                                         ptr(maps), ptr(parts), ptr(out), _lib.current_stream()), "face_loss_forward")
+                                         0 if extra is None else extra.numel(), ptr(maps), ptr(parts), ptr(out),
+                                         _lib.current_stream()), "face_loss_forward")
         ctx.cfg = cfg
-        ctx.shapes = (alpha is not None, attn is not None, extra is not None)
+        ctx.shapes = (alpha is not None, attn is not None, None if extra is None else extra_shape)
         ctx.save_for_backward(image, gt, face_mask, hair_mask, mouth_mask, bg, maps, out,
                               *([lips_rect] if lips_rect is not None else []))
         return out[0], out[1]
@@ -185,7 +187,10 @@ class _FusedFaceLoss(torch.autograd.Function):
                                                    ptr(mouth_mask), ptr(bg), ptr(lips_rect), ptr(maps), ptr(out),
                                                    ptr(g_loss), ptr(g_l1), ptr(d_image), ptr(d_alpha), ptr(d_attn),
                                                    _lib.current_stream()), "face_loss_backward")
-        d_extra = (g_loss * cfg.w_extra) if (has_extra and g_loss is not None) else None
+        d_extra = None
+        if has_extra is not None and g_loss is not None:
+            # d loss / d extra[i] = w_extra * g for every element (extra enters as a sum); w_extra == 1 needs no launch
+            d_extra = (g_loss if cfg.w_extra == 1.0 else g_loss * cfg.w_extra).expand(has_extra)
         return d_image, d_alpha, d_attn, d_extra, None, None, None, None, None, None, None
 
 

@@ -73,8 +73,10 @@ def _ones(like):
 
 
 def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, scaling_modifier=1.0, frame_idx=None,
-                  return_attn=False, personalized=False, align=False, detach_motion=False):
-    """Render with the universal (motion_net) and personalised (pc.neural_motion_grid) motion fields."""
+                  return_attn=False, personalized=False, align=False, detach_motion=False, motion_reg_weight=None):
+    """Render with the universal (motion_net) and personalised (pc.neural_motion_grid) motion fields.
+    ``motion_reg_weight`` (extension): also return ``motion_reg`` = partial sums of weight * the motion regulariser of
+    train_face.py:510-514, computed inside the fused deform operator (None when that operator is not used)."""
     screenspace_points = _screenspace_points(pc)
     rasterizer = GaussianRasterizer(_settings(viewpoint_camera, pc, bg_color, scaling_modifier,
                                               getattr(pipe, "debug", False)))
@@ -102,6 +104,7 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             from . import deferred
             xyz.register_hook(lambda g, dev=dev: deferred.flush_async(dev))
     motion_preds = motion_net(xyz, audio_feat, exp_feat)
+    motion_reg = None
 
     fused = (align and not personalized and not detach_motion and pc.get_xyz.is_cuda
              and motion_preds.get("_h") is not None and dict.get(p_motion_preds, "_p") is not None
@@ -109,8 +112,10 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     if fused:
         # deltas + softplus / normalize / sigmoid in one HIP kernel per pass (instag_amd/glue.py)
         from .glue import deform_activate
-        means3D, scales, rotations, opacity = deform_activate(pc.get_xyz, pc._scaling, pc._rotation, pc._opacity,
-                                                              motion_preds["_h"], p_motion_preds["_p"])
+        outs_d = deform_activate(pc.get_xyz, pc._scaling, pc._rotation, pc._opacity, motion_preds["_h"],
+                                 p_motion_preds["_p"], motion_reg_weight)
+        means3D, scales, rotations, opacity = outs_d[:4]
+        motion_reg = outs_d[4] if motion_reg_weight is not None else None
     else:
         d_xyz, d_scale, d_rot = motion_preds["d_xyz"], motion_preds["d_scale"], motion_preds["d_rot"]
         if personalized:
@@ -179,7 +184,7 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             "visibility_filter": lambda: radii > 0,      # one launch, only when somebody reads it
             "depth": depth, "alpha": alpha, "normal": normal, "radii": radii, "motion": motion_preds,
             "p_motion": p_motion_preds if personalized or align else None, "attn": rendered_attn,
-            "p_attn": p_rendered_attn})
+            "p_attn": p_rendered_attn, "motion_reg": motion_reg})
 
 
 def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_net_face, pipe=None, bg_color=None,

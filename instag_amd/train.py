@@ -208,9 +208,12 @@ class FaceTrainer:
         dev = self.bg.device
         td = frame.talking_dict
         extra = alpha = attn = lips = None
+        w_extra = 1e-5
         if warm:
             m, pm = pkg["motion"], pkg["p_motion"]
-            if pkg["render"].is_cuda and m.get("_h") is not None and pm.get("_p") is not None:
+            if pkg.get("motion_reg") is not None:
+                extra, w_extra = pkg["motion_reg"], 1.0        # already weighted, computed by the deform operator
+            elif pkg["render"].is_cuda and m.get("_h") is not None and pm.get("_p") is not None:
                 from .glue import motion_l1_reg
                 extra = motion_l1_reg(m["_h"], pm["_p"])
             else:
@@ -219,13 +222,13 @@ class FaceTrainer:
             alpha, attn, lips = pkg["alpha"], pkg["attn"], td["lips_rect"].to(dev)
         return face_loss(pkg["render"], frame.original_image.to(dev), td["face_mask"].to(dev), td["hair_mask"].to(dev),
                          td["mouth_mask"].to(dev), self.bg, alpha=alpha, attn=attn, lips_rect=lips, extra=extra,
-                         lambda_dssim=self.opt.lambda_dssim, hair_mask_iter=hair_mask_iter)
+                         lambda_dssim=self.opt.lambda_dssim, w_extra=w_extra, hair_mask_iter=hair_mask_iter)
 
     # ---- one step ---------------------------------------------------------------------------------------------
     def _forward_backward(self, frame: Frame):
         from .renderer import render_motion
         pkg = render_motion(frame, self.g, self.motion_net, None, self.bg, return_attn=True, personalized=False,
-                            align=True)
+                            align=True, motion_reg_weight=1e-5)
         loss, Ll1 = self.loss_fn(frame, pkg, warm=True)
         from .deferred import deferred_grads
         with deferred_grads(self.device if self.on_gpu else None):

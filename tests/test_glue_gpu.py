@@ -325,3 +325,38 @@ def test_fuse_renderer_graph_matches_eager():
     finally:
         r.close()
         diff_gauss.set_capacity_plan(None)
+
+
+def test_deform_activate_with_fused_regulariser():
+    """deform_activate(reg_weight): partial sums == weight * the five mean-|.| terms, gradients == deform + regulariser."""
+    from instag_amd.glue import deform_activate
+    g = torch.Generator().manual_seed(3)
+    N = 3001
+    vals = dict(xyz=torch.randn(N, 3, generator=g), scaling=torch.randn(N, 3, generator=g),
+                rotation=torch.randn(N, 4, generator=g), opacity=torch.randn(N, 1, generator=g),
+                h=torch.randn(N, 11, generator=g), p=torch.randn(N, 6, generator=g))
+    wm, ws, wr, wo = (torch.randn(N, k, generator=g) for k in (3, 3, 4, 1))
+    w = 0.37
+
+    def ref(t):
+        ps = torch.tanh(t["p"][:, 3:] / 5) * 0.25 + 1
+        means = t["xyz"] + (t["h"][:, :3] * 1e-2) * ps
+        scales = torch.nn.functional.softplus(t["scaling"] + t["h"][:, 8:11])
+        rots = torch.nn.functional.normalize(t["rotation"] + t["h"][:, 3:7])
+        op = torch.sigmoid(t["opacity"])
+        reg = ((t["h"][:, :3] * 1e-2).abs().mean() + t["h"][:, 3:7].abs().mean() + t["h"][:, 7:8].abs().mean()
+               + t["h"][:, 8:11].abs().mean() + (t["p"][:, :3] * 1e-2).abs().mean())
+        return means, scales, rots, op, w * reg
+
+    td = {k: v.double().requires_grad_(True) for k, v in vals.items()}
+    m, s, r, o, reg = ref(td)
+    ((m * wm.double()).sum() + (s * ws.double()).sum() + (r * wr.double()).sum() + (o * wo.double()).sum()
+     + 2.5 * reg).backward()
+    th = {k: v.cuda().requires_grad_(True) for k, v in vals.items()}
+    mh, sh, rh, oh, parts = deform_activate(th["xyz"], th["scaling"], th["rotation"], th["opacity"], th["h"], th["p"],
+                                            reg_weight=w)
+    ((mh * wm.cuda()).sum() + (sh * ws.cuda()).sum() + (rh * wr.cuda()).sum() + (oh * wo.cuda()).sum()
+     + 2.5 * parts.sum()).backward()
+    assert abs(float(parts.sum()) - float(reg)) <= 1e-6 * max(1.0, abs(float(reg)))
+    for k in vals:
+        _close(th[k].grad, td[k].grad, "d_" + k, tol=2e-5)
