@@ -67,14 +67,19 @@ int instag_grid_total_variation(const float* inputs, const float* embeddings, fl
  * enc_xz), including the (x+bound)/(2 bound) mapping (gridencoder/grid.py:149).  Each plane's table ([total_params,1],
  * shared `offsets` [L+1]) must fit 64 KB.  backward: grad [N,3L] -> dxyz [N,3] (written, may be NULL) and the three
  * table gradients (written, not accumulated; summed over workgroups in a fixed order).  workspace:
- * instag_triplane_backward_workspace_bytes(N, total_params) bytes of scratch. */
+ * instag_triplane_backward_workspace_bytes(N, total_params) bytes of scratch.
+ * shift (optional, [N, shift_stride >= 3]): the encoders are evaluated at xyz + shift_scale * shift[:, :3] (the universal
+ * field sits behind the personalised alignment, gaussian_renderer/__init__.py:196-197); backward then also writes
+ * dshift [N, shift_stride] = (shift_scale * d/dpoint, 0, ...) when it is non-NULL (needs dxyz). */
 int instag_triplane_forward(const float* xyz, const float* table_xy, const float* table_yz,
-                            const float* table_xz, const int32_t* offsets, float* out, uint32_t N, uint32_t L,
+                            const float* table_xz, const int32_t* offsets, float* out, const float* shift,
+                            uint32_t shift_stride, float shift_scale, uint32_t N, uint32_t L,
                             float S, uint32_t H, float bound, uint32_t total_params, instag_stream_t stream);
 size_t instag_triplane_backward_workspace_bytes(uint32_t N, uint32_t total_params);
 int instag_triplane_backward(const float* grad, const float* xyz, const float* table_xy, const float* table_yz,
                              const float* table_xz, const int32_t* offsets, float* dxyz, float* dtable_xy,
                              float* dtable_yz, float* dtable_xz, void* workspace, size_t workspace_bytes,
+                             const float* shift, uint32_t shift_stride, float shift_scale, float* dshift,
                              uint32_t N, uint32_t L, float S, uint32_t H, float bound, uint32_t total_params,
                              instag_stream_t stream);
 

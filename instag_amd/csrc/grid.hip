@@ -522,7 +522,19 @@ struct TriPlaneArgs {
   const int32_t* offsets;     // [L+1], shared by the three planes
   uint32_t N, L, H;
   float S, bound;
+  const float* shift;         // optional [N, shift_stride]: the point is xyz + shift_scale * shift[:, :3]
+  uint32_t shift_stride;      //   (the universal field is evaluated at xyz + p_xyz, gaussian_renderer/__init__.py:196-197)
+  float shift_scale;
 };
+
+__device__ __forceinline__ void tp_point(const TriPlaneArgs& a, uint32_t b, float p[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) p[k] = a.xyz[3 * b + k];
+  if (a.shift) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) p[k] += a.shift_scale * a.shift[(size_t)b * a.shift_stride + k];
+  }
+}
 
 __device__ __forceinline__ void plane_coords(int plane, const float p[3], float x[2]) {
   // xy = (x,y), yz = (y,z), xz = (x,z)   (motion_net.py:244-247)
@@ -578,7 +590,8 @@ triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
     tp_stage_table<GRID_BLOCK, false>(s_tab, nullptr, a.tables[plane], T);
     __syncthreads();
     for (uint32_t b = b0 + threadIdx.x; b < b1; b += GRID_BLOCK) {
-      const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
+      float p[3];
+      tp_point(a, b, p);
       float xw[2];
       plane_coords(plane, p, xw);
       const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
@@ -620,7 +633,7 @@ inline unsigned tp_bwd_blocks(uint32_t N) {
 
 __global__ void __launch_bounds__(TP_BWD_BLOCK)
 triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]*/, float* __restrict__ dxyz /*[N,3] or null*/,
-                         float* __restrict__ ws /*[gridDim.x][3T]*/) {
+                         float* __restrict__ dshift /*[N, shift_stride] or null*/, float* __restrict__ ws /*[gridDim.x][3T]*/) {
   extern __shared__ __align__(16) unsigned long long s_mem64[];      // [T] i64 gradient | [T] f32 table of the plane
   __shared__ TpLevel s_lv[TP_MAX_L];
   __shared__ float s_wmax[TP_BWD_BLOCK / 64];
@@ -662,7 +675,8 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
     for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK) s_acc[i] = 0ull;
     __syncthreads();
     for (uint32_t b = b0 + threadIdx.x; b < b1; b += TP_BWD_BLOCK) {
-      const float p[3] = {a.xyz[3 * b], a.xyz[3 * b + 1], a.xyz[3 * b + 2]};
+      float p[3];
+      tp_point(a, b, p);
       float xw[2];
       plane_coords(plane, p, xw);
       const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
@@ -699,7 +713,15 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
         gx *= inv2b; gy *= inv2b;
         if (plane == 0) { d[0] = gx; d[1] = gy; d[2] = 0.f; }
         else if (plane == 1) { d[1] += gx; d[2] += gy; }
-        else { d[0] += gx; d[2] += gy; }
+        else {
+          const float d0 = d[0] + gx, d1 = d[1], d2 = d[2] + gy;
+          d[0] = d0; d[2] = d2;
+          if (dshift) {               // d/d shift[:, :3] = shift_scale * d/d point, the other columns get no gradient here
+            float* ds = dshift + (size_t)b * a.shift_stride;
+            ds[0] = a.shift_scale * d0; ds[1] = a.shift_scale * d1; ds[2] = a.shift_scale * d2;
+            for (uint32_t k = 3; k < a.shift_stride; ++k) ds[k] = 0.f;
+          }
+        }
       }
     }
     __syncthreads();
@@ -739,14 +761,16 @@ triplane_reduce_kernel(const float* __restrict__ ws, uint32_t nslices, uint32_t 
 extern "C" {
 
 int instag_triplane_forward(const float* xyz, const float* table_xy, const float* table_yz, const float* table_xz,
-                            const int32_t* offsets, float* out, uint32_t N, uint32_t L, float S, uint32_t H,
+                            const int32_t* offsets, float* out, const float* shift, uint32_t shift_stride,
+                            float shift_scale, uint32_t N, uint32_t L, float S, uint32_t H,
                             float bound, uint32_t total_params, instag_stream_t stream) {
   using namespace instag;
   INSTAG_REQUIRE(xyz && table_xy && table_yz && table_xz && offsets && out, "triplane_forward: NULL tensor");
   INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
   INSTAG_REQUIRE(total_params * sizeof(float) <= 64 * 1024, "triplane: a plane's table must fit 64 KB of LDS");
+  INSTAG_REQUIRE(shift == nullptr || shift_stride >= 3, "triplane: shift needs at least 3 columns");
   if (N == 0) return INSTAG_OK;
-  TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound};
+  TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound, shift, shift_stride, shift_scale};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_GRID_FWD, s);
   triplane_forward_kernel<<<fwd_blocks(N), GRID_BLOCK, total_params * sizeof(float), s>>>(a, out);
@@ -760,7 +784,8 @@ size_t instag_triplane_backward_workspace_bytes(uint32_t N, uint32_t total_param
 
 int instag_triplane_backward(const float* grad, const float* xyz, const float* table_xy, const float* table_yz,
                              const float* table_xz, const int32_t* offsets, float* dxyz, float* dtable_xy,
-                             float* dtable_yz, float* dtable_xz, void* workspace, size_t workspace_bytes, uint32_t N,
+                             float* dtable_yz, float* dtable_xz, void* workspace, size_t workspace_bytes,
+                             const float* shift, uint32_t shift_stride, float shift_scale, float* dshift, uint32_t N,
                              uint32_t L, float S, uint32_t H, float bound, uint32_t total_params,
                              instag_stream_t stream) {
   using namespace instag;
@@ -784,9 +809,12 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     attr_set = true;
   }
-  TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound};
+  INSTAG_REQUIRE(shift == nullptr || shift_stride >= 3, "triplane: shift needs at least 3 columns");
+  INSTAG_REQUIRE(dshift == nullptr || (shift != nullptr && dxyz != nullptr), "triplane_backward: dshift needs shift and dxyz");
+  TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound, shift, shift_stride, shift_scale};
   ProfScope p(K_GRID_BWD, s);
-  triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)12 * total_params, s>>>(a, grad, dxyz, (float*)workspace);
+  triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)12 * total_params, s>>>(a, grad, dxyz, dshift,
+                                                                                    (float*)workspace);
   INSTAG_CHECK_LAUNCH();
   triplane_reduce_kernel<<<div_up<uint32_t>(3 * total_params, 32), 256, 0, s>>>((const float*)workspace, blocks,
                                                                               total_params, dtable_xy, dtable_yz,

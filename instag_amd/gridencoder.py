@@ -150,38 +150,47 @@ class GridEncoder(nn.Module):
 
 class _tri_plane_encode(Function):
     """cat(enc_xy(xy), enc_yz(yz), enc_xz(xz)) of three identically configured 2-D, C=1 encoders in one kernel
-    (csrc/grid.hip: triplane_*).  Equivalent to scene/motion_net.py:244-258 of the reference."""
+    (csrc/grid.hip: triplane_*).  Equivalent to scene/motion_net.py:244-258 of the reference.  Optional ``shift``
+    [N, >=3]: the encoders are evaluated at xyz + shift_scale * shift[:, :3]."""
 
     @staticmethod
-    def forward(ctx, xyz, emb_xy, emb_yz, emb_xz, offsets, S, H, bound):
+    def forward(ctx, xyz, emb_xy, emb_yz, emb_xz, offsets, S, H, bound, shift, shift_scale):
         xyz = xyz.contiguous().float()
         tabs = [e.contiguous().float() for e in (emb_xy, emb_yz, emb_xz)]
         _check_inputs(xyz=xyz, offsets=offsets, emb_xy=tabs[0], emb_yz=tabs[1], emb_xz=tabs[2])
+        shift = None if shift is None else shift.contiguous().float()
         N = xyz.shape[0]
         L = offsets.shape[0] - 1
         T = tabs[0].shape[0]
         out = torch.empty(N, 3 * L, device=xyz.device, dtype=torch.float32)
         check(_lib.lib().instag_triplane_forward(ptr(xyz), ptr(tabs[0]), ptr(tabs[1]), ptr(tabs[2]), ptr(offsets),
-                                                 ptr(out), N, L, S, H, float(bound), T, _lib.current_stream()),
+                                                 ptr(out), ptr(shift), 0 if shift is None else shift.shape[1],
+                                                 float(shift_scale), N, L, S, H, float(bound), T,
+                                                 _lib.current_stream()),
               "triplane_forward")
-        ctx.save_for_backward(xyz, tabs[0], tabs[1], tabs[2], offsets)
-        ctx.meta = (N, L, S, H, float(bound), T)
+        ctx.save_for_backward(xyz, tabs[0], tabs[1], tabs[2], offsets, *([shift] if shift is not None else []))
+        ctx.meta = (N, L, S, H, float(bound), T, float(shift_scale))
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        xyz, t0, t1, t2, offsets = ctx.saved_tensors
-        N, L, S, H, bound, T = ctx.meta
+        saved = ctx.saved_tensors
+        xyz, t0, t1, t2, offsets = saved[:5]
+        shift = saved[5] if len(saved) > 5 else None
+        N, L, S, H, bound, T, shift_scale = ctx.meta
         grad = grad.contiguous().float()
         L_ = _lib.lib()
-        dxyz = torch.empty_like(xyz) if ctx.needs_input_grad[0] else None
+        want_shift = shift is not None and ctx.needs_input_grad[8]
+        dxyz = torch.empty_like(xyz) if (ctx.needs_input_grad[0] or want_shift) else None
+        dshift = torch.empty_like(shift) if want_shift else None
         dt = torch.empty(3, T, 1, device=xyz.device, dtype=torch.float32)
         ws_bytes = L_.instag_triplane_backward_workspace_bytes(N, T)
         ws = torch.empty(max(1, ws_bytes // 4), device=xyz.device, dtype=torch.float32)
         check(L_.instag_triplane_backward(ptr(grad), ptr(xyz), ptr(t0), ptr(t1), ptr(t2), ptr(offsets),
-                                          ptr(dxyz), ptr(dt[0]), ptr(dt[1]), ptr(dt[2]), ptr(ws), ws_bytes, N, L, S, H,
-                                          bound, T, _lib.current_stream()), "triplane_backward")
-        return dxyz, dt[0], dt[1], dt[2], None, None, None, None
+                                          ptr(dxyz), ptr(dt[0]), ptr(dt[1]), ptr(dt[2]), ptr(ws), ws_bytes,
+                                          ptr(shift), 0 if shift is None else shift.shape[1], shift_scale, ptr(dshift),
+                                          N, L, S, H, bound, T, _lib.current_stream()), "triplane_backward")
+        return (dxyz if ctx.needs_input_grad[0] else None), dt[0], dt[1], dt[2], None, None, None, None, dshift, None
 
 
 def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
@@ -203,8 +212,9 @@ def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
     return True
 
 
-def tri_plane_encode(xyz, enc_xy, enc_yz, enc_xz, bound):
-    """xyz [N,3] -> [N, 3*L]; the three encoders must satisfy tri_plane_supported()."""
+def tri_plane_encode(xyz, enc_xy, enc_yz, enc_xz, bound, shift=None, shift_scale=1.0):
+    """xyz [N,3] (+ shift_scale * shift[:, :3]) -> [N, 3*L]; the three encoders must satisfy tri_plane_supported()."""
     e0 = enc_xy
     return _tri_plane_encode.apply(xyz, enc_xy.embeddings, enc_yz.embeddings, enc_xz.embeddings, e0.offsets,
-                                   float(np.log2(e0.per_level_scale)), int(e0.base_resolution), bound)
+                                   float(np.log2(e0.per_level_scale)), int(e0.base_resolution), bound, shift,
+                                   shift_scale)

@@ -159,12 +159,18 @@ class _TriPlaneField(nn.Module):
         self.sigma_net = MLP(self.in_dim + audio_dim + self.eye_dim + ind_dim, out_dim, hidden_dim, self.num_layers)
         self.aud_ch_att_net = MLP(self.in_dim, audio_dim, 32, 2)
 
-    def encode_x(self, xyz, bound):
+    def encode_x(self, xyz, bound, shift=None):
+        """``shift`` = (tensor [N, >=3], scale): encode xyz + scale * tensor[:, :3] (fused into the kernel on the GPU)."""
         if xyz.is_cuda:
             from . import gridencoder as _ge
             if _ge.tri_plane_supported(self.encoder_xy, self.encoder_yz, self.encoder_xz):
                 # the three planes in one HIP kernel, output already concatenated
+                if shift is not None:
+                    return _ge.tri_plane_encode(xyz, self.encoder_xy, self.encoder_yz, self.encoder_xz, bound,
+                                                shift[0], shift[1])
                 return _ge.tri_plane_encode(xyz, self.encoder_xy, self.encoder_yz, self.encoder_xz, bound)
+        if shift is not None:
+            xyz = torch.add(xyz, shift[0][..., :3], alpha=shift[1])
         xy, yz = xyz[:, :-1], xyz[:, 1:]
         xz = torch.cat([xyz[:, :1], xyz[:, -1:]], dim=-1)
         return torch.cat([self.encoder_xy(xy, bound=bound), self.encoder_yz(yz, bound=bound),
@@ -201,14 +207,14 @@ class _TriPlaneField(nn.Module):
         ev.record(torch.cuda.current_stream(a.device))
         self._audio_pending = (a, e, ev, _side_stream(a.device, stream_index))
 
-    def _trunk(self, x, a, e, c, enc_x=None):
+    def _trunk(self, x, a, e, c, enc_x=None, x_shift=None):
         """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim], amb3); amb3 = the [N,3] tensor
         (aud, eye, 0) the two ambient columns are views of (fused path) or None.  (Nothing of a step may be kept
         on the module: a live autograd graph across steps breaks stream capture.)"""
         fork = x.is_cuda and CONCURRENT_AUDIO
         pending = self.__dict__.pop("_audio_pending", None)
         if enc_x is None:
-            enc_x = self.encode_x(x, bound=self.bound)
+            enc_x = self.encode_x(x, bound=self.bound, shift=x_shift)
         aud_ch_att = self.aud_ch_att_net(enc_x)
         eye_pre = self.eye_att_net(enc_x) if self.exp_eye else None
         if fork:
@@ -254,8 +260,10 @@ class MotionNetwork(_TriPlaneField):
         super().__init__(args.audio_extractor, audio_dim, 64, True, 11, ind_dim, encoder_cls)
         self.cache = None
 
-    def forward(self, x, a, e=None, c=None):
-        _, amb_aud, amb_eye, h, amb3 = self._trunk(x, a, e, c)
+    def forward(self, x, a, e=None, c=None, x_shift=None):
+        """Reference signature (x, a, e, c).  Extension: ``x_shift`` = (tensor, scale) evaluates the field at
+        x + scale * tensor[:, :3] without materialising the sum (render_motion's xyz + p_xyz)."""
+        _, amb_aud, amb_eye, h, amb3 = self._trunk(x, a, e, c, x_shift=x_shift)
         def outputs(h, amb_aud, amb_eye):
             return LazyOutputs({
                 "d_xyz": lambda: h[..., :3] * 1e-2, "d_rot": h[..., 3:7], "d_opa": h[..., 7:8],

@@ -12,6 +12,7 @@ import math
 import torch
 
 from .diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
+from .motion_net import MotionNetwork as _MotionNetwork
 
 CONCURRENT_PASSES = True      # fork the attention raster pass(es) onto a second stream
 SHARED_ATTN_PASS = True       # attention map as an auxiliary colour set of the main raster pass
@@ -94,16 +95,23 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             pc.neural_motion_grid.start_audio(audio_feat, 2, exp_feat)
     if personalized or align:
         p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat, exp_feat)
+    x_shift = None
     if align:
         p_raw = p_motion_preds.get("_p")
-        # xyz + p_xyz with p_xyz = p[:, :3] * 1e-2 as one launch
-        xyz = torch.add(xyz, p_raw[..., :3], alpha=1e-2) if p_raw is not None else xyz + p_motion_preds["p_xyz"]
-        if xyz.is_cuda and xyz.requires_grad:
-            # backward reaches this point when the universal field is done and the personalised field's chain is
-            # about to start: the weight gradients queued so far can run beside it (instag_amd/deferred.py)
-            from . import deferred
-            xyz.register_hook(lambda g, dev=dev: deferred.flush_async(dev))
-    motion_preds = motion_net(xyz, audio_feat, exp_feat)
+        if p_raw is not None and xyz.is_cuda and isinstance(motion_net, _MotionNetwork):
+            # xyz + p_xyz (= p[:, :3] * 1e-2) is formed inside the tri-plane kernel
+            x_shift = (p_raw, 1e-2)
+            if p_raw.requires_grad:
+                # backward reaches p when the universal field is done and the personalised field's chain is about to
+                # start: the weight gradients queued so far can run beside it (instag_amd/deferred.py)
+                from . import deferred
+                p_raw.register_hook(lambda g, dev=dev: deferred.flush_async(dev))
+        else:
+            xyz = xyz + p_motion_preds["p_xyz"]
+    if x_shift is not None:
+        motion_preds = motion_net(xyz, audio_feat, exp_feat, x_shift=x_shift)
+    else:
+        motion_preds = motion_net(xyz, audio_feat, exp_feat)
     motion_reg = None
 
     fused = (align and not personalized and not detach_motion and pc.get_xyz.is_cuda

@@ -185,3 +185,38 @@ def test_tri_plane_encode_matches_three_encoders():
     assert float((xa.grad - xb.grad).abs().max()) <= 2e-4 * float(xb.grad.abs().max())
     for g_, e in zip(ga, encs):
         assert float((g_ - e.embeddings.grad).abs().max()) <= 2e-4 * float(e.embeddings.grad.abs().max())
+
+
+def test_tri_plane_encode_with_shift():
+    """tri_plane_encode(xyz, shift=(p, s)) == tri_plane_encode(xyz + s * p[:, :3]); gradients reach xyz and p[:, :3]."""
+    from instag_amd.gridencoder import GridEncoder, tri_plane_encode
+    torch.manual_seed(4)
+    cfg = dict(input_dim=2, num_levels=12, level_dim=1, base_resolution=16, log2_hashmap_size=17,
+               desired_resolution=256 * 0.15)
+    es = [GridEncoder(**cfg).cuda() for _ in range(3)]
+    with torch.no_grad():
+        for e in es:
+            e.embeddings.copy_(torch.randn_like(e.embeddings) * 0.1)
+    N = 4099
+    xyz0, p0 = (torch.rand(N, 3) * 0.2 - 0.1).cuda(), torch.randn(N, 6).cuda()
+    w = torch.randn(N, 36).cuda()
+
+    def run(fused):
+        xyz, p = xyz0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+        for e in es:
+            e.embeddings.grad = None
+        if fused:
+            out = tri_plane_encode(xyz, es[0], es[1], es[2], 0.15, shift=p, shift_scale=1e-2)
+        else:
+            out = tri_plane_encode(torch.add(xyz, p[:, :3], alpha=1e-2), es[0], es[1], es[2], 0.15)
+        (out * w).sum().backward()
+        return out.detach(), xyz.grad, p.grad, [e.embeddings.grad.clone() for e in es]
+
+    o_r, gx_r, gp_r, ge_r = run(False)
+    o_f, gx_f, gp_f, ge_f = run(True)
+    assert torch.equal(o_f, o_r) or float((o_f - o_r).abs().max()) <= 1e-7
+    assert float((gx_f - gx_r).abs().max()) <= 1e-6 * max(1.0, float(gx_r.abs().max()))
+    assert float((gp_f - gp_r).abs().max()) <= 1e-6 * max(1.0, float(gp_r.abs().max()))
+    assert float(gp_f[:, 3:].abs().max()) == 0.0
+    for a, b in zip(ge_f, ge_r):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
