@@ -127,6 +127,10 @@ typedef struct instag_raster_args {
   const float* rotations;      /* [N,4] (r,x,y,z), already normalised */
   const float* cov3Ds_precomp; /* [N,6] xx,xy,xz,yy,yz,zz */
   const float* extra_attrs;    /* [N,E] or NULL */
+  /* optional split SH storage (scene/gaussian_model.py keeps _features_dc [N,1,3] and _features_rest [N,M-1,3] as
+     separate parameters and concatenates them on every call, :183-186): when shs_rest != NULL, `shs` holds only the
+     DC coefficient [N,1,3] and shs_rest the other M-1; M is still the total count.  NULL = `shs` is [N,M,3]. */
+  const float* shs_rest;
 } instag_raster_args;
 
 size_t instag_raster_geom_bytes(int32_t N);
@@ -174,6 +178,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                            float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs,
                            float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
+                           float* dL_dshs_rest /* [N,M-1,3], with split SH storage: then dL_dshs is [N,1,3] */,
                            instag_stream_t stream);
 
 /* backward of the auxiliary colour set over the forward's state: dL_dout_aux [3,H,W] -> dL_daux_colors [N,3] and

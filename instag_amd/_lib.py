@@ -44,6 +44,7 @@ class RasterArgs(C.Structure):
         ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp),
         ("means3D", vp), ("shs", vp), ("colors_precomp", vp), ("opacities", vp),
         ("scales", vp), ("rotations", vp), ("cov3Ds_precomp", vp), ("extra_attrs", vp),
+        ("shs_rest", vp),
     ]
 
 
@@ -74,7 +75,7 @@ _PROTOS = {
                                              vp, vp, vp]),
     "instag_raster_backward": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, sz, vp, sz, i64, vp,
                                          vp, vp, vp, vp, vp, vp, sz,
-                                         vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+                                         vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "instag_raster_debug_export": (C.c_int, [vp, sz, vp, sz, vp, sz, i32, i64, i32, i32,
                                              vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "instag_mlp_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

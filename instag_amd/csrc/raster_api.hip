@@ -115,6 +115,7 @@ static int validate(const instag_raster_args* a) {
   INSTAG_REQUIRE(a->E == 0 || a->E == 1, "extra_attrs: only 0 or 1 channel is supported");
   INSTAG_REQUIRE(a->sh_degree >= 0 && a->sh_degree <= 3, "sh_degree must be in [0,3]");
   if (a->shs) INSTAG_REQUIRE((a->sh_degree + 1) * (a->sh_degree + 1) <= a->M, "shs has fewer coefficients than sh_degree needs");
+  INSTAG_REQUIRE(a->shs_rest == nullptr || (a->shs != nullptr && a->M >= 2), "shs_rest needs shs (the DC term) and M >= 2");
   INSTAG_REQUIRE(a->bg && a->viewmatrix && a->projmatrix && a->campos, "camera pointers must not be NULL");
   INSTAG_REQUIRE(a->N == 0 || (a->means3D && a->opacities), "means3D / opacities must not be NULL");
   return INSTAG_OK;
@@ -152,7 +153,7 @@ using namespace instag;
 extern "C" {
 
 const char* instag_last_error(void) { return g_err.c_str(); }
-int instag_abi_version(void) { return 2; }
+int instag_abi_version(void) { return 3; }
 
 size_t instag_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t instag_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
@@ -277,7 +278,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                            void* workspace, size_t workspace_bytes, float* dL_dmeans3D, float* dL_dmeans2D,
                            float* dL_dshs, float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
-                           instag_stream_t stream_) {
+                           float* dL_dshs_rest, instag_stream_t stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (int e = validate(a)) return e;
   INSTAG_REQUIRE(radii != nullptr || a->N == 0, "radii is NULL");
@@ -304,7 +305,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                                     (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
                                     radii, inst_grad, (uint32_t)R, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp,
                                     dL_dopacities, dL_dscales, dL_drotations, dL_dcov3Ds_precomp,
-                                    a->E > 0 ? dL_dextra_attrs : nullptr, s);
+                                    a->E > 0 ? dL_dextra_attrs : nullptr, dL_dshs_rest, s);
 }
 
 int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes, const void* binning,

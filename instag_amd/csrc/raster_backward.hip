@@ -22,7 +22,15 @@ __device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,
 struct BwdIO {
   const float *means3D, *shs, *scales, *rots, *cov3Dp;
   float *dmeans3D, *dmeans2D, *dshs, *dcolors, *dopac, *dscales, *drots, *dcov3D, *dextra;
+  const float* shs_rest;     // split SH storage: shs = [N,1,3], shs_rest = [N,M-1,3]; gradients likewise
+  float* dshs_rest;
 };
+
+// gradient slot of SH coefficient m of Gaussian g (concatenated or split storage)
+__device__ __forceinline__ float* dsh_slot(const BwdIO& io, int g, int m, int M) {
+  if (io.shs_rest) return m == 0 ? io.dshs + (size_t)g * 3 : io.dshs_rest + ((size_t)g * (M - 1) + (m - 1)) * 3;
+  return io.dshs + ((size_t)g * M + m) * 3;
+}
 
 __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
@@ -144,8 +152,19 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
 
     // ---- colour: SH coefficients and view direction ---------------------------------------------
     if (io.shs) {
-      const float* __restrict__ sh = io.shs + (size_t)g * c.M * 3;
-      float* dsh = io.dshs ? io.dshs + (size_t)g * c.M * 3 : nullptr;
+      float sh[48];
+      {
+        const float* __restrict__ s0 = io.shs_rest ? io.shs + (size_t)g * 3 : io.shs + (size_t)g * c.M * 3;
+        const float* __restrict__ s1 = io.shs_rest ? io.shs_rest + (size_t)g * (c.M - 1) * 3 - 3 : s0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          if (m < nsh) {
+            const float* src = m == 0 ? s0 : s1 + 3 * m;
+            sh[3 * m] = src[0]; sh[3 * m + 1] = src[1]; sh[3 * m + 2] = src[2];
+          }
+        }
+      }
+      const bool want_dsh = io.dshs != nullptr;
       const float ddx = px - c.campos[0], ddy = py - c.campos[1], ddz = pz - c.campos[2];
       const float inv_len = 1.0f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
       const float x = ddx * inv_len, y = ddy * inv_len, z = ddz * inv_len;
@@ -170,8 +189,8 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float dc = (flags & (1u << ch)) ? 0.f : dcol[ch];
-        if (dsh) {
-          for (int m = 0; m < c.M; ++m) dsh[3 * m + ch] = (m < nsh) ? basis[m] * dc : 0.f;
+        if (want_dsh) {
+          for (int m = 0; m < c.M; ++m) dsh_slot(io, g, m, c.M)[ch] = (m < nsh) ? basis[m] * dc : 0.f;
         }
         if (c.sh_degree > 0) {
           const float s1 = sh[3 + ch], s2 = sh[6 + ch], s3 = sh[9 + ch];
@@ -260,8 +279,10 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
   } else {
     if (io.dmeans2D) { io.dmeans2D[3 * g + 0] = 0.f; io.dmeans2D[3 * g + 1] = 0.f; io.dmeans2D[3 * g + 2] = 0.f; }
     if (io.shs && io.dshs) {
-      float* dsh = io.dshs + (size_t)g * c.M * 3;
-      for (int m = 0; m < 3 * c.M; ++m) dsh[m] = 0.f;
+      for (int m = 0; m < c.M; ++m) {
+        float* d = dsh_slot(io, g, m, c.M);
+        d[0] = 0.f; d[1] = 0.f; d[2] = 0.f;
+      }
     }
     if (!io.shs && io.dcolors) { io.dcolors[3 * g + 0] = 0.f; io.dcolors[3 * g + 1] = 0.f; io.dcolors[3 * g + 2] = 0.f; }
   }
@@ -317,11 +338,11 @@ int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, con
                                const int32_t* radii, const float* inst_grad, uint32_t capacity,
                                float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                                float* dL_dopacities, float* dL_dscales, float* dL_drotations,
-                               float* dL_dcov3D, float* dL_dextra, hipStream_t s) {
+                               float* dL_dcov3D, float* dL_dextra, float* dL_dshs_rest, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   BwdIO io{a->means3D, a->shs, a->scales, a->rotations, a->cov3Ds_precomp,
            dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations,
-           dL_dcov3D, dL_dextra};
+           dL_dcov3D, dL_dextra, a->shs_rest, dL_dshs_rest};
   ProfScope p(K_PREPROCESS_BWD, s);
   preprocess_backward_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, io, rec2d, cov3d, tiles_touched, flags,
                                                                radii, inst_grad, capacity);

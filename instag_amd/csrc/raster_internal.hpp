@@ -51,7 +51,7 @@ int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, con
                                float* dL_dmeans3D,
                                float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                                float* dL_dopacities, float* dL_dscales, float* dL_drotations,
-                               float* dL_dcov3D, float* dL_dextra, hipStream_t s);
+                               float* dL_dcov3D, float* dL_dextra, float* dL_dshs_rest, hipStream_t s);
 int launch_aux_backward_reduce(const Camera& c, const float* rec2d, const uint32_t* tiles_touched, const int32_t* radii,
                                const float* inst_grad, uint32_t capacity, float* dL_daux_colors, float* dL_dmeans2D,
                                hipStream_t s);

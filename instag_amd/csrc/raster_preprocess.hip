@@ -45,7 +45,7 @@ __device__ __forceinline__ bool tile_kept(float px, float py, float A, float B, 
 }
 
 struct PreIn {
-  const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *extra;
+  const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *extra, *shs_rest;
 };
 
 __global__ void __launch_bounds__(256)
@@ -174,7 +174,20 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
 
   float cr, cg, cb;
   if (in.shs) {
-    const float* __restrict__ sh = in.shs + (size_t)g * c.M * 3;
+    // the active coefficients in registers, from the concatenated [N,M,3] tensor or from the (dc | rest) pair
+    float sh[48];
+    {
+      const int nsh = (c.sh_degree + 1) * (c.sh_degree + 1);
+      const float* __restrict__ s0 = in.shs_rest ? in.shs + (size_t)g * 3 : in.shs + (size_t)g * c.M * 3;
+      const float* __restrict__ s1 = in.shs_rest ? in.shs_rest + (size_t)g * (c.M - 1) * 3 - 3 : s0;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        if (m < nsh) {
+          const float* src = m == 0 ? s0 : s1 + 3 * m;
+          sh[3 * m] = src[0]; sh[3 * m + 1] = src[1]; sh[3 * m + 2] = src[2];
+        }
+      }
+    }
     const float dx = px - c.campos[0], dy = py - c.campos[1], dz = pz - c.campos[2];
     const float ln = sqrtf((dx * dx + dy * dy) + dz * dz);
     const float x = dx / ln, y = dy / ln, z = dz / ln;
@@ -353,7 +366,7 @@ int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d
                       uint32_t* order_in, int32_t* radii, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   PreIn in{a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales, a->rotations,
-           a->cov3Ds_precomp, a->extra_attrs};
+           a->cov3Ds_precomp, a->extra_attrs, a->shs_rest};
   ProfScope p(K_PREPROCESS, s);
   preprocess_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, in, rec2d, cov3d, tiles_touched, flags, cull_thr, depth_key,
                                                      order_in, radii);

@@ -97,12 +97,17 @@ def set_capacity_plan(plan):
 
 class _State:
     """Opaque device buffers kept between forward and backward (geom / binning / image)."""
-    __slots__ = ("args", "keep", "geom", "binning", "image", "R", "radii", "N", "H", "W", "E", "M", "aux")
+    __slots__ = ("args", "keep", "geom", "binning", "image", "R", "radii", "N", "H", "W", "E", "M", "aux", "split_sh")
 
 
 def _make_args(s: GaussianRasterizationSettings, means3D, shs, colors, opac, scales, rots, cov3D, extra):
     N = means3D.shape[0]
-    M = 0 if shs is None else shs.shape[1]
+    shs_rest = None
+    if isinstance(shs, (tuple, list)):           # split SH storage: (dc [N,1,3], rest [N,M-1,3])
+        shs, shs_rest = shs
+        if shs_rest.shape[1] == 0:
+            shs_rest = None
+    M = 0 if shs is None else shs.shape[1] + (0 if shs_rest is None else shs_rest.shape[1])
     E = 0 if extra is None else (extra.shape[1] if extra.dim() > 1 else 1)
     bg, view, proj, campos = _f32c(s.bg), _f32c(s.viewmatrix), _f32c(s.projmatrix), _f32c(s.campos)
     _require_cuda(bg=bg, viewmatrix=view, projmatrix=proj, campos=campos)
@@ -114,7 +119,8 @@ def _make_args(s: GaussianRasterizationSettings, means3D, shs, colors, opac, sca
     a.bg, a.viewmatrix, a.projmatrix, a.campos = ptr(bg), ptr(view), ptr(proj), ptr(campos)
     a.means3D, a.shs, a.colors_precomp, a.opacities = ptr(means3D), ptr(shs), ptr(colors), ptr(opac)
     a.scales, a.rotations, a.cov3Ds_precomp, a.extra_attrs = ptr(scales), ptr(rots), ptr(cov3D), ptr(extra)
-    keep = (bg, view, proj, campos, means3D, shs, colors, opac, scales, rots, cov3D, extra)
+    a.shs_rest = ptr(shs_rest)
+    keep = (bg, view, proj, campos, means3D, shs, shs_rest, colors, opac, scales, rots, cov3D, extra)
     return a, keep, N, M, E
 
 
@@ -159,6 +165,7 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
     st.args, st.keep, st.geom, st.binning, st.image = a, keep, geom, binning, image
     st.R, st.radii, st.N, st.H, st.W, st.E, st.M = R, radii, N, H, W, E, M
     st.aux = aux_colors
+    st.split_sh = isinstance(shs, (tuple, list)) and shs[1].shape[1] > 0
     if aux_colors is not None:
         return (color, depth, normal, alpha, radii, extra_img, aux_img), st
     return (color, depth, normal, alpha, radii, extra_img), st
@@ -213,9 +220,12 @@ def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra,
 
     use_sh = st.args.shs is not None
     use_cov = st.args.cov3Ds_precomp is not None
+    split = bool(st.split_sh)
     out = dict(
         means3D=buf(want["means3D"], N, 3), means2D=buf(want["means2D"], N, 3),
-        shs=buf(want["shs"] and use_sh, N, M, 3), colors=buf(want["colors"] and not use_sh, N, 3),
+        shs=buf(want["shs"] and use_sh, N, 1 if split else M, 3),
+        shs_rest=buf(want["shs"] and use_sh and split, N, M - 1, 3),
+        colors=buf(want["colors"] and not use_sh, N, 3),
         opacities=buf(want["opacities"], N, 1), scales=buf(want["scales"] and not use_cov, N, 3),
         rotations=buf(want["rotations"] and not use_cov, N, 4), cov3D=buf(want["cov3D"] and use_cov, N, 6),
         extra=buf(want["extra"] and st.E > 0, N, st.E),
@@ -228,7 +238,7 @@ def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra,
                                    ptr(gs[4]) if st.E > 0 else None, ptr(ws), ws.numel(),
                                    ptr(out["means3D"]), ptr(out["means2D"]), ptr(out["shs"]), ptr(out["colors"]),
                                    ptr(out["opacities"]), ptr(out["scales"]), ptr(out["rotations"]),
-                                   ptr(out["cov3D"]), ptr(out["extra"]), stream),
+                                   ptr(out["cov3D"]), ptr(out["extra"]), ptr(out["shs_rest"]), stream),
           "rasterize_gaussians_backward")
     return out
 
@@ -236,14 +246,17 @@ def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra,
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                extra_attrs, raster_settings, aux_colors=None):
+                extra_attrs, raster_settings, aux_colors=None, sh_rest=None):
         _require_cuda(means3D=means3D)
         ctx.set_materialize_grads(False)      # unused outputs (depth / normal / extra) stay NULL in backward
         m3, shs, col = _f32c(means3D), _f32c(sh), _f32c(colors_precomp)
+        if sh_rest is not None:
+            _require_cuda(shs_rest=sh_rest)
+            shs = (shs, _f32c(sh_rest))         # split SH storage: no concatenation, gradients come back split
         op, sc, ro = _f32c(opacities), _f32c(scales), _f32c(rotations)
         cov, ex, aux = _f32c(cov3Ds_precomp), _f32c(extra_attrs), _f32c(aux_colors)
-        _require_cuda(shs=shs, colors_precomp=col, opacities=op, scales=sc, rotations=ro, cov3Ds_precomp=cov,
-                      extra_attrs=ex, aux_colors=aux)
+        _require_cuda(shs=shs[0] if isinstance(shs, tuple) else shs, colors_precomp=col, opacities=op, scales=sc,
+                      rotations=ro, cov3Ds_precomp=cov, extra_attrs=ex, aux_colors=aux)
         if aux is not None and tuple(aux.shape) != (m3.shape[0], 3):
             raise RuntimeError("aux_colors must be [N,3]")
         outs, st = rasterize_forward(raster_settings, m3, shs, col, op, sc, ro, cov, ex, aux)
@@ -271,8 +284,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if main_grads:
             g = rasterize_backward(st, g_color, g_depth, g_normal, g_alpha, g_extra, want)
         else:
-            g = dict(means3D=None, means2D=None, shs=None, colors=None, opacities=None, scales=None, rotations=None,
-                     cov3D=None, extra=None)
+            g = dict(means3D=None, means2D=None, shs=None, shs_rest=None, colors=None, opacities=None, scales=None,
+                     rotations=None, cov3D=None, extra=None)
         if aux_needed:
             # the aux image only shares the forward state with the main images: its backward runs beside theirs,
             # enqueued AFTER the main one so that in a captured step the main chain keeps its graph branch
@@ -304,13 +317,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_op = None if g["opacities"] is None else g["opacities"].reshape(op_shape)
         g_ex = None if g["extra"] is None else g["extra"].reshape(ex_shape)
         return (g["means3D"], g["means2D"], g["shs"], g["colors"], g_op, g["scales"], g["rotations"],
-                g["cov3D"], g_ex, None, d_aux)
+                g["cov3D"], g_ex, None, d_aux, g.get("shs_rest"))
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         extra_attrs, raster_settings, aux_colors=None):
+    sh_rest = None
+    if isinstance(sh, (tuple, list)):
+        sh, sh_rest = sh
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, extra_attrs, raster_settings, aux_colors)
+                                     cov3Ds_precomp, extra_attrs, raster_settings, aux_colors, sh_rest)
 
 
 class GaussianRasterizer(nn.Module):
@@ -329,7 +345,9 @@ class GaussianRasterizer(nn.Module):
                 cov3Ds_precomp=None, extra_attrs=None, aux_colors=None):
         """Same call and 6-tuple as the reference's rasterizer.  Extension: ``aux_colors`` [N,3] appends a 7th
         output, the image a second call with ``colors_precomp=aux_colors`` on the detached geometry would
-        return (gradients reach aux_colors and means2D only), at the cost of three more blend channels."""
+        return (gradients reach aux_colors and means2D only), at the cost of three more blend channels.
+        ``shs`` may also be the pair (features_dc [N,1,3], features_rest [N,M-1,3]) the Gaussian model stores
+        (scene/gaussian_model.py:183-186 concatenates them on every call): same result without the copy."""
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception('Please provide excatly one of either SHs or precomputed colors!')
         if ((scales is None or rotations is None) and cov3Ds_precomp is None) or \

@@ -128,6 +128,12 @@ class GaussianModel:
         return torch.cat((self._p["f_dc"], self._p["f_rest"]), dim=1)
 
     @property
+    def get_features_pair(self):
+        """(features_dc [N,1,3], features_rest [N,M-1,3]) for the MI355X rasterizer, which reads the two parameters
+        in place (no concatenation forward, no split of the gradient backward)."""
+        return self._p["f_dc"], self._p["f_rest"]
+
+    @property
     def num_points(self):
         return self._p["xyz"].shape[0]
 

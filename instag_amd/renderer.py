@@ -168,8 +168,9 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             if personalized:
                 p_rendered_attn = attn_pass(p_motion_preds)
 
+    shs = pc.get_features_pair if (means3D.is_cuda and hasattr(pc, "get_features_pair")) else pc.get_features
     outs = rasterizer(
-        means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
+        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=ones,
         **({"aux_colors": attn_colors(motion_preds)} if shared else {}))
     image, depth, normal, alpha, radii, extra = outs[:6]

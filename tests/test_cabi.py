@@ -20,14 +20,14 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/instag_hip.h but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.instag_abi_version() == 2
+    assert lib.instag_abi_version() == 3
     assert lib.instag_last_error() is not None
 
 
 def test_struct_layout_matches_header():
     from instag_amd._lib import RasterArgs
-    # 11 x 4-byte scalars (44 B) padded to 48, then 12 pointers
-    assert ctypes.sizeof(RasterArgs) == 48 + 12 * 8
+    # 11 x 4-byte scalars (44 B) padded to 48, then 13 pointers (the last one: shs_rest)
+    assert ctypes.sizeof(RasterArgs) == 48 + 13 * 8
     assert RasterArgs.bg.offset == 48 and RasterArgs.extra_attrs.offset == 48 + 11 * 8
 
 

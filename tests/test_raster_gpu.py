@@ -413,3 +413,38 @@ def test_full_size_properties(n, size, deg):
         assert torch.equal(x, y)
     for k in g1:
         assert torch.equal(gc[k], g1[k]), k
+
+
+@pytest.mark.parametrize("deg", [0, 1, 3])
+def test_split_sh_storage_matches_concatenated(deg):
+    """shs=(dc, rest) == shs=cat(dc, rest): bit-identical images and gradients (no concatenation on the device)."""
+    from instag_amd.diff_gauss import GaussianRasterizer
+    N, size = 3000, 96
+    a, sd = make_scene(N, size, sh_degree=deg, seed=5)
+    st = hip_settings(sd)
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(3, size, size, generator=g).cuda()
+    M = a["shs"].shape[1]
+
+    def run(split):
+        d = {k: a[k].cuda().clone().requires_grad_(True) for k in ("means3D", "opacities", "scales", "rotations")}
+        dc = a["shs"][:, :1].cuda().clone().requires_grad_(True)
+        rest = a["shs"][:, 1:].cuda().clone().requires_grad_(True)
+        m2 = torch.zeros(N, 3, device="cuda", requires_grad=True)
+        shs = (dc, rest) if split else torch.cat([dc, rest], dim=1)
+        outs = GaussianRasterizer(st)(means3D=d["means3D"], means2D=m2, shs=shs, opacities=d["opacities"],
+                                      scales=d["scales"], rotations=d["rotations"],
+                                      extra_attrs=torch.ones(N, 1, device="cuda"))
+        ((outs[0] * w).sum() + outs[3].sum()).backward()
+        grads = {k: v.grad for k, v in d.items()}
+        grads.update(dc=dc.grad, rest=rest.grad if M > 1 else None, m2=m2.grad)
+        return outs, grads
+
+    o_c, g_c = run(False)
+    o_s, g_s = run(True)
+    for x, y in zip(o_s, o_c):
+        assert torch.equal(x, y)
+    for k in g_c:
+        if g_c[k] is None:
+            continue
+        assert g_s[k] is not None and torch.equal(g_s[k], g_c[k]), k
