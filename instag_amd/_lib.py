@@ -124,6 +124,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             from . import build as _build
             _build.build(verbose=False)          # raises if hipcc is missing: no silent fallback
+        # torch first: its wheel bundles its own libamdhip64; loaded before ours, the dynamic linker resolves our
+        # DT_NEEDED entry to that same runtime (one HIP runtime per process).  The other order gives two runtimes and
+        # "no ROCm-capable device is detected" from the second one.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(handle, name)
