@@ -396,6 +396,9 @@ class GraphedStep:
             self.graph_b = torch.cuda.CUDAGraph()
             with _no_gc(), torch.cuda.graph(self.graph_b):
                 with torch.no_grad():
+                    if self.distributed:
+                        # mean over ranks of the summed gradients (the statistics behind them stay sums)
+                        self._bucket[:self._n_grad].mul_(1.0 / dist.get_world_size())
                     scatter_grad_bucket(self._params, self._bucket[:self._n_grad])
                     n = self._norm.numel()
                     norm = self._bucket[self._n_grad:self._n_grad + n].view_as(self._norm)
@@ -413,9 +416,7 @@ class GraphedStep:
         self.graph_a.replay()
         if self.graph_b is not None:
             if self.distributed:
-                world = dist.get_world_size()
-                dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
-                self._bucket[:self._n_grad] /= world
+                dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)       # the division by the world size is in graph B
                 dist.all_reduce(self._rmax, op=dist.ReduceOp.MAX)
             self.graph_b.replay()
 

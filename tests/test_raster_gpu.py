@@ -448,3 +448,17 @@ def test_split_sh_storage_matches_concatenated(deg):
         if g_c[k] is None:
             continue
         assert g_s[k] is not None and torch.equal(g_s[k], g_c[k]), k
+
+
+def test_dp_two_ranks_share_one_gpu():
+    """Data-parallel train step with two ranks on this one card (gloo): replicas stay bit-identical, and the
+    two-graph form used with several ranks agrees with the eager form (tests/dp_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "dp_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    assert r.returncode == 0 and "DP-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
