@@ -181,6 +181,80 @@ class GaussianModel:
         self.spatial_lr_scale = spatial_lr_scale
         return self.load_raw(raw, device)
 
+    # ---- checkpoints (scene/gaussian_model.py:115-166, 430-527) -------------------------------------------------------
+    def construct_list_of_attributes(self):
+        M = self._p["f_rest"].shape[1]
+        names = ["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)]
+        names += [f"f_rest_{i}" for i in range(3 * M)] + ["opacity"]
+        names += [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)]
+        return names
+
+    def _ply_columns(self, xyz, scale, rotation):
+        from collections import OrderedDict
+        import numpy as np
+        xyz = xyz.detach().cpu().numpy()
+        # channel-major like the reference: [N,M,3] -> transpose(1,2) -> [N,3,M] -> flatten
+        f_dc = self._p["f_dc"].detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
+        f_rest = self._p["f_rest"].detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy()
+        cols = np.concatenate((xyz, np.zeros_like(xyz), f_dc, f_rest, self._p["opacity"].detach().cpu().numpy(),
+                               scale.detach().cpu().numpy(), rotation.detach().cpu().numpy()), axis=1)
+        return OrderedDict((k, cols[:, i]) for i, k in enumerate(self.construct_list_of_attributes()))
+
+    def save_ply(self, path):
+        from .ply_io import write_vertex_ply
+        write_vertex_ply(path, self._ply_columns(self._p["xyz"], self._p["scaling"], self._p["rotation"]))
+
+    def save_deformed_ply(self, xyz, scale, rotation, path):
+        """scale is the raw (pre-activation) scale of the deformed Gaussians; stored as log(activation(scale))."""
+        from .ply_io import write_vertex_ply
+        write_vertex_ply(path, self._ply_columns(xyz, torch.log(self.scaling_activation(scale)), rotation))
+
+    def load_ply(self, path, device="cuda"):
+        import numpy as np
+        from .ply_io import read_vertex_ply
+        c = read_vertex_ply(path)
+        n = len(c["x"])
+        M1 = (self.max_sh_degree + 1) ** 2 - 1
+        rest_names = sorted((k for k in c if k.startswith("f_rest_")), key=lambda k: int(k.split("_")[-1]))
+        assert len(rest_names) == 3 * M1, "SH degree of the file does not match the model"
+        stack = lambda names: np.stack([np.asarray(c[k], dtype=np.float32) for k in names], axis=1)
+        f_dc = stack(["f_dc_0", "f_dc_1", "f_dc_2"]).reshape(n, 3, 1)
+        f_rest = stack(rest_names).reshape(n, 3, M1) if M1 else np.zeros((n, 3, 0), np.float32)
+        scale_names = sorted((k for k in c if k.startswith("scale_")), key=lambda k: int(k.split("_")[-1]))
+        rot_names = sorted((k for k in c if k.startswith("rot")), key=lambda k: int(k.split("_")[-1]))
+        raw = dict(xyz=torch.from_numpy(stack(["x", "y", "z"])), opacity=torch.from_numpy(stack(["opacity"])),
+                   features_dc=torch.from_numpy(f_dc).transpose(1, 2).contiguous(),
+                   features_rest=torch.from_numpy(f_rest).transpose(1, 2).contiguous(),
+                   scaling=torch.from_numpy(stack(scale_names)), rotation=torch.from_numpy(stack(rot_names)))
+        self.active_sh_degree = self.max_sh_degree
+        return self.load_raw(raw, device)
+
+    def capture(self):
+        """Same 15-tuple as the reference's checkpoint (GridRenderer state = None: dead code there)."""
+        opt = self.optimizer.state_dict() if hasattr(self.optimizer, "state_dict") else None
+        nmg = None if self.neural_motion_grid is None else self.neural_motion_grid.state_dict()
+        p = self._p
+        return (self.active_sh_degree, p["xyz"], p["f_dc"], p["f_rest"], p["identity"], p["scaling"], p["rotation"],
+                p["opacity"], self.max_radii2D, self.xyz_gradient_accum, self.denom, opt, self.spatial_lr_scale, None, nmg)
+
+    def restore(self, model_args, training_args=None):
+        (self.active_sh_degree, xyz, f_dc, f_rest, identity, scaling, rotation, opacity, max_radii2D,
+         xyz_gradient_accum, denom, opt_dict, self.spatial_lr_scale, _neural_renderer_state, nmg_state) = model_args
+        dev = xyz.device
+        vals = dict(xyz=xyz, f_dc=f_dc, f_rest=f_rest, identity=identity, opacity=opacity, scaling=scaling,
+                    rotation=rotation)
+        self._p = {k: nn.Parameter(v.detach().clone().float().contiguous().requires_grad_(True)) for k, v in vals.items()}
+        self.max_radii2D = max_radii2D.detach().clone()
+        if nmg_state is not None and self.neural_motion_grid is not None:
+            self.neural_motion_grid.load_state_dict(nmg_state)
+        if training_args is not None:
+            self.training_setup(training_args)
+            if opt_dict is not None and hasattr(self.optimizer, "load_state_dict"):
+                self.optimizer.load_state_dict(opt_dict)
+        self.xyz_gradient_accum = xyz_gradient_accum.detach().clone().to(dev)
+        self.denom = denom.detach().clone().to(dev)
+        return self
+
     # ---- optimizer ---------------------------------------------------------------------------------
     def training_setup(self, opt=OptimizationParams, fused: Optional[bool] = None, capturable: bool = False):
         dev = self._p["xyz"].device

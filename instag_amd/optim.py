@@ -124,6 +124,40 @@ class MultiTensorAdam:
         """Call after replacing parameters / state tensors (densify, prune)."""
         self._layout_key = None
 
+    # ---- checkpointing in torch.optim's format (scene/gaussian_model.py:127, :161 store / load optimizer.state_dict()) --
+    def state_dict(self):
+        index, groups = {}, []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                index.setdefault(id(p), len(index))
+                ids.append(index[id(p)])
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "params": ids})
+        state = {}
+        for g in self.param_groups:
+            for p in g["params"]:
+                st = self.state.get(p)
+                if st and "exp_avg" in st:
+                    step = st.get("step")
+                    state[index[id(p)]] = {"step": torch.zeros(()) if step is None else step.detach().reshape(()).clone(),
+                                           "exp_avg": st["exp_avg"], "exp_avg_sq": st["exp_avg_sq"]}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        params = [p for g in self.param_groups for p in g["params"]]
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            for k, v in saved.items():
+                if k != "params":
+                    g[k] = v
+        for idx, st in sd["state"].items():
+            p = params[int(idx)]
+            mine = self._ensure_state(p)
+            mine["exp_avg"].copy_(st["exp_avg"])
+            mine["exp_avg_sq"].copy_(st["exp_avg_sq"])
+            step = torch.as_tensor(st.get("step", 0.0), dtype=torch.float32, device=p.device).reshape(1)
+            mine["step"] = step.clone()
+        self.invalidate()
+
 
 class CombinedAdam(MultiTensorAdam):
     """One launch for several MultiTensorAdam optimizers (the reference steps ``gaussians.optimizer`` and

@@ -360,3 +360,32 @@ def test_deform_activate_with_fused_regulariser():
     assert abs(float(parts.sum()) - float(reg)) <= 1e-6 * max(1.0, abs(float(reg)))
     for k in vals:
         _close(th[k].grad, td[k].grad, "d_" + k, tol=2e-5)
+
+
+def test_multi_tensor_adam_state_dict_roundtrip():
+    from instag_amd.optim import MultiTensorAdam
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(1)
+        return [torch.nn.Parameter(torch.randn(300, 7, device="cuda")), torch.nn.Parameter(torch.randn(41, device="cuda"))]
+    grads = [[torch.randn(300, 7, device="cuda"), torch.randn(41, device="cuda")] for _ in range(4)]
+    pa = make()
+    oa = MultiTensorAdam([{"params": [pa[0]], "lr": 1e-2}, {"params": [pa[1]], "lr": 3e-3}], eps=1e-15)
+    for g in grads[:2]:
+        for p, gg in zip(pa, g):
+            p.grad = gg.clone()
+        oa.step()
+    pb = make()
+    with torch.no_grad():
+        for p, q in zip(pb, pa):
+            p.copy_(q)
+    ob = MultiTensorAdam([{"params": [pb[0]], "lr": 1.0}, {"params": [pb[1]], "lr": 1.0}], eps=1e-15)
+    ob.load_state_dict(oa.state_dict())
+    assert [g["lr"] for g in ob.param_groups] == [1e-2, 3e-3]
+    for g in grads[2:]:
+        for ps, o in ((pa, oa), (pb, ob)):
+            for p, gg in zip(ps, g):
+                p.grad = gg.clone()
+            o.step()
+    for p, q in zip(pa, pb):
+        assert torch.equal(p, q)

@@ -110,3 +110,54 @@ def test_grad_bucket_roundtrip():
     assert b.shape == (13,) and float(b[10:].abs().max()) == 0
     scatter_grad_bucket(ps, b * 2)
     assert torch.equal(ps[0].grad, torch.arange(10.0).view(5, 2) * 2) and ps[1].grad is not None
+
+
+def test_ply_roundtrip_and_reference_layout(tmp_path):
+    """save_ply / load_ply without the plyfile package: header and column order of scene/gaussian_model.py:430-463,
+    channel-major SH flattening (:447-448), exact float32 round trip; an ASCII file of the same layout is readable."""
+    import numpy as np
+    from instag_amd.gaussian_model import GaussianModel
+    from instag_amd.ply_io import read_vertex_ply
+    gm = GaussianModel(1).create_random(37, "cpu", seed=3)
+    with torch.no_grad():
+        gm._p["f_rest"].copy_(torch.randn_like(gm._p["f_rest"]))
+    path = str(tmp_path / "pc" / "point_cloud.ply")
+    gm.save_ply(path)
+    head = open(path, "rb").read(2048).split(b"end_header\n")[0].decode().splitlines()
+    assert head[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 37"]
+    names = [h.split()[-1] for h in head[3:]]
+    assert all(h.startswith("property float ") for h in head[3:])
+    assert names == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(9)] \
+        + ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    cols = read_vertex_ply(path)
+    # f_rest_k = channel k // 3 ... of the [N,3,M-1] view: f_rest_0..2 are the R channel's coefficients 1..3
+    assert np.array_equal(cols["f_rest_1"], gm._p["f_rest"][:, 1, 0].detach().numpy())
+    gm2 = GaussianModel(1).load_ply(path, device="cpu")
+    for k in ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"):
+        assert torch.equal(gm2._p[k], gm._p[k].detach()), k
+    # ASCII variant
+    apath = str(tmp_path / "ascii.ply")
+    with open(apath, "w") as fh:
+        fh.write("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 37\n")
+        fh.write("".join(f"property float {n}\n" for n in names) + "end_header\n")
+        for i in range(37):
+            fh.write(" ".join(repr(float(cols[n][i])) for n in names) + "\n")
+    gm3 = GaussianModel(1).load_ply(apath, device="cpu")
+    assert torch.equal(gm3._p["xyz"], gm._p["xyz"].detach())
+
+
+def test_capture_restore_roundtrip():
+    from instag_amd.gaussian_model import GaussianModel, OptimizationParams
+    gm = GaussianModel(1).create_random(50, "cpu", seed=1)
+    gm.training_setup(OptimizationParams, fused=False)
+    for p in gm.per_gaussian_parameters():
+        p.grad = torch.randn_like(p)
+    gm.optimizer.step()
+    ckpt = gm.capture()
+    assert len(ckpt) == 15
+    gm2 = GaussianModel(1).create_random(50, "cpu", seed=9)
+    gm2.restore(ckpt, OptimizationParams)
+    for k in gm._p:
+        assert torch.equal(gm2._p[k], gm._p[k])
+    s1, s2 = gm.optimizer.state_dict()["state"], gm2.optimizer.state_dict()["state"]
+    assert len(s1) == len(s2) and all(torch.equal(s1[i]["exp_avg"], s2[i]["exp_avg"]) for i in s1)
