@@ -60,6 +60,42 @@ def quat_to_rotmat(q):
     return R.view(-1, 3, 3)
 
 
+def sh_basis(deg: int, dirs: torch.Tensor) -> torch.Tensor:
+    """Real spherical-harmonic basis [N, (deg+1)^2] at unit directions, in the coefficient order and sign
+    convention of utils/sh_utils.py:57-117 (degree <= 3); normalisation constants from their closed forms."""
+    assert 0 <= deg <= 3
+    x, y, z = dirs[..., 0], dirs[..., 1], dirs[..., 2]
+    pi = math.pi
+    cols = [torch.full_like(x, 0.5 / math.sqrt(pi))]
+    if deg >= 1:
+        k1 = math.sqrt(3.0 / (4.0 * pi))
+        cols += [-k1 * y, k1 * z, -k1 * x]
+    if deg >= 2:
+        xx, yy, zz = x * x, y * y, z * z
+        k2 = 0.5 * math.sqrt(15.0 / pi)
+        cols += [k2 * x * y, -k2 * y * z, 0.25 * math.sqrt(5.0 / pi) * (2.0 * zz - xx - yy), -k2 * x * z,
+                 0.5 * k2 * (xx - yy)]
+    if deg >= 3:
+        a = 0.25 * math.sqrt(35.0 / (2.0 * pi))
+        b = 0.5 * math.sqrt(105.0 / pi)
+        c = 0.25 * math.sqrt(21.0 / (2.0 * pi))
+        d = 0.25 * math.sqrt(7.0 / pi)
+        cols += [-a * y * (3 * xx - yy), b * x * y * z, -c * y * (4 * zz - xx - yy),
+                 d * z * (2 * zz - 3 * xx - 3 * yy), -c * x * (4 * zz - xx - yy), 0.5 * b * z * (xx - yy),
+                 -a * x * (xx - 3 * yy)]
+    return torch.stack(cols, dim=-1)
+
+
+def sh_to_rgb(deg: int, features: torch.Tensor, xyz: torch.Tensor, camera_center: torch.Tensor) -> torch.Tensor:
+    """View-dependent colour clamp_min(eval_sh + 0.5, 0) of features [N, M, 3] seen from camera_center
+    (train_face.py:729-741, gaussian_renderer/__init__.py:100-104)."""
+    d = xyz - camera_center.reshape(1, 3)
+    d = d / d.norm(dim=1, keepdim=True)
+    m = (deg + 1) ** 2
+    rgb = torch.einsum("nm,nmc->nc", sh_basis(deg, d), features[:, :m, :])
+    return torch.clamp_min(rgb + 0.5, 0.0)
+
+
 class OptimizationParams:
     """Hot-path values of /root/reference/arguments/__init__.py:79-99."""
     iterations = 10000

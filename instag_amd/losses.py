@@ -52,6 +52,30 @@ def ssim(img1, img2, window_size=11, size_average=True):
     return m.mean() if size_average else m.mean(1).mean(1).mean(1)
 
 
+def normalize(input, mean=None, std=None):
+    """utils/loss_utils.py:17-20: per-row standardisation whose denominator is padded by 1 % of the global std."""
+    input_mean = torch.mean(input, dim=1, keepdim=True) if mean is None else mean
+    input_std = torch.std(input, dim=1, keepdim=True) if std is None else std
+    return (input - input_mean) / (input_std + 1e-2 * torch.std(input.reshape(-1)))
+
+
+def geometry_prior_loss(normal, depth, gt_normal, gt_depth, face_mask, hair_mask, mouth_mask, use_depth=True,
+                        w_normal=0.01, w_depth=1e-2):
+    """Few-shot geometry priors of the face branch after warm_step + 2000 (train_face.py:458-504): the rendered
+    normal against the monocular normal (1 - n_gt * n per channel, summed over channels, mean over head minus
+    mouth) and, outside the 100 iterations after an opacity reset, the standardised rendered depth against the
+    standardised monocular depth (mean |.| over face minus mouth).  normal [3,H,W], depth [1,H,W] or [H,W]."""
+    head = face_mask | hair_mask
+    m = (head ^ mouth_mask).to(normal.dtype)
+    per_px = (1.0 - gt_normal * normal).sum(0)
+    loss = w_normal * (per_px * m).sum() / m.sum()
+    if use_depth:
+        d = depth[0] if depth.dim() == 3 else depth
+        sel = (face_mask ^ mouth_mask).to(d.dtype)       # masked means as sums: no host round trip (graph capture)
+        loss = loss + w_depth * ((normalize(d) - normalize(gt_depth)).abs() * sel).sum() / sel.sum()
+    return loss
+
+
 def psnr(img1, img2):
     mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
     return 20 * torch.log10(1.0 / torch.sqrt(mse))

@@ -12,6 +12,10 @@ from . import _lib
 from ._lib import check, ptr
 
 
+# multiply-add work launched so far (2 flops per MAC), read by bench.py for the MFMA roofline of the MLP kernels
+STATS = {"fwd_flops": 0, "bwd_flops": 0}
+
+
 def supported(dim_in, dim_hidden, dim_out, num_layers) -> bool:
     return num_layers in (2, 3) and 1 <= dim_in <= 96 and 1 <= dim_hidden <= 64 and 1 <= dim_out <= 32
 
@@ -42,6 +46,7 @@ class _FusedMLP(torch.autograd.Function):
         ctx.save_for_backward(x, w1c, w2c, w3c, a1, a2)
         ctx.weights = (w1, w2, w3)          # the caller's tensors (leaf parameters in the deferred-gradient mode)
         ctx.dims = (N, K0, H, O, NL)
+        STATS["fwd_flops"] += 2 * N * (K0 * H + (H * H if NL == 3 else 0) + H * O)
         return y
 
     @staticmethod
@@ -57,6 +62,7 @@ class _FusedMLP(torch.autograd.Function):
         dx = torch.empty(N, K0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         check(L.instag_mlp_backward(ptr(dy), ptr(a1), ptr(a2), ptr(w1), ptr(w2), ptr(w3), ptr(dz1), ptr(dz2), ptr(dx),
                                     N, K0, H, O, NL, stream), "mlp_backward")
+        STATS["bwd_flops"] += 2 * N * (H * O + (H * H if NL == 3 else 0) + (K0 * H if dx is not None else 0))
         # weight gradients: only the optimizer reads them.  Inside a ``deferred_grads`` block (instag_amd/deferred.py)
         # they are queued and computed after the rest of the backward pass in one batched launch
         from . import deferred

@@ -114,8 +114,10 @@ def activated(params):
     )
 
 
-def synthetic_frame(size=512, seed=0, device="cpu"):
-    """Per-frame training inputs of config C3 (audio window, AU vector, GT image, masks)."""
+def synthetic_frame(size=512, seed=0, device="cpu", priors=False, background=False):
+    """Per-frame training inputs of config C3 (audio window, AU vector, GT image, masks).  ``priors`` adds the
+    monocular normal [3,H,W] (unit vectors) / depth [H,W] maps of train_face.py:466-504, ``background`` the
+    per-camera scene background [3,H,W] of train_fuse_con.py:113."""
     g = torch.Generator().manual_seed(1000 + seed)
     auds = torch.randn(8, 29, 16, generator=g)
     au_exp = torch.rand(6, generator=g)
@@ -131,4 +133,9 @@ def synthetic_frame(size=512, seed=0, device="cpu"):
                               int(c - 0.1 * size), int(c + 0.1 * size)], dtype=torch.int32)
     out = dict(auds=auds, au_exp=au_exp, gt_image=gt, face_mask=head, hair_mask=hair, mouth_mask=mouth,
                lips_rect=lips_rect)
+    if priors:
+        out["normal"] = torch.nn.functional.normalize(torch.randn(3, size, size, generator=g), dim=0)
+        out["depth"] = 0.8 + 0.1 * torch.rand(size, size, generator=g)
+    if background:
+        out["background"] = torch.rand(3, size, size, generator=g)
     return {k: v.to(device) for k, v in out.items()}

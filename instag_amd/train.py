@@ -46,9 +46,15 @@ class Frame:
 
     TENSORS = ("world_view_transform", "full_proj_transform", "camera_center", "original_image")
     DICT_TENSORS = ("auds", "au_exp", "face_mask", "hair_mask", "mouth_mask", "lips_rect")
+    # present only for the stages that read them: monocular normal [3,H,W] / depth [H,W] priors
+    # (train_face.py:466-504), per-camera scene background [3,H,W] in [0,1] (train_fuse_con.py:113)
+    OPTIONAL_DICT_TENSORS = ("normal", "depth", "background")
+
+    def _dict_keys(self):
+        return self.DICT_TENSORS + tuple(k for k in self.OPTIONAL_DICT_TENSORS if self.talking_dict.get(k) is not None)
 
     def _named_tensors(self):
-        return [(k, getattr(self, k)) for k in self.TENSORS] + [(k, self.talking_dict[k]) for k in self.DICT_TENSORS]
+        return [(k, getattr(self, k)) for k in self.TENSORS] + [(k, self.talking_dict[k]) for k in self._dict_keys()]
 
     def packed(self, device=None) -> "Frame":
         """Copy whose tensors are views into ONE byte buffer, so that feeding a frame to a captured step is a
@@ -66,7 +72,7 @@ class Frame:
             v = buf[o:o + nbytes].view(t.dtype).view(t.shape)
             v.copy_(t)
             views[k] = v
-        td = {k: views[k] for k in self.DICT_TENSORS}
+        td = {k: views[k] for k in self._dict_keys()}
         f = Frame(self.image_height, self.image_width, self.FoVx, self.FoVy, views["world_view_transform"],
                   views["full_proj_transform"], views["camera_center"], td, views["original_image"])
         f._buf = buf
@@ -86,7 +92,7 @@ class Frame:
             return
         for k in self.TENSORS:
             getattr(self, k).copy_(getattr(other, k), non_blocking=True)
-        for k in self.DICT_TENSORS:
+        for k in self._dict_keys():
             self.talking_dict[k].copy_(other.talking_dict[k], non_blocking=True)
 
 
@@ -94,6 +100,9 @@ def make_frame(cam, frame_data) -> Frame:
     td = dict(auds=frame_data["auds"], au_exp=frame_data["au_exp"], face_mask=frame_data["face_mask"],
               hair_mask=frame_data["hair_mask"], mouth_mask=frame_data["mouth_mask"],
               lips_rect=frame_data["lips_rect"])
+    for k in Frame.OPTIONAL_DICT_TENSORS:
+        if frame_data.get(k) is not None:
+            td[k] = frame_data[k]
     f = Frame(cam.image_height, cam.image_width, cam.FoVx, cam.FoVy, cam.world_view_transform,
               cam.full_proj_transform, cam.camera_center, td, frame_data["gt_image"])
     return f.packed() if frame_data["gt_image"].is_cuda else f
@@ -135,11 +144,39 @@ def allreduce_gradients(params: List[torch.Tensor], extras: Optional[List[torch.
         o += e.numel()
 
 
+@dataclass(frozen=True)
+class FacePhase:
+    """What a face-branch iteration computes (train_face.py:340-350, 426-575)."""
+    align: bool = True             # personalised field's alignment on (iteration > 1000)
+    warm: bool = True              # iteration > warm_step: motion / alpha / attention regularisers
+    hair_mask_iter: bool = False   # hair painted to background in image and target, hair attention terms off
+    priors: bool = False           # iteration > warm_step + 2000: monocular-normal term
+    prior_depth: bool = False      # ... and, outside the 100 iterations after an opacity reset, the depth term
+
+
+C3_PHASE = FacePhase()             # the phase config C3 / bench.py measures (warm_step < iteration <= warm_step + 2000)
+
+
+def face_phase(iteration: int, opt=OptimizationParams, warm_step: int = 3000, hair_mask_interval: int = 7,
+               mode_long: bool = False) -> FacePhase:
+    """Phase of iteration `iteration` under the reference's schedule (train_face.py:39-46, 340-350, 458-478)."""
+    lpips_start_iter = opt.densify_until_iter - 1500
+    hair = (warm_step < iteration < lpips_start_iter - 1000) and iteration % hair_mask_interval != 0
+    align = iteration > 1000 if iteration < warm_step else True
+    priors = (not mode_long) and iteration > warm_step + 2000
+    return FacePhase(align=align, warm=iteration > warm_step, hair_mask_iter=hair, priors=priors,
+                     prior_depth=priors and iteration % opt.opacity_reset_interval > 100)
+
+
 class FaceTrainer:
-    """Holds the Gaussians, the UMF (motion_net) and the PMF (gaussians.neural_motion_grid) and steps them."""
+    """Holds the Gaussians, the UMF (motion_net) and the PMF (gaussians.neural_motion_grid) and steps them.
+    ``schedule=None`` runs every step in the C3 phase; ``schedule="reference"`` follows train_face.py's
+    iteration-dependent phases (face_phase) and its densification order."""
 
     def __init__(self, gaussians: GaussianModel, motion_net, background, opt=OptimizationParams,
-                 cameras_extent: float = 0.2, densify: bool = True, seed: int = 0):
+                 cameras_extent: float = 0.2, densify: bool = True, seed: int = 0, schedule: Optional[str] = None):
+        assert schedule in (None, "reference")
+        self.schedule = schedule
         self.g = gaussians
         self.motion_net = motion_net
         self.bg = background
@@ -203,8 +240,13 @@ class FaceTrainer:
         return ps
 
     # ---- loss block (train_face.py:450-456, 508-540) --------------------------------------------------------
-    def loss_fn(self, frame: Frame, pkg, warm: bool, hair_mask_iter: bool = False):
-        """-> (loss, Ll1).  `warm` = iteration > warm_step: motion regularisers, alpha and attention terms."""
+    def phase_of(self, it: int) -> FacePhase:
+        return face_phase(it, self.opt) if self.schedule == "reference" else C3_PHASE
+
+    def loss_fn(self, frame: Frame, pkg, warm: bool, hair_mask_iter: bool = False, priors: bool = False,
+                prior_depth: bool = False):
+        """-> (loss, Ll1).  `warm` = iteration > warm_step: motion regularisers, alpha and attention terms;
+        `priors` / `prior_depth`: the monocular normal / depth terms of train_face.py:458-504."""
         dev = self.bg.device
         td = frame.talking_dict
         extra = alpha = attn = lips = None
@@ -220,16 +262,24 @@ class FaceTrainer:
                 extra = (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()
                          + m["d_scale"].abs().mean() + pm["p_xyz"].abs().mean())
             alpha, attn, lips = pkg["alpha"], pkg["attn"], td["lips_rect"].to(dev)
-        return face_loss(pkg["render"], frame.original_image.to(dev), td["face_mask"].to(dev), td["hair_mask"].to(dev),
-                         td["mouth_mask"].to(dev), self.bg, alpha=alpha, attn=attn, lips_rect=lips, extra=extra,
-                         lambda_dssim=self.opt.lambda_dssim, w_extra=w_extra, hair_mask_iter=hair_mask_iter)
+        loss, Ll1 = face_loss(pkg["render"], frame.original_image.to(dev), td["face_mask"].to(dev),
+                              td["hair_mask"].to(dev), td["mouth_mask"].to(dev), self.bg, alpha=alpha, attn=attn,
+                              lips_rect=lips, extra=extra, lambda_dssim=self.opt.lambda_dssim, w_extra=w_extra,
+                              hair_mask_iter=hair_mask_iter)
+        if priors:
+            from .losses import geometry_prior_loss
+            loss = loss + geometry_prior_loss(pkg["normal"], pkg["depth"], td["normal"].to(dev),
+                                              td["depth"].to(dev) if prior_depth else None, td["face_mask"].to(dev),
+                                              td["hair_mask"].to(dev), td["mouth_mask"].to(dev), use_depth=prior_depth)
+        return loss, Ll1
 
     # ---- one step ---------------------------------------------------------------------------------------------
-    def _forward_backward(self, frame: Frame):
+    def _forward_backward(self, frame: Frame, phase: FacePhase = C3_PHASE):
         from .renderer import render_motion
         pkg = render_motion(frame, self.g, self.motion_net, None, self.bg, return_attn=True, personalized=False,
-                            align=True, motion_reg_weight=1e-5)
-        loss, Ll1 = self.loss_fn(frame, pkg, warm=True)
+                            align=phase.align, motion_reg_weight=1e-5 if phase.warm else None)
+        loss, Ll1 = self.loss_fn(frame, pkg, warm=phase.warm, hair_mask_iter=phase.hair_mask_iter,
+                                 priors=phase.priors, prior_depth=phase.prior_depth)
         from .deferred import deferred_grads
         with deferred_grads(self.device if self.on_gpu else None):
             # the MLPs' weight gradients are batched into one launch at the end (deferred.py); the root gradient is
@@ -243,48 +293,104 @@ class FaceTrainer:
         return pkg, loss, Ll1
 
     @torch.no_grad()
-    def _stats_and_optimizers(self, pkg, distributed: bool):
-        vs_grad = pkg["viewspace_points"].grad
+    def _update_stats(self, vs_grad, radii):
+        """Densification statistics of this rank's frame (train_face.py:670-671; scene/gaussian_model.py:683-685).
+        With several ranks they stay LOCAL sums / maxima and are exchanged once, when a densification reads them
+        (sync_densification_stats): sum and max commute with the per-step accumulation."""
         g = self.g
-        if not distributed and vs_grad.is_cuda and g.max_radii2D.dtype == torch.float32 \
-                and pkg["radii"].dtype == torch.int32 and vs_grad.is_contiguous():
+        if vs_grad.is_cuda and g.max_radii2D.dtype == torch.float32 and radii.dtype == torch.int32 \
+                and vs_grad.is_contiguous():
             from .glue import densify_stats
-            densify_stats(vs_grad, pkg["radii"], g.max_radii2D, g.xyz_gradient_accum, g.denom)
-            self._step_optimizers()
+            densify_stats(vs_grad, radii, g.max_radii2D, g.xyz_gradient_accum, g.denom)
             return
-        vis = pkg["visibility_filter"]
-        radii = pkg["radii"].to(self.g.max_radii2D.dtype)
-        norm = torch.norm(vs_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
-        cnt = vis[:, None].to(norm.dtype)
-        rmax = torch.where(vis, radii, torch.zeros_like(radii))
+        vis = radii > 0
+        rmax = torch.where(vis, radii.to(g.max_radii2D.dtype), torch.zeros_like(g.max_radii2D))
+        g.max_radii2D.copy_(torch.max(g.max_radii2D, rmax))
+        g.add_densification_stats(vs_grad, vis)
+
+    @torch.no_grad()
+    def sync_densification_stats(self):
+        """Several ranks: every replica gets the statistics of all ranks' frames (sum of the gradient norms and
+        visibility counts, maximum of the screen radii) before a densification decides on them."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        g = self.g
+        both = torch.cat([g.xyz_gradient_accum.reshape(-1), g.denom.reshape(-1)])
+        dist.all_reduce(both, op=dist.ReduceOp.SUM)
+        n = g.xyz_gradient_accum.numel()
+        g.xyz_gradient_accum.copy_(both[:n].view_as(g.xyz_gradient_accum))
+        g.denom.copy_(both[n:].view_as(g.denom))
+        dist.all_reduce(g.max_radii2D, op=dist.ReduceOp.MAX)
+
+    @torch.no_grad()
+    def _stats_and_optimizers(self, pkg, distributed: bool, it: Optional[int] = None, frame: Optional[Frame] = None):
+        """Everything of an iteration behind loss.backward(), in the reference's order (train_face.py:667-788):
+        statistics -> [gradient exchange] -> [densify / prune / opacity reset] -> optimizers."""
+        self._update_stats(pkg["viewspace_points"].grad, pkg["radii"])
         if distributed:
-            # statistics become the sum over ranks; gradients the mean (== accumulation over the ranks' frames)
-            allreduce_gradients(self._all_params(), extras=[norm, cnt])
-            dist.all_reduce(rmax, op=dist.ReduceOp.MAX)
-        self.g.max_radii2D.copy_(torch.max(self.g.max_radii2D, rmax))
-        self.g.xyz_gradient_accum.add_(norm)
-        self.g.denom.add_(cnt)
+            allreduce_gradients(self._all_params())
+        if it is not None:
+            self._maybe_densify(it, frame)
         self._step_optimizers()
 
     def _zero_grad(self):
         self.motion_optimizer.zero_grad(set_to_none=True)
         self.g.optimizer.zero_grad(set_to_none=True)
 
-    def _maybe_densify(self, it):
-        if self.densify and it < self.opt.densify_until_iter and it > self.opt.densify_from_iter \
-                and it % self.opt.densification_interval == 0:
-            size_threshold = 20 if it > self.opt.opacity_reset_interval else None
-            self.g.densify_and_prune(self.opt.densify_grad_threshold, 0.05 + 0.25 * it / self.opt.densify_until_iter,
-                                     self.extent, size_threshold, generator=self.gen)
-            self._graph = None        # N changed: the captured graph is stale
-            return True
-        return False
+    def _densify_due(self, it):
+        o = self.opt
+        if not self.densify:
+            return False
+        densify = it < o.densify_until_iter and it > o.densify_from_iter and it % o.densification_interval == 0
+        reset = it < o.densify_until_iter and it % o.opacity_reset_interval == 0
+        prune = self.schedule == "reference" and it > o.densify_from_iter and it % o.densification_interval == 0
+        return densify or reset or prune
+
+    @torch.no_grad()
+    def _maybe_densify(self, it, frame: Optional[Frame] = None):
+        """Adaptive density control of the face branch (train_face.py:667-746).  Runs BEFORE the optimizers, as in
+        the reference: the rebuilt Gaussian parameters carry no gradient, so only the motion network steps in such an
+        iteration.  Any change of the parameter set drops a captured graph."""
+        if not self._densify_due(it):
+            return False
+        o = self.opt
+        interval_hit = it > o.densify_from_iter and it % o.densification_interval == 0
+        if it < o.densify_until_iter:
+            if interval_hit:
+                self.sync_densification_stats()
+                size_threshold = 20 if it > o.opacity_reset_interval else None
+                self.g.densify_and_prune(o.densify_grad_threshold, 0.05 + 0.25 * it / o.densify_until_iter,
+                                         self.extent, size_threshold, generator=self.gen)
+            if it % o.opacity_reset_interval == 0:
+                self.g.reset_opacity()
+        if self.schedule == "reference" and interval_hit:
+            # train_face.py:729-746: Gaussians that took the background's green, and the ones behind z = -0.07
+            from .gaussian_model import sh_to_rgb
+            center = frame.camera_center.to(self.device)
+            rgb = sh_to_rgb(self.g.active_sh_degree, self.g.get_features, self.g.get_xyz, center)
+            green = (rgb[:, 0] < 30 / 255) & (rgb[:, 1] > 225 / 255) & (rgb[:, 2] < 30 / 255)
+            self.g.prune_points(green)
+            self.g.prune_points(self.g.get_xyz[:, -1] < -0.07)
+        self._drop_graph()
+        return True
+
+    def _drop_graph(self):
+        if self._graph is not None:
+            from . import diff_gauss
+            diff_gauss.set_capacity_plan(None)
+        self._graph = None
+        self._graph_phase = None
 
     def step(self, frame: Frame):
         self.iteration += 1
         it = self.iteration
         self._set_learning_rates(it)
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        phase = self.phase_of(it)
+        if self._graph is not None and (self._densify_due(it) or phase != getattr(self, "_graph_phase", phase)):
+            # the captured launches belong to another phase / another parameter set: run this step eagerly
+            # (enable_graph() captures the new phase when the caller asks for it again)
+            self._drop_graph()
         if self._graph is not None:
             self._graph.replay(frame)
             loss, Ll1 = self._graph.loss, self._graph.l1
@@ -292,11 +398,10 @@ class FaceTrainer:
             from . import diff_gauss
             if diff_gauss._CAPACITY_PLAN is not None:
                 diff_gauss._CAPACITY_PLAN.begin_step()
-            pkg, loss, Ll1 = self._forward_backward(frame)
-            self._stats_and_optimizers(pkg, distributed)
+            pkg, loss, Ll1 = self._forward_backward(frame, phase)
+            self._stats_and_optimizers(pkg, distributed, it, frame)
             self._zero_grad()
-        self._maybe_densify(it)
-        self.last = dict(loss=loss.detach(), l1=Ll1.detach(), num_points=self.g.num_points)
+        self.last = dict(loss=loss.detach(), l1=Ll1.detach(), num_points=self.g.num_points, phase=phase)
         return self.last
 
     # ---- graph mode --------------------------------------------------------------------------------------------
@@ -304,9 +409,12 @@ class FaceTrainer:
                      split_for_allreduce: Optional[bool] = None):
         """Capture the whole step into a hipGraph.  Runs `warmup_steps` eager steps plus two capacity-mode steps
         first (they advance the iteration counter like any other step) to measure the instance counts and warm
-        every library."""
+        every library.  The graph holds the launches of the NEXT iteration's phase (FacePhase); step() falls back
+        to eager launches when the schedule moves to another phase or the parameter set changes."""
         self._graph = None
-        self._graph = GraphedStep(self, example_frame, headroom, warmup_steps, split_for_allreduce)
+        phase = self.phase_of(self.iteration + max(1, warmup_steps) + 3)       # the iteration right after capture
+        self._graph = GraphedStep(self, example_frame, headroom, warmup_steps, split_for_allreduce, phase)
+        self._graph_phase = phase
         return self._graph
 
 
@@ -329,8 +437,9 @@ class _no_gc:
 
 class GraphedStep:
     def __init__(self, trainer: FaceTrainer, example: Frame, headroom: float, warmup_steps: int,
-                 split_for_allreduce: Optional[bool] = None):
+                 split_for_allreduce: Optional[bool] = None, phase: FacePhase = C3_PHASE):
         from . import diff_gauss
+        self.phase = phase
         t = self.trainer = trainer
         dev = t.device
         assert dev.type == "cuda", "graph mode needs the GPU"
@@ -344,7 +453,7 @@ class GraphedStep:
         for _ in range(max(1, warmup_steps)):
             t.iteration += 1
             t._set_learning_rates(t.iteration)
-            pkg, _, _ = t._forward_backward(self.static)
+            pkg, _, _ = t._forward_backward(self.static, phase)
             t._stats_and_optimizers(pkg, self.distributed)
             t._zero_grad()
             del pkg        # a live autograd graph keeps grad accumulators bound to this (non-capture) stream
@@ -360,7 +469,7 @@ class GraphedStep:
                 t.iteration += 1
                 t._set_learning_rates(t.iteration)
                 self.plan.begin_step()
-                pkg, _, _ = t._forward_backward(self.static)
+                pkg, _, _ = t._forward_backward(self.static, phase)
                 t._stats_and_optimizers(pkg, self.distributed)
                 t._zero_grad()
                 del pkg
@@ -368,44 +477,34 @@ class GraphedStep:
         torch.cuda.synchronize(dev)
         # 3. capture.  With several ranks the gradient exchange stays outside the graphs:
         #    graph A = forward + backward (+ bucket fill), eager all-reduce, graph B = statistics + optimizers.
+        # other threads (the collective library's watchdog) may touch the HIP runtime while this thread captures
+        mode = {"capture_error_mode": "thread_local"} if self.distributed else {}
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         self.plan.begin_step()
         if not self.split:
-            with _no_gc(), torch.cuda.graph(self.graph_a):
-                pkg, loss, l1 = t._forward_backward(self.static)
+            with _no_gc(), torch.cuda.graph(self.graph_a, **mode):
+                pkg, loss, l1 = t._forward_backward(self.static, phase)
                 t._stats_and_optimizers(pkg, False)
                 t._zero_grad()
             # nothing captured is released before the capture has ended (ROCm 7.2: frees inside the capture
             # window intermittently crash hipStreamEndCapture)
             del pkg
         else:
-            with _no_gc(), torch.cuda.graph(self.graph_a):
-                pkg, loss, l1 = t._forward_backward(self.static)
-                vis = pkg["visibility_filter"]
-                vs_grad = pkg["viewspace_points"].grad
-                self._norm = torch.norm(vs_grad[:, :2], dim=-1, keepdim=True) * vis[:, None]
-                self._cnt = vis[:, None].to(self._norm.dtype)
-                radii = pkg["radii"].to(t.g.max_radii2D.dtype)
-                self._rmax = torch.where(vis, radii, torch.zeros_like(radii))
+            with _no_gc(), torch.cuda.graph(self.graph_a, **mode):
+                pkg, loss, l1 = t._forward_backward(self.static, phase)
+                self._vs_grad, self._radii = pkg["viewspace_points"].grad, pkg["radii"]
                 self._params = t._all_params()
-                self._bucket = torch.cat([flat_grad_bucket(self._params), self._norm.reshape(-1),
-                                          self._cnt.reshape(-1)])
+                self._bucket = flat_grad_bucket(self._params)
             del pkg
-            self._n_grad = sum(p.numel() for p in self._params)
             self.graph_b = torch.cuda.CUDAGraph()
-            with _no_gc(), torch.cuda.graph(self.graph_b):
+            with _no_gc(), torch.cuda.graph(self.graph_b, **mode):
                 with torch.no_grad():
                     if self.distributed:
-                        # mean over ranks of the summed gradients (the statistics behind them stay sums)
-                        self._bucket[:self._n_grad].mul_(1.0 / dist.get_world_size())
-                    scatter_grad_bucket(self._params, self._bucket[:self._n_grad])
-                    n = self._norm.numel()
-                    norm = self._bucket[self._n_grad:self._n_grad + n].view_as(self._norm)
-                    cnt = self._bucket[self._n_grad + n:].view_as(self._cnt)
-                    t.g.max_radii2D.copy_(torch.max(t.g.max_radii2D, self._rmax))
-                    t.g.xyz_gradient_accum.add_(norm)
-                    t.g.denom.add_(cnt)
+                        # mean over ranks of the summed gradients
+                        self._bucket.mul_(1.0 / dist.get_world_size())
+                    scatter_grad_bucket(self._params, self._bucket)
+                    t._update_stats(self._vs_grad, self._radii)        # local; exchanged when a densification reads them
                     t._step_optimizers()
                     t._zero_grad()
         self.loss, self.l1 = loss, l1
@@ -417,7 +516,6 @@ class GraphedStep:
         if self.graph_b is not None:
             if self.distributed:
                 dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)       # the division by the world size is in graph B
-                dist.all_reduce(self._rmax, op=dist.ReduceOp.MAX)
             self.graph_b.replay()
 
     def check_overflow(self):

@@ -1,0 +1,240 @@
+"""Train steps of the two stages that follow the face branch: the mouth branch and the face+mouth fuse stage.
+
+Counterparts of /root/reference/train_mouth.py:106-293 and /root/reference/train_fuse_con.py:75-245 restricted to
+the hot path (render -> loss -> backward -> statistics / density control -> optimizers).  Same kernels as the face
+branch behind other callers: ``render_motion_mouth_con`` / ``render_motion`` of
+instag_amd/renderer.py, the fused L1+SSIM operator, the single-launch Adam.  Frame selection by AU25, LPIPS,
+logging and checkpoint cadence are the reference's data pipeline / control plane and stay out.
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .gaussian_model import GaussianModel, OptimizationParams, sh_to_rgb
+from .losses import l1_and_ssim
+from .train import Frame
+
+GEOMETRY = ("xyz", "opacity", "scaling", "rotation")
+
+
+def _lips_mask(like: torch.Tensor, lips_rect) -> torch.Tensor:
+    """lips_mask[xmin:xmax, ymin:ymax] = True (train_mouth.py:168-170: the rect indexes rows first)."""
+    r0, r1, c0, c1 = [int(v) for v in (lips_rect.tolist() if torch.is_tensor(lips_rect) else lips_rect)]
+    m = torch.zeros_like(like, dtype=torch.bool)
+    m[r0:r1, c0:c1] = True
+    return m
+
+
+def mouth_loss(image, alpha, gt, mouth_mask, lips_mask, bg, p_xyz=None, warm=True, lambda_dssim=0.2):
+    """Loss block of the mouth branch (train_mouth.py:186-221) -> (loss, Ll1).  Outside the lips rectangle the
+    mouth-mask fringe of the render is painted with the background; the target shows the image inside the mouth mask
+    only.  ``warm`` (iteration > warm_step) adds the alignment and alpha terms."""
+    bg3 = bg[:, None, None]
+    gt_green = torch.where(mouth_mask[None], gt, bg3.expand_as(gt))
+    image_green = torch.where((lips_mask ^ mouth_mask)[None], bg3.expand_as(image), image)
+    Ll1, s = l1_and_ssim(image_green, gt_green)
+    loss = Ll1 + lambda_dssim * (1.0 - s)
+    if warm:
+        lm = lips_mask.to(alpha.dtype)
+        if p_xyz is not None:
+            loss = loss + 1e-5 * p_xyz.abs().mean()
+        loss = loss + 1e-3 * (((1 - alpha) * lm).mean() + (alpha * (1 - lm)).mean())
+    return loss, Ll1
+
+
+def fuse_loss(image, gt, lambda_dssim=0.2):
+    """train_fuse_con.py:176-181 (iteration >= bg_iter = 0, always): whole-frame L1 + DSSIM -> (loss, Ll1)."""
+    Ll1, s = l1_and_ssim(image, gt)
+    return Ll1 + lambda_dssim * (1.0 - s), Ll1
+
+
+@dataclass(frozen=True)
+class MouthPhase:
+    align: bool = True
+    warm: bool = True
+    late: bool = False        # iteration > bg_iter: black background, geometry and the motion field frozen
+
+
+def mouth_phase(iteration: int, opt=OptimizationParams, warm_step: int = 3000,
+                bg_iter: Optional[int] = None) -> MouthPhase:
+    """train_mouth.py:48-52, 152-196 (mode_long = False): bg_iter = motion_stop_iter = iterations - 1000."""
+    bg_iter = opt.iterations - 1000 if bg_iter is None else bg_iter
+    align = iteration > 1000 if iteration < warm_step else True
+    return MouthPhase(align=align, warm=iteration > warm_step, late=iteration > bg_iter)
+
+
+def _make_optimizers(gaussians: GaussianModel, motion_net, opt, on_gpu: bool):
+    groups = motion_net.get_params(5e-3, 5e-4) if motion_net is not None else None
+    motion_opt = None
+    if groups is not None:
+        if on_gpu:
+            from .optim import MultiTensorAdam
+            motion_opt = MultiTensorAdam(groups, lr=5e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01,
+                                         decoupled=True)
+        else:
+            motion_opt = torch.optim.AdamW(groups, lr=5e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    gaussians.training_setup(opt, fused=on_gpu)
+    return motion_opt
+
+
+def _push_lrs(*optimizers):
+    for o in optimizers:
+        if o is not None and hasattr(o, "set_lrs"):
+            o.set_lrs()
+
+
+class MouthTrainer:
+    """One iteration of train_mouth.py: the mouth Gaussians + MouthMotionNetwork are optimised, the (trained) face
+    Gaussians + face field only supply the jaw-movement feature."""
+
+    def __init__(self, gaussians: GaussianModel, motion_net, gaussians_face: GaussianModel, motion_net_face,
+                 background, opt=OptimizationParams, cameras_extent: float = 0.2, densify: bool = True, seed: int = 0,
+                 warm_step: int = 3000, bg_iter: Optional[int] = None):
+        self.bg_iter = bg_iter
+        self.g, self.motion_net = gaussians, motion_net
+        self.g_face, self.motion_net_face = gaussians_face, motion_net_face
+        self.bg = background
+        self.opt, self.extent, self.densify, self.warm_step = opt, cameras_extent, densify, warm_step
+        self.device = gaussians.get_xyz.device
+        self.on_gpu = self.device.type == "cuda"
+        self.iteration = 0
+        self.rng = random.Random(seed)                                       # k = randint(10, 50), train_mouth.py:175
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        self.motion_optimizer = _make_optimizers(gaussians, motion_net, opt, self.on_gpu)
+        self._base_lr = [float(g["lr"]) for g in self.motion_optimizer.param_groups]
+        self._frozen = False
+        self.last = {}
+
+    def _set_learning_rates(self, it):
+        f = 0.1 if (it - 1) < self.warm_step else 0.5 ** ((it - 1) / self.opt.iterations)     # LambdaLR, :64
+        for grp, base in zip(self.motion_optimizer.param_groups, self._base_lr):
+            grp["lr"] = base * f
+        self.g.update_learning_rate(it)
+        _push_lrs(self.motion_optimizer, self.g.optimizer)
+
+    def _freeze_late(self):
+        """train_mouth.py:189-196: after bg_iter the motion field and the Gaussians' geometry stop learning."""
+        if self._frozen:
+            return
+        for p in self.motion_net.parameters():
+            p.requires_grad_(False)
+        for k in GEOMETRY:
+            self.g._p[k].requires_grad_(False)
+        self._frozen = True
+
+    def forward(self, frame: Frame, phase: MouthPhase, k: int):
+        from .renderer import render_motion_mouth_con
+        bg = torch.zeros_like(self.bg) if phase.late else self.bg
+        pkg = render_motion_mouth_con(frame, self.g, self.motion_net, self.g_face, self.motion_net_face, None, bg,
+                                      personalized=False, align=phase.align, k=k)
+        td = frame.talking_dict
+        dev = self.device
+        mouth = td["mouth_mask"].to(dev)
+        lips = _lips_mask(mouth, td["lips_rect"])
+        p_xyz = pkg["p_motion"]["p_xyz"] if (phase.warm and pkg["p_motion"] is not None) else None
+        loss, Ll1 = mouth_loss(pkg["render"], pkg["alpha"], frame.original_image.to(dev), mouth, lips, bg, p_xyz,
+                               warm=phase.warm, lambda_dssim=self.opt.lambda_dssim)
+        return pkg, loss, Ll1
+
+    @torch.no_grad()
+    def _density_control(self, it, pkg, frame: Frame):
+        """train_mouth.py:260-285."""
+        o = self.opt
+        if not (self.densify and it < o.densify_until_iter):
+            return
+        vis = pkg["visibility_filter"]
+        radii = pkg["radii"].to(self.g.max_radii2D.dtype)
+        self.g.max_radii2D.copy_(torch.max(self.g.max_radii2D, torch.where(vis, radii, torch.zeros_like(radii))))
+        self.g.add_densification_stats(pkg["viewspace_points"].grad, vis)
+        if it > o.densify_from_iter and it % o.densification_interval == 0:
+            size_threshold = 20 if it > o.opacity_reset_interval else None
+            self.g.densify_and_prune(o.densify_grad_threshold, 0.05 + 0.25 * it / o.densify_until_iter, self.extent,
+                                     size_threshold, generator=self.gen)
+            if it > 2000:
+                # Gaussians that took the background's green are pushed towards removal (:276-279)
+                rgb = sh_to_rgb(self.g.active_sh_degree, self.g.get_features, self.g.get_xyz,
+                                frame.camera_center.to(self.device))
+                green = (rgb[:, 0] < 100 / 255) & (rgb[:, 1] > 180 / 255) & (rgb[:, 2] < 100 / 255)
+                self.g.xyz_gradient_accum[green] /= 2
+                self.g._opacity.data[green] = self.g.inverse_opacity_activation(
+                    torch.ones_like(self.g._opacity.data[green]) * 0.1)
+                self.g._scaling.data[green] /= 10
+        if it % o.opacity_reset_interval == 0:
+            self.g.reset_opacity()
+
+    def step(self, frame: Frame):
+        self.iteration += 1
+        it = self.iteration
+        self._set_learning_rates(it)
+        if it % 1000 == 0:
+            self.g.active_sh_degree = min(self.g.active_sh_degree + 1, self.g.max_sh_degree)      # oneupSHdegree, :111
+        phase = mouth_phase(it, self.opt, self.warm_step, self.bg_iter)
+        if phase.late:
+            self._freeze_late()
+        k = self.rng.randint(10, 50)
+        pkg, loss, Ll1 = self.forward(frame, phase, k)
+        loss.backward()
+        self._density_control(it, pkg, frame)
+        if it < self.opt.iterations:
+            self.motion_optimizer.step()
+            self.g.optimizer.step()
+            self.motion_optimizer.zero_grad(set_to_none=True)
+            self.g.optimizer.zero_grad(set_to_none=True)
+        self.last = dict(loss=loss.detach(), l1=Ll1.detach(), num_points=self.g.num_points, phase=phase, k=k)
+        return self.last
+
+
+class FuseTrainer:
+    """One iteration of train_fuse_con.py: face and mouth are rendered, composited over the per-camera background
+    and compared with the whole frame; both motion fields and most of the geometry are frozen from the first
+    iteration (bg_iter = 0), so the step tunes colours (both models) and the face's opacity."""
+
+    FROZEN_FACE = ("xyz", "scaling", "rotation")
+    FROZEN_MOUTH = ("xyz", "opacity", "scaling", "rotation")
+
+    def __init__(self, gaussians: GaussianModel, motion_net, gaussians_mouth: GaussianModel, motion_net_mouth,
+                 background, opt=OptimizationParams, seed: int = 0):
+        self.g, self.motion_net = gaussians, motion_net
+        self.g_mouth, self.motion_net_mouth = gaussians_mouth, motion_net_mouth
+        self.bg, self.opt = background, opt
+        self.device = gaussians.get_xyz.device
+        self.on_gpu = self.device.type == "cuda"
+        self.iteration = 0
+        gaussians.training_setup(opt, fused=self.on_gpu)
+        gaussians_mouth.training_setup(opt, fused=self.on_gpu)
+        for net in (motion_net, motion_net_mouth):
+            for p in net.parameters():
+                p.requires_grad_(False)
+        for k in self.FROZEN_FACE:
+            gaussians._p[k].requires_grad_(False)
+        for k in self.FROZEN_MOUTH:
+            gaussians_mouth._p[k].requires_grad_(False)
+        self.last = {}
+
+    def forward(self, frame: Frame):
+        from .renderer import render_fuse
+        dev = self.device
+        scene_bg = frame.talking_dict.get("background")
+        out = render_fuse(frame, self.g, self.motion_net, self.g_mouth, self.motion_net_mouth, None, self.bg,
+                          scene_background=None if scene_bg is None else scene_bg.to(dev))
+        loss, Ll1 = fuse_loss(out["image"], frame.original_image.to(dev), self.opt.lambda_dssim)
+        return out, loss, Ll1
+
+    def step(self, frame: Frame):
+        self.iteration += 1
+        it = self.iteration
+        self.g.update_learning_rate(it)           # train_fuse_con.py:85 (the mouth model keeps its initial rates)
+        _push_lrs(self.g.optimizer)
+        out, loss, Ll1 = self.forward(frame)
+        loss.backward()
+        if it < self.opt.iterations:
+            self.g.optimizer.step()
+            self.g_mouth.optimizer.step()
+            self.g.optimizer.zero_grad(set_to_none=True)
+            self.g_mouth.optimizer.zero_grad(set_to_none=True)
+        self.last = dict(loss=loss.detach(), l1=Ll1.detach(), image=out["image"].detach())
+        return self.last

@@ -161,3 +161,91 @@ def test_capture_restore_roundtrip():
         assert torch.equal(gm2._p[k], gm._p[k])
     s1, s2 = gm.optimizer.state_dict()["state"], gm2.optimizer.state_dict()["state"]
     assert len(s1) == len(s2) and all(torch.equal(s1[i]["exp_avg"], s2[i]["exp_avg"]) for i in s1)
+
+
+def test_face_phase_schedule_matches_reference_table():
+    """train_face.py:39-46, 340-350, 458-478 with iterations = 10000 (warm_step 3000, lpips_start 7500)."""
+    from instag_amd.train import C3_PHASE, FacePhase, face_phase
+    assert face_phase(500) == FacePhase(align=False, warm=False)
+    assert face_phase(1000).align is False and face_phase(1001).align is True
+    assert face_phase(3000) == FacePhase(align=True, warm=False)
+    assert face_phase(3003) == C3_PHASE                                # 3003 % 7 == 0: a "hair" iteration
+    assert face_phase(3004).hair_mask_iter and face_phase(6499).hair_mask_iter and not face_phase(6500).hair_mask_iter
+    assert not face_phase(5000).priors and face_phase(5001).priors and face_phase(5001).prior_depth
+    assert face_phase(6050).priors and not face_phase(6050).prior_depth          # 6050 % 3000 = 50 <= 100
+    assert face_phase(6101).prior_depth
+
+
+def test_normalize_and_sh_basis_match_reference_goldens():
+    import numpy as np
+    from instag_amd.gaussian_model import sh_basis, sh_to_rgb
+    from instag_amd.losses import normalize
+    here = os.path.dirname(os.path.abspath(__file__))
+    g3 = np.load(f"{here}/golden/g3_losses.npz")
+    got = normalize(torch.tensor(g3["a"][0]))
+    assert float((got - torch.tensor(g3["normalize"])).abs().max()) <= 1e-5
+    g1 = np.load(f"{here}/golden/g1_eval_sh.npz")
+    coef, dirs = torch.tensor(g1["coef"]), torch.tensor(g1["dirs"])
+    for deg in range(4):
+        m = (deg + 1) ** 2
+        out = torch.einsum("nm,ncm->nc", sh_basis(deg, dirs), coef[:, :, :m])
+        assert float((out - torch.tensor(g1[f"deg{deg}"])).abs().max()) <= 1e-6, deg
+    # colours as the density control reads them: clamp_min(eval_sh + 0.5, 0) along xyz - camera
+    xyz, cam = dirs * 2.0, torch.zeros(3)
+    rgb = sh_to_rgb(3, coef.transpose(1, 2).contiguous(), xyz, cam)
+    assert float((rgb - torch.clamp_min(torch.tensor(g1["deg3"]) + 0.5, 0)).abs().max()) <= 1e-6
+
+
+def test_stage_losses_match_reference_statements():
+    """geometry_prior_loss / mouth_loss / fuse_loss against the reference's own lines (boolean indexing, in-place
+    painting) on the CPU."""
+    from instag_amd.losses import geometry_prior_loss, l1_loss, normalize, ssim
+    from instag_amd.scene_synth import synthetic_frame
+    from instag_amd.train_stages import _lips_mask, fuse_loss, mouth_loss
+    fd = synthetic_frame(64, 3, priors=True)
+    g = torch.Generator().manual_seed(0)
+    normal = torch.nn.functional.normalize(torch.randn(3, 64, 64, generator=g), dim=0)
+    depth = torch.rand(1, 64, 64, generator=g)
+    face, hair, mouth = fd["face_mask"], fd["hair_mask"], fd["mouth_mask"]
+    head = face + hair
+    # train_face.py:466, 478-504
+    want = 0.01 * (1 - fd["normal"] * normal).sum(0)[head ^ mouth].mean()
+    want_d = want + 1e-2 * (normalize(depth[0])[face ^ mouth] - normalize(fd["depth"])[face ^ mouth]).abs().mean()
+    got = geometry_prior_loss(normal, depth, fd["normal"], None, face, hair, mouth, use_depth=False)
+    got_d = geometry_prior_loss(normal, depth, fd["normal"], fd["depth"], face, hair, mouth, use_depth=True)
+    assert abs(float(got - want)) <= 1e-6 and abs(float(got_d - want_d)) <= 1e-6
+    # train_mouth.py:168-170, 186-221
+    bg = torch.tensor([0.0, 1.0, 0.0])
+    image, alpha = torch.rand(3, 64, 64, generator=g), torch.rand(1, 64, 64, generator=g)
+    gt, p_xyz = fd["gt_image"], torch.randn(100, 3, generator=g)
+    xmin, xmax, ymin, ymax = fd["lips_rect"].tolist()
+    lips = torch.zeros_like(mouth)
+    lips[xmin:xmax, ymin:ymax] = True
+    assert torch.equal(lips, _lips_mask(mouth, fd["lips_rect"]))
+    gt_green = gt * mouth + bg[:, None, None] * ~mouth
+    img = image.clone()
+    img[:, (lips ^ mouth)] = bg[:, None]
+    l1 = l1_loss(img, gt_green)
+    want = l1 + 0.2 * (1.0 - ssim(img, gt_green))
+    got, got_l1 = mouth_loss(image, alpha, gt, mouth, lips, bg, p_xyz, warm=False)
+    assert abs(float(got - want)) <= 1e-6 and abs(float(got_l1 - l1)) <= 1e-7
+    want = want + 1e-5 * p_xyz.abs().mean() + 1e-3 * (((1 - alpha) * lips).mean() + (alpha * ~lips).mean())
+    got, _ = mouth_loss(image, alpha, gt, mouth, lips, bg, p_xyz, warm=True)
+    assert abs(float(got - want)) <= 1e-6
+    # train_fuse_con.py:176-181
+    got, _ = fuse_loss(image, gt)
+    assert abs(float(got - (l1_loss(image, gt) + 0.2 * (1.0 - ssim(image, gt))))) <= 1e-6
+
+
+def test_frame_packs_optional_tensors():
+    from instag_amd.scene_synth import synthetic_frame, toy_cameras
+    from instag_amd.train import make_frame
+    cam = toy_cameras(32)[0]
+    plain = make_frame(cam, synthetic_frame(32, 0)).packed()
+    rich = make_frame(cam, synthetic_frame(32, 1, priors=True, background=True)).packed()
+    assert "normal" not in plain.talking_dict and rich.talking_dict["normal"].shape == (3, 32, 32)
+    other = make_frame(cam, synthetic_frame(32, 2, priors=True, background=True)).packed()
+    rich.copy_from(other)
+    for k in ("normal", "depth", "background", "auds", "face_mask"):
+        assert torch.equal(rich.talking_dict[k], other.talking_dict[k]), k
+    assert torch.equal(rich.original_image, other.original_image)

@@ -1,0 +1,252 @@
+"""GPU tests of the train-step callers around the hot path: the face branch's iteration-dependent phases and
+density control (train_face.py:340-350, 426-575, 667-788), the mouth branch (train_mouth.py:106-293) and the fuse
+stage (train_fuse_con.py:75-245).  Each fused / restructured loss block is compared with the plain-torch statement of
+the reference's lines on the same rendered outputs; gradients through the same HIP rasterizer."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class SmallOpt:
+    """OptimizationParams with every schedule boundary pulled into the first dozen iterations."""
+    iterations = 14
+    position_lr_init = 0.00016
+    position_lr_final = 0.0000016
+    position_lr_delay_mult = 0.01
+    position_lr_max_steps = 45000
+    feature_lr = 0.0025
+    opacity_lr = 0.05
+    scaling_lr = 0.003
+    rotation_lr = 0.001
+    percent_dense = 0.005
+    lambda_dssim = 0.2
+    densification_interval = 3
+    opacity_reset_interval = 6
+    densify_from_iter = 2
+    densify_until_iter = 11
+    densify_grad_threshold = 0.00002
+
+
+def _frames(size, n, dev, **kw):
+    from instag_amd.scene_synth import synthetic_frame, toy_cameras
+    from instag_amd.train import make_frame
+    cams = toy_cameras(size)
+    return [make_frame(cams[i].to(dev), synthetic_frame(size, i, dev, **kw)) for i in range(n)]
+
+
+def _grads(tr):
+    out = {k: p.grad.detach().clone() for k, p in tr.g._p.items() if p.grad is not None}
+    for name, net in (("umf", tr.motion_net), ("pmf", tr.g.neural_motion_grid)):
+        for n_, p_ in net.named_parameters():
+            if p_.grad is not None:
+                out[f"{name}.{n_}"] = p_.grad.detach().clone()
+    return out
+
+
+@pytest.mark.parametrize("it", [500, 1500, 3004, 3003, 5001, 6050])
+def test_face_phase_step_matches_torch_loss_statement(it):
+    """Every phase of the face branch: the trainer's loss (fused loss block + prior terms) and the gradients it sends
+    to the Gaussians and both motion fields == the reference's lines written with plain torch ops (boolean-mask
+    indexing, in-place painting) behind the same render."""
+    from instag_amd.deferred import deferred_grads
+    from instag_amd.losses import face_loss_torch, normalize
+    from instag_amd.renderer import render_motion
+    from instag_amd.train import build_trainer, face_phase
+    dev = torch.device("cuda")
+    frame = _frames(96, 1, dev, priors=True)[0]
+    phase = face_phase(it)
+    tr = build_trainer(3000, dev, seed=2)
+    pkg, loss, l1 = tr._forward_backward(frame, phase)
+    got = _grads(tr)
+    tr._zero_grad()
+
+    pkg2 = render_motion(frame, tr.g, tr.motion_net, None, tr.bg, return_attn=True, personalized=False,
+                         align=phase.align)
+    td = frame.talking_dict
+    face, hair, mouth = td["face_mask"], td["hair_mask"], td["mouth_mask"]
+    extra = alpha = attn = lips = None
+    if phase.warm:
+        m, pm = pkg2["motion"], pkg2["p_motion"]
+        extra = (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()
+                 + m["d_scale"].abs().mean() + pm["p_xyz"].abs().mean())
+        alpha, attn, lips = pkg2["alpha"], pkg2["attn"], td["lips_rect"]
+    want, want_l1 = face_loss_torch(pkg2["render"], frame.original_image, face, hair, mouth, tr.bg, alpha=alpha,
+                                    attn=attn, lips_rect=lips, extra=extra, hair_mask_iter=phase.hair_mask_iter)
+    if phase.priors:
+        head = face + hair
+        want = want + 0.01 * (1 - td["normal"] * pkg2["normal"]).sum(0)[head ^ mouth].mean()
+        if phase.prior_depth:
+            sel = face ^ mouth
+            want = want + 1e-2 * (normalize(pkg2["depth"][0])[sel] - normalize(td["depth"])[sel]).abs().mean()
+    with deferred_grads(dev):
+        want.backward()
+    ref = _grads(tr)
+    assert abs(float(loss) - float(want)) <= 2e-6 * max(1.0, abs(float(want))), (float(loss), float(want))
+    assert abs(float(l1) - float(want_l1)) <= 2e-6
+    assert set(got) == set(ref), set(got) ^ set(ref)
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        err = float((got[k] - ref[k]).abs().max())
+        assert err <= 2e-4 * scale + 1e-9, (k, err, scale)
+    if phase.priors:
+        # the normal / depth images carried gradient: the full (all-channel) blend backward ran
+        assert float(got["rotation"].abs().max()) > 0
+
+
+def test_reference_schedule_density_control_order():
+    """schedule="reference": statistics -> densify / prune / opacity reset -> optimizers (train_face.py:667-788).  In
+    a density-control iteration the rebuilt Gaussians take no Adam step (they carry no gradient), the motion field
+    does; a captured graph is dropped when the parameter set changes."""
+    from instag_amd import diff_gauss
+    from instag_amd.gaussian_model import GaussianModel
+    from instag_amd.motion_net import MotionNetwork, PersonalizedMotionNetwork
+    from instag_amd.scene_synth import synthetic_gaussians
+    from instag_amd.train import FaceTrainer
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    args = SimpleNamespace(audio_extractor="deepspeech", type="face")
+    g = GaussianModel(1, neural_motion_grid=PersonalizedMotionNetwork(args=args).to(dev))
+    g.load_raw(synthetic_gaussians(3000, sh_degree=1, seed=3), dev)
+    tr = FaceTrainer(g, MotionNetwork(args=args).to(dev), torch.tensor([0.0, 1.0, 0.0], device=dev), opt=SmallOpt,
+                     densify=True, seed=0, schedule="reference")
+    frames = _frames(96, 3, dev, priors=True)
+    try:
+        counts = []
+        for i in range(1, 13):
+            due = tr._densify_due(i)
+            if i == 5:
+                tr.enable_graph(frames[0], warmup_steps=1)      # iterations 5..7 are spent inside enable_graph
+                assert tr._graph is not None and tr.iteration == 7
+                continue
+            if i in (6, 7):
+                continue
+            w_before = next(tr.motion_net.sigma_net.parameters()).detach().clone()
+            out = tr.step(frames[i % 3])
+            assert tr.iteration == i
+            assert torch.isfinite(out["loss"]), i
+            if i == 8:
+                assert tr._graph is not None and not tr._graph.check_overflow()      # replayed
+            counts.append(tr.g.num_points)
+            assert not torch.equal(w_before, next(tr.motion_net.sigma_net.parameters()).detach()), i
+            if due:
+                assert tr._graph is None, "the graph must be dropped when the parameter set is rebuilt"
+                st = tr.g.optimizer.state[tr.g._p["xyz"]]
+                assert st["exp_avg"].shape == tr.g._p["xyz"].shape
+            assert tr.g.xyz_gradient_accum.shape[0] == tr.g.num_points == tr.g.max_radii2D.shape[0]
+        assert len(set(counts)) > 1, counts          # densify / prune changed N at least once
+        # iteration 9 is a density-control iteration (9 % 3 == 0): run eagerly, the graph dropped
+        assert tr._graph is None
+    finally:
+        diff_gauss.set_capacity_plan(None)
+
+
+def _mouth_setup(dev, n_face=1500, n_mouth=900, seed=4):
+    from instag_amd.gaussian_model import GaussianModel
+    from instag_amd.motion_net import MotionNetwork, MouthMotionNetwork, PersonalizedMotionNetwork
+    torch.manual_seed(seed)
+    face_args = SimpleNamespace(audio_extractor="deepspeech", type="face")
+    mouth_args = SimpleNamespace(audio_extractor="deepspeech", type="mouth")
+    pc_face = GaussianModel(1, PersonalizedMotionNetwork(args=face_args).to(dev)).create_random(n_face, dev, seed=1)
+    face_net = MotionNetwork(args=face_args).to(dev)
+    pc = GaussianModel(1, PersonalizedMotionNetwork(args=mouth_args).to(dev)).create_random(n_mouth, dev, seed=2)
+    net = MouthMotionNetwork(args=mouth_args).to(dev)
+    return pc_face, face_net, pc, net
+
+
+def test_mouth_trainer_phases_and_freeze():
+    """MouthTrainer over its three phases (no alignment -> alignment -> warm -> late): loss == the reference's lines on
+    the same render, density control keeps the optimizer state consistent, and after bg_iter the geometry and the
+    motion field stop moving while the colours keep learning."""
+    from instag_amd.losses import l1_loss, ssim
+    from instag_amd.train_stages import MouthTrainer, mouth_phase
+    dev = torch.device("cuda")
+    pc_face, face_net, pc, net = _mouth_setup(dev)
+    bg = torch.tensor([0.0, 1.0, 0.0], device=dev)
+    tr = MouthTrainer(pc, net, pc_face, face_net, bg, opt=SmallOpt, densify=True, seed=0, warm_step=3, bg_iter=10)
+    frames = _frames(96, 3, dev)
+    assert mouth_phase(2, SmallOpt, 3).warm is False and mouth_phase(4, SmallOpt, 3).warm
+    assert mouth_phase(10, SmallOpt, 3, 10).late is False and mouth_phase(11, SmallOpt, 3, 10).late
+    assert mouth_phase(9001).late and not mouth_phase(9000).late             # the reference's bg_iter = 9000
+
+    # loss statement (warm phase) on the trainer's own render
+    frame = frames[0]
+    pkg, loss, l1 = tr.forward(frame, mouth_phase(4, SmallOpt, 3), k=12)
+    td = frame.talking_dict
+    mouth = td["mouth_mask"]
+    xmin, xmax, ymin, ymax = td["lips_rect"].tolist()
+    lips = torch.zeros_like(mouth)
+    lips[xmin:xmax, ymin:ymax] = True
+    gt = frame.original_image
+    gt_green = gt * mouth + bg[:, None, None] * ~mouth
+    img = pkg["render"].detach().clone()
+    img[:, (lips ^ mouth)] = bg[:, None]
+    alpha = pkg["alpha"].detach()
+    want_l1 = l1_loss(img, gt_green)
+    want = want_l1 + 0.2 * (1.0 - ssim(img, gt_green)) + 1e-5 * pkg["p_motion"]["p_xyz"].detach().abs().mean() \
+        + 1e-3 * (((1 - alpha) * lips).mean() + (alpha * ~lips).mean())
+    assert abs(float(loss) - float(want)) <= 2e-6 * max(1.0, abs(float(want))), (float(loss), float(want))
+    assert abs(float(l1) - float(want_l1)) <= 2e-6
+    loss.backward()
+    assert pc._xyz.grad is not None and all(p.grad is None for p in face_net.parameters())
+    tr.motion_optimizer.zero_grad(set_to_none=True)
+    tr.g.optimizer.zero_grad(set_to_none=True)
+
+    ks = []
+    for i in range(1, 11):                       # iterations 1..10: every phase before bg_iter, density control on
+        out = tr.step(frames[i % 3])
+        assert torch.isfinite(out["loss"]) and not out["phase"].late, i
+        ks.append(out["k"])
+        assert tr.g.xyz_gradient_accum.shape[0] == tr.g.num_points
+        assert tr.g.optimizer.state[tr.g._p["xyz"]]["exp_avg"].shape == tr.g._p["xyz"].shape
+    assert all(10 <= k <= 50 for k in ks) and len(set(ks)) > 1
+    xyz0, sc0 = tr.g._p["xyz"].detach().clone(), tr.g._p["scaling"].detach().clone()
+    fdc0 = tr.g._p["f_dc"].detach().clone()
+    w0 = next(net.sigma_net.parameters()).detach().clone()
+    for i in range(11, 14):                      # bg_iter = 10: black background, geometry + motion field frozen
+        out = tr.step(frames[i % 3])
+        assert out["phase"].late and out["phase"].warm and torch.isfinite(out["loss"])
+    assert torch.equal(xyz0, tr.g._p["xyz"].detach()) and torch.equal(sc0, tr.g._p["scaling"].detach())
+    assert torch.equal(w0, next(net.sigma_net.parameters()).detach())
+    assert not torch.equal(fdc0, tr.g._p["f_dc"].detach())
+
+
+def test_fuse_trainer_step():
+    """FuseTrainer: composition == train_fuse_con.py:106-121 on the two renders, frozen parameters stay put, the
+    trainable ones (face colours + opacity, mouth colours) move, and the loss goes down on a repeated frame."""
+    from instag_amd.losses import l1_loss, ssim
+    from instag_amd.train_stages import FuseTrainer
+    dev = torch.device("cuda")
+    pc_face, face_net, pc_mouth, mouth_net = _mouth_setup(dev, n_face=3000, n_mouth=800, seed=6)
+    bg = torch.tensor([0.0, 1.0, 0.0], device=dev)
+    tr = FuseTrainer(pc_face, face_net, pc_mouth, mouth_net, bg)
+    frame = _frames(96, 1, dev, background=True)[0]
+    out, loss, l1 = tr.forward(frame)
+    fa, ma = out["face"]["alpha"], out["mouth"]["alpha"]
+    scene_bg = frame.talking_dict["background"]
+    mouth_image = out["mouth"]["render"] - bg[:, None, None] * (1.0 - ma) + scene_bg * (1.0 - ma)
+    image = out["face"]["render"] - bg[:, None, None] * (1.0 - fa) + mouth_image * (1.0 - fa)
+    assert float((out["image"] - image).abs().max()) <= 1e-6
+    want = l1_loss(image, frame.original_image) + 0.2 * (1.0 - ssim(image, frame.original_image))
+    assert abs(float(loss) - float(want)) <= 2e-6
+    loss.backward()
+    assert pc_face._p["xyz"].grad is None and pc_mouth._p["opacity"].grad is None
+    assert pc_face._p["opacity"].grad is not None and pc_mouth._p["f_dc"].grad is not None
+    assert all(p.grad is None for p in face_net.parameters()) and all(p.grad is None for p in mouth_net.parameters())
+    tr.g.optimizer.zero_grad(set_to_none=True)
+    tr.g_mouth.optimizer.zero_grad(set_to_none=True)
+
+    frozen = {("f", k): pc_face._p[k].detach().clone() for k in FuseTrainer.FROZEN_FACE}
+    frozen.update({("m", k): pc_mouth._p[k].detach().clone() for k in FuseTrainer.FROZEN_MOUTH})
+    op0, fdc0, mdc0 = (pc_face._p["opacity"].detach().clone(), pc_face._p["f_dc"].detach().clone(),
+                       pc_mouth._p["f_dc"].detach().clone())
+    losses = [float(tr.step(frame)["loss"]) for _ in range(12)]
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0], losses
+    for (which, k), v in frozen.items():
+        cur = (pc_face if which == "f" else pc_mouth)._p[k].detach()
+        assert torch.equal(v, cur), (which, k)
+    assert not torch.equal(op0, pc_face._p["opacity"].detach())
+    assert not torch.equal(fdc0, pc_face._p["f_dc"].detach()) and not torch.equal(mdc0, pc_mouth._p["f_dc"].detach())
