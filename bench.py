@@ -27,6 +27,7 @@ KERNEL_IDS = {"preprocess": 0, "duplicate": 1, "sort": 2, "ranges": 3, "blend_fw
               "preprocess_bwd": 6, "grid_fwd": 7, "grid_bwd": 8, "mlp_fwd": 11, "mlp_bwd": 12, "mlp_wgrad": 13}
 NON_RASTER = ("grid_fwd", "grid_bwd", "mlp_fwd", "mlp_bwd", "mlp_wgrad")
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA (32x32x2 / 16x16x4), 64 FLOP/clk/SIMD
 
 
 def algorithmic_bytes(kernel, N, M, R, P, grid_points=0):
@@ -39,8 +40,8 @@ def algorithmic_bytes(kernel, N, M, R, P, grid_points=0):
         "blend_fwd": 60 * R + 44 * P,
         "blend_bwd": 124 * R + 44 * P,
         "preprocess_bwd": 64 * R + N * (128 + 24 * M),
-        "grid_fwd": grid_points * 152,
-        "grid_bwd": grid_points * 152,
+        "grid_fwd": grid_points * 156,      # tri-plane launch: xyz 12 B + 3 planes x 12 levels x 4 B out
+        "grid_bwd": grid_points * 168,      # + 12 B gradient to xyz
     }.get(kernel, 0)
 
 
@@ -167,9 +168,11 @@ def main():
             use_graph = False
     run(args.warmup)
     log("warm-up done")
+    from instag_amd import mlp as mlp_ops
     if not use_graph:
         L.instag_prof_enable(-1)      # eager mode: HIP events bracket every kernel of the timed region itself
         L.instag_prof_reset()
+        mlp_ops.STATS.update(fwd_flops=0, bwd_flops=0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,6 +202,7 @@ def main():
         diff_gauss.set_capacity_plan(None)
         L.instag_prof_enable(-1)
         L.instag_prof_reset()
+        mlp_ops.STATS.update(fwd_flops=0, bwd_flops=0)
         run(args.steps)
         torch.cuda.synchronize()
         log("instrumented eager pass done")
@@ -228,6 +232,22 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, N, size),
                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(kern[dom]["avg_us"], 2),
                         "launches": kern[dom]["launches"], "num_rendered": R}
+        # the other two figures SURVEY.md 8(d) asks for: hash-grid GB/s (HBM) and the MLP kernels' MFMA rate
+        secondary = {}
+        for k in ("grid_fwd", "grid_bwd"):
+            if k in kern:
+                ab = algorithmic_bytes(k, N, M, R, P, grid_points=N)
+                gbs = ab / (kern[k]["avg_us"] * 1e-6) / 1e9
+                secondary[k] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": ab,
+                                "avg_launch_us": round(kern[k]["avg_us"], 2)}
+        for k, key in (("mlp_fwd", "fwd_flops"), ("mlp_bwd", "bwd_flops")):
+            if k in kern and kern[k]["total_ms"] > 0:
+                tf = mlp_ops.STATS[key] / (kern[k]["total_ms"] * 1e-3) / 1e12
+                secondary[k] = {"bound": "mfma", "dtype": "f32", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+                                "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                                "flops_per_step": mlp_ops.STATS[key] // max(1, args.steps),
+                                "launches_per_step": kern[k]["launches"] // max(1, args.steps)}
         value = world * args.steps / elapsed
         out = {
             "metric": "train-step frames/sec @512x512, 100k Gaussians", "value": round(value, 3),
@@ -241,6 +261,7 @@ def main():
                        "frames_per_step_per_gpu": 1, "parallelism": f"dp{world}",
                        "execution": "hipGraph replay" if use_graph else "eager"},
             "roofline": roofline,
+            "secondary_rooflines": secondary,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "raster_fwd_bwd_ms_per_frame": round(sum(v["total_ms"] for k, v in kern.items()
                                                      if k not in NON_RASTER) / args.steps, 4),

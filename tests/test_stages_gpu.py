@@ -173,7 +173,7 @@ def test_mouth_trainer_phases_and_freeze():
 
     # loss statement (warm phase) on the trainer's own render
     frame = frames[0]
-    pkg, loss, l1 = tr.forward(frame, mouth_phase(4, SmallOpt, 3), k=12)
+    pkg, loss, l1 = tr.forward(frame, mouth_phase(4, SmallOpt, 3, 10), k=12)
     td = frame.talking_dict
     mouth = td["mouth_mask"]
     xmin, xmax, ymin, ymax = td["lips_rect"].tolist()
