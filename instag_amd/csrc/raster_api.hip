@@ -2,6 +2,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <mutex>
 #include <vector>
@@ -43,6 +44,59 @@ ProfScope::~ProfScope() {
   p.pending[kernel_].push_back({start_, stop});
 }
 
+// ---- instance sort by tile id -----------------------------------------------------------------------
+// The instances arrive in depth order, so the (tile, depth) sort is a stable sort on the ceil(log2 tiles) bits of the
+// tile id.  rocPRIM's onesweep radix sort with a radix as wide as that key does it in ONE scatter pass (1024 tiles =
+// 10 bits: one histogram + one pass instead of 8 + 2 bits in two passes, each with its look-back clears); merge sort
+// is never chosen (it would compare whole keys).
+namespace {
+template <unsigned Bits>
+using TileSortConfig = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<256, 12>, Bits,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    0>;
+
+template <unsigned Bits>
+hipError_t tile_sort_bits(void* temp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
+                          uint32_t* vals_out, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s) {
+  if (vals_in == nullptr && vals_out == nullptr && temp != nullptr)
+    return rocprim::radix_sort_keys<TileSortConfig<Bits>>(temp, bytes, keys_in, keys_out, n, begin_bit, end_bit, s);
+  if (temp == nullptr) {
+    // size query: the larger of the key-only and the pair form
+    size_t a = 0, b = 0;
+    hipError_t e = rocprim::radix_sort_keys<TileSortConfig<Bits>>(nullptr, a, keys_in, keys_out, n, begin_bit, end_bit, s);
+    if (e != hipSuccess) return e;
+    e = rocprim::radix_sort_pairs<TileSortConfig<Bits>>(nullptr, b, keys_in, keys_out, vals_in, vals_out, n, begin_bit,
+                                                        end_bit, s);
+    bytes = std::max(a, b);
+    return e;
+  }
+  return rocprim::radix_sort_pairs<TileSortConfig<Bits>>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n,
+                                                         begin_bit, end_bit, s);
+}
+
+// bits = width of the tile id; vals_* null = key-only form
+hipError_t tile_sort(void* temp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
+                     uint32_t* vals_out, size_t n, unsigned begin_bit, unsigned bits, hipStream_t s) {
+  const unsigned end_bit = begin_bit + bits;
+  if (bits <= 8) return tile_sort_bits<8>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
+  if (bits <= 10) return tile_sort_bits<10>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
+  if (bits <= 12) return tile_sort_bits<6>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
+  if (bits <= 16) return tile_sort_bits<8>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
+  return tile_sort_bits<10>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
+}
+}  // namespace
+
+// scan input: kept-tile count of the Gaussian at depth rank i, gathered on the fly (no materialised permutation)
+namespace {
+struct CountAtRank {
+  const uint32_t* tiles_touched;
+  __host__ __device__ uint32_t operator()(uint32_t g) const { return tiles_touched[g]; }
+};
+using RankedCounts = rocprim::transform_iterator<const uint32_t*, CountAtRank, uint32_t>;
+}  // namespace
+
 // ---- layouts ----------------------------------------------------------------------------------------
 GeomLayout geom_layout(int32_t N) {
   GeomLayout L;
@@ -60,7 +114,8 @@ GeomLayout geom_layout(int32_t N) {
   L.order = o; o = align_up(o + n * sizeof(uint32_t), 256);
   L.tt_sorted = o; o = align_up(o + n * sizeof(uint32_t), 256);
   size_t tmp = 0;
-  (void)rocprim::inclusive_scan(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, n, rocprim::plus<uint32_t>());
+  (void)rocprim::inclusive_scan(nullptr, tmp, RankedCounts((const uint32_t*)nullptr, CountAtRank{nullptr}),
+                                (uint32_t*)nullptr, n, rocprim::plus<uint32_t>());
   L.scan_temp = o; L.scan_temp_bytes = tmp; o = align_up(o + tmp, 256);
   size_t tmp2 = 0;
   (void)rocprim::radix_sort_pairs(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
@@ -92,11 +147,13 @@ BinningLayout binning_layout(int64_t R) {
   L.vals = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.gid_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.point_list = o; o = align_up(o + r * sizeof(uint32_t), 256);
-  size_t tmp = 0, tmp_keys = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, r, 0, 32);
-  (void)rocprim::radix_sort_keys(nullptr, tmp_keys, (uint32_t*)nullptr, (uint32_t*)nullptr, r, 0, 32);
-  tmp = std::max(tmp, tmp_keys);
+  // the largest request over the radix widths tile_sort() may pick (the tile count is not known here)
+  size_t tmp = 0;
+  for (unsigned bits : {8u, 10u, 12u, 16u, 20u}) {
+    size_t t = 0;
+    (void)tile_sort(nullptr, t, nullptr, nullptr, nullptr, nullptr, r, 0, bits, nullptr);
+    tmp = std::max(tmp, t);
+  }
   L.sort_temp = o; L.sort_temp_bytes = tmp; o = align_up(o + tmp, 256);
   L.total = o;
   return L;
@@ -138,11 +195,10 @@ static int per_gaussian_stage(const instag_raster_args* a, const Camera& c, char
                                                (uint32_t*)(gb + L.depth_key_sorted), (uint32_t*)(gb + L.order_in),
                                                (uint32_t*)(gb + L.order), (size_t)a->N, 0, 32, s));
   }
-  if (int e = launch_gather_counts(a->N, tiles_touched, (const uint32_t*)(gb + L.order), (uint32_t*)(gb + L.tt_sorted), s))
-    return e;
   size_t tmp = L.scan_temp_bytes;
-  INSTAG_CHECK_HIP(rocprim::inclusive_scan(gb + L.scan_temp, tmp, (uint32_t*)(gb + L.tt_sorted), point_offsets,
-                                           (size_t)a->N, rocprim::plus<uint32_t>(), s));
+  INSTAG_CHECK_HIP(rocprim::inclusive_scan(gb + L.scan_temp, tmp,
+                                           RankedCounts((const uint32_t*)(gb + L.order), CountAtRank{tiles_touched}),
+                                           point_offsets, (size_t)a->N, rocprim::plus<uint32_t>(), s));
   return INSTAG_OK;
 }
 
@@ -189,7 +245,7 @@ int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t
 static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
                         size_t binning_bytes, void* image, size_t image_bytes, int64_t R, bool pad,
                         float* out_color, float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
-                        const float* aux_colors, float* out_aux, hipStream_t s) {
+                        const float* aux_colors, float* out_aux, int32_t* status, hipStream_t s) {
   INSTAG_REQUIRE(out_color && out_depth && out_normal && out_alpha, "output images must not be NULL");
   INSTAG_REQUIRE((aux_colors == nullptr) == (out_aux == nullptr), "aux_colors and out_aux go together");
   INSTAG_REQUIRE(R >= 0 && R < (int64_t)1 << 31, "instance count out of range");
@@ -213,10 +269,9 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   if (R > 0 && a->N > 0) {
     // the duplicate kernel also clears the tile ranges and (capacity mode) pads the unused key slots
     if (int e = launch_duplicate(c, (float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.order),
-                                 (const uint32_t*)(gb + GL.tt_sorted),
                                  (const uint32_t*)(gb + GL.point_offsets), (const uint32_t*)(gb + GL.flags),
                                  (const float*)(gb + GL.cull_thr), keys_u,
-                                 vals_u, gid_u, (uint32_t)R, pad, ranges, packed, s)) return e;
+                                 vals_u, gid_u, (uint32_t)R, pad, ranges, packed, status, s)) return e;
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;
     {
@@ -224,11 +279,9 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
       size_t tmp = BL.sort_temp_bytes;
       const int bits = tile_bits > 0 ? tile_bits : 1;
       if (packed)
-        INSTAG_CHECK_HIP(rocprim::radix_sort_keys(bb + BL.sort_temp, tmp, keys_u, keys, (size_t)R, PACK_SHIFT,
-                                                  PACK_SHIFT + bits, s));
+        INSTAG_CHECK_HIP(tile_sort(bb + BL.sort_temp, tmp, keys_u, keys, nullptr, nullptr, (size_t)R, PACK_SHIFT, bits, s));
       else
-        INSTAG_CHECK_HIP(rocprim::radix_sort_pairs(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0,
-                                                   bits, s));
+        INSTAG_CHECK_HIP(tile_sort(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0, bits, s));
     }
     if (int e = launch_ranges(R, keys, vals, gid_u, point_list, ranges, (uint32_t)tiles, packed, s)) return e;
   } else {
@@ -246,7 +299,7 @@ int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t
                                  instag_stream_t stream_) {
   if (int e = validate(a)) return e;
   return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, R, false, out_color,
-                      out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux, (hipStream_t)stream_);
+                      out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux, nullptr, (hipStream_t)stream_);
 }
 
 int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
@@ -262,13 +315,14 @@ int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size
   if (geom_bytes < L.total) { set_error("geom buffer too small"); return INSTAG_E_SPACE; }
   char* gb = (char*)geom;
   const Camera c = make_camera(a);
-  uint32_t* point_offsets = (uint32_t*)(gb + L.point_offsets);
   if (a->N > 0) {
     if (int e = per_gaussian_stage(a, c, gb, L, radii, s)) return e;
+  } else {
+    INSTAG_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), s));
   }
-  if (int e = launch_status(a->N, point_offsets, (uint32_t)capacity, status, s)) return e;
+  // [R needed, overflow] is written by the duplicate kernel
   return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, capacity, true, out_color,
-                      out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux, s);
+                      out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux, status, s);
 }
 
 int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes, const void* binning,

@@ -17,13 +17,12 @@ Camera make_camera(const instag_raster_args* a);
 int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
                       uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, uint32_t* depth_key,
                       uint32_t* order_in, int32_t* radii, hipStream_t s);
-int launch_gather_counts(int N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* tt_sorted, hipStream_t s);
 int launch_export_keys(int64_t R, const uint32_t* tile_keys, const uint32_t* point_list, const float* rec2d,
                        uint64_t* keys64, bool packed, hipStream_t s);
-int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order, const uint32_t* tt_sorted,
+int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order,
                      const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint32_t* keys,
                      uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, bool pad, int32_t* ranges,
-                     bool packed, hipStream_t s);
+                     bool packed, int32_t* status, hipStream_t s);
 int launch_ranges(int64_t R, const uint32_t* keys_sorted, uint32_t* slots_sorted, const uint32_t* gid_unsorted,
                   uint32_t* point_list, int32_t* ranges, uint32_t ntiles, bool packed, hipStream_t s);
 
@@ -31,7 +30,6 @@ int launch_ranges(int64_t R, const uint32_t* keys_sorted, uint32_t* slots_sorted
 // (R < 2^21 instances, < 2^11 - 1 tiles; config C3 qualifies).  Half the bytes per radix pass of a pair sort.
 constexpr int PACK_SHIFT = 21;
 inline bool use_packed_keys(int64_t R, int tiles) { return R < ((int64_t)1 << PACK_SHIFT) && tiles < (1 << 11) - 1; }
-int launch_status(int N, const uint32_t* point_offsets, uint32_t capacity, int32_t* status, hipStream_t s);
 
 // raster_blend.hip
 int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,

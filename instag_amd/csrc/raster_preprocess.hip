@@ -250,11 +250,18 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
 // the slot back to the Gaussian.  The exclusive instance offset is recorded in the blend record.
 __global__ void __launch_bounds__(256)
 duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ order,
-                 const uint32_t* __restrict__ tt_sorted, const uint32_t* __restrict__ point_offsets,
+                 const uint32_t* __restrict__ point_offsets,
                  const uint32_t* __restrict__ flags, const float* __restrict__ cull_thr,
                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ gid_unsorted,
-                 uint32_t capacity, uint32_t pad_to, int32_t* __restrict__ ranges, uint32_t nranges, int packed) {
+                 uint32_t capacity, uint32_t pad_to, int32_t* __restrict__ ranges, uint32_t nranges, int packed,
+                 int32_t* __restrict__ status) {
   const int i = blockIdx.x * 256 + threadIdx.x;      // rank in depth order
+  if (status != nullptr && i == 0) {
+    // capacity mode: publish the instance count and the overflow flag without a host round trip
+    const uint32_t R = point_offsets[N - 1];
+    status[0] = (int32_t)R;
+    status[1] = R > capacity ? 1 : 0;
+  }
   // housekeeping that used to be two memsets: unused instance slots get all-ones keys (they sort last and own no
   // tile range), the tile ranges start out empty
   {
@@ -264,7 +271,7 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
     for (uint32_t k = (uint32_t)i; k < nranges; k += total) ranges[k] = 0;
   }
   if (i >= N) return;
-  const uint32_t tt = tt_sorted[i];
+  const uint32_t tt = point_offsets[i] - (i > 0 ? point_offsets[i - 1] : 0u);   // kept tiles of this Gaussian
   if (tt == 0) return;
   if (point_offsets[i] > capacity) return;   // capacity mode: instances beyond the buffer are dropped (flagged)
   const uint32_t g = order[i];
@@ -289,13 +296,6 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
       ++off;
     }
   }
-}
-
-__global__ void __launch_bounds__(256)
-gather_counts_kernel(int N, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ order,
-                     uint32_t* __restrict__ tt_sorted) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < N) tt_sorted[i] = tiles_touched[order[i]];
 }
 
 // debug / parity: the 64-bit (tile<<32 | depth bits) key of every sorted instance
@@ -337,13 +337,6 @@ ranges_kernel(int64_t R, const uint32_t* __restrict__ keys, uint32_t* __restrict
   if (i == R - 1 && tile < ntiles) ranges[2 * tile + 1] = (int32_t)R;
 }
 
-// capacity mode: publish the instance count and the overflow flag without a host round trip
-__global__ void status_kernel(int N, const uint32_t* __restrict__ point_offsets, uint32_t capacity,
-                              int32_t* __restrict__ status) {
-  const uint32_t R = N > 0 ? point_offsets[N - 1] : 0u;
-  status[0] = (int32_t)R;
-  status[1] = R > capacity ? 1 : 0;
-}
 
 }  // namespace
 
@@ -374,22 +367,15 @@ int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d
   return INSTAG_OK;
 }
 
-int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order, const uint32_t* tt_sorted,
+int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order,
                      const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint32_t* keys,
                      uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, bool pad, int32_t* ranges,
-                     bool packed, hipStream_t s) {
+                     bool packed, int32_t* status, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_DUPLICATE, s);
-  duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, order, tt_sorted, point_offsets, flags,
+  duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, order, point_offsets, flags,
                                                      cull_thr, keys, vals, gid_unsorted, capacity, pad ? capacity : 0u,
-                                                     ranges, (uint32_t)(2 * c.grid_x * c.grid_y), packed ? 1 : 0);
-  INSTAG_CHECK_LAUNCH();
-  return INSTAG_OK;
-}
-
-int launch_gather_counts(int N, const uint32_t* tiles_touched, const uint32_t* order, uint32_t* tt_sorted, hipStream_t s) {
-  if (N == 0) return INSTAG_OK;
-  gather_counts_kernel<<<div_up(N, 256), 256, 0, s>>>(N, tiles_touched, order, tt_sorted);
+                                                     ranges, (uint32_t)(2 * c.grid_x * c.grid_y), packed ? 1 : 0, status);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -409,12 +395,6 @@ int launch_ranges(int64_t R, const uint32_t* keys_sorted, uint32_t* slots_sorted
   ProfScope p(K_RANGES, s);
   ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, keys_sorted, slots_sorted, gid_unsorted,
                                                                   point_list, ranges, ntiles, packed ? 1 : 0);
-  INSTAG_CHECK_LAUNCH();
-  return INSTAG_OK;
-}
-
-int launch_status(int N, const uint32_t* point_offsets, uint32_t capacity, int32_t* status, hipStream_t s) {
-  status_kernel<<<1, 1, 0, s>>>(N, point_offsets, capacity, status);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
