@@ -106,7 +106,6 @@ class MouthTrainer:
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.motion_optimizer = _make_optimizers(gaussians, motion_net, opt, self.on_gpu)
         self._base_lr = [float(g["lr"]) for g in self.motion_optimizer.param_groups]
-        self._frozen = False
         self.last = {}
 
     def _set_learning_rates(self, it):
@@ -118,13 +117,10 @@ class MouthTrainer:
 
     def _freeze_late(self):
         """train_mouth.py:189-196: after bg_iter the motion field and the Gaussians' geometry stop learning."""
-        if self._frozen:
-            return
         for p in self.motion_net.parameters():
             p.requires_grad_(False)
         for k in GEOMETRY:
-            self.g._p[k].requires_grad_(False)
-        self._frozen = True
+            self.g._p[k].requires_grad_(False)      # (every late iteration: density control rebuilds the leaves)
 
     def forward(self, frame: Frame, phase: MouthPhase, k: int):
         from .renderer import render_motion_mouth_con

@@ -3,7 +3,7 @@
     python scripts/timeline.py <dir> <step index (counted by adam_step launches)>"""
 import csv, glob, re, sys
 d = sys.argv[1]; step = int(sys.argv[2])
-f = glob.glob(f'{d}/*/*_kernel_trace.csv')[0]
+f = (glob.glob(f'{d}/*/*_kernel_trace.csv') + glob.glob(f'{d}/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 ends = [i for i, r in enumerate(rows) if 'adam_step_kernel' in r['Kernel_Name']]      # one launch per step

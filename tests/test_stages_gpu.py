@@ -165,7 +165,10 @@ def test_mouth_trainer_phases_and_freeze():
     dev = torch.device("cuda")
     pc_face, face_net, pc, net = _mouth_setup(dev)
     bg = torch.tensor([0.0, 1.0, 0.0], device=dev)
-    tr = MouthTrainer(pc, net, pc_face, face_net, bg, opt=SmallOpt, densify=True, seed=0, warm_step=3, bg_iter=10)
+    # prune threshold 0.05 + 0.25 it / densify_until_iter stays below the initial opacity (0.1), the opacity reset (10)
+    # comes after the last densification (9): otherwise the compressed schedule would prune every Gaussian
+    MouthOpt = type("MouthOpt", (SmallOpt,), {"opacity_reset_interval": 10, "densify_until_iter": 200})
+    tr = MouthTrainer(pc, net, pc_face, face_net, bg, opt=MouthOpt, densify=True, seed=0, warm_step=3, bg_iter=10)
     frames = _frames(96, 3, dev)
     assert mouth_phase(2, SmallOpt, 3).warm is False and mouth_phase(4, SmallOpt, 3).warm
     assert mouth_phase(10, SmallOpt, 3, 10).late is False and mouth_phase(11, SmallOpt, 3, 10).late
@@ -205,6 +208,7 @@ def test_mouth_trainer_phases_and_freeze():
     xyz0, sc0 = tr.g._p["xyz"].detach().clone(), tr.g._p["scaling"].detach().clone()
     fdc0 = tr.g._p["f_dc"].detach().clone()
     w0 = next(net.sigma_net.parameters()).detach().clone()
+    tr.densify = False                           # (the reference's schedule has no density control after bg_iter)
     for i in range(11, 14):                      # bg_iter = 10: black background, geometry + motion field frozen
         out = tr.step(frames[i % 3])
         assert out["phase"].late and out["phase"].warm and torch.isfinite(out["loss"])
