@@ -615,6 +615,66 @@ triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
   }
 }
 
+// All three tables resident in LDS at once (3T floats; the face fields' 3 x 37.9 KB), one work item per (point, plane):
+// one staging phase and one barrier per workgroup instead of three, three times as many threads in flight, and a
+// thread's 12 levels leave as three 16-byte stores into an output row that consecutive threads write contiguously
+// (work item w of a workgroup owns out[(b0*3 + w) * L ...]).
+constexpr int TPF_BLOCK = 1024;
+
+__global__ void __launch_bounds__(TPF_BLOCK)
+triplane_forward_all_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
+  extern __shared__ __align__(16) float s_tab[];          // [3][T]
+  __shared__ TpLevel s_lv[TP_MAX_L];
+  const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;
+  const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
+  const uint32_t T = (uint32_t)a.offsets[a.L];
+  const float inv2b = 1.0f / (2.0f * a.bound);
+  tp_levels(a, s_lv);
+#pragma unroll
+  for (int plane = 0; plane < 3; ++plane) {
+    const float* __restrict__ src = a.tables[plane];
+    for (uint32_t i = threadIdx.x; i < T; i += TPF_BLOCK) s_tab[plane * T + i] = src[i];
+  }
+  __syncthreads();
+  if (b0 >= b1) return;
+  const uint32_t items = 3u * (b1 - b0);
+  const bool vec = (a.L & 3u) == 0;
+  for (uint32_t w = threadIdx.x; w < items; w += TPF_BLOCK) {
+    const uint32_t pt = w / 3u, plane = w - 3u * pt, b = b0 + pt;
+    float p[3];
+    tp_point(a, b, p);
+    float xw[2];
+    plane_coords((int)plane, p, xw);
+    const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
+    const bool oob = x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f;
+    const float* __restrict__ tabp = s_tab + plane * T;
+    float* o = out + ((size_t)b * 3 + plane) * a.L;
+    for (uint32_t l4 = 0; l4 < a.L; l4 += 4) {
+      float v[4];
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t l = min(l4 + q, a.L - 1);
+        const TpLevel lv = s_lv[l];
+        const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
+        const float flx = floorf(px), fly = floorf(py);
+        const float fx = px - flx, fy = py - fly;
+        // (out-of-range points read cell 0: the value is discarded)
+        const float* tab = tabp + lv.offset + (oob ? 0u : (uint32_t)flx + (uint32_t)fly * lv.stride);
+        const float v00 = tab[0], v10 = tab[1], v01 = tab[lv.stride], v11 = tab[lv.stride + 1];
+        const float r = ((1.f - fx) * (1.f - fy)) * v00 + (fx * (1.f - fy)) * v10 + ((1.f - fx) * fy) * v01 + (fx * fy) * v11;
+        v[q] = oob ? 0.f : r;
+      }
+      if (vec) {
+        *reinterpret_cast<float4*>(o + l4) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q)
+          if (l4 + q < a.L) o[l4 + q] = v[q];
+      }
+    }
+  }
+}
+
 // Backward, stage 1: plane by plane, the plane's table (T floats) and the gradient of the workgroup's points
 // (T 64-bit fixed-point accumulators) live in LDS.  LDS FLOAT atomics run at roughly one lane at a time on gfx950
 // (measured here: 14.4 M ds_add_f32 cost 80 us, the same number of ds_add_u64 nothing beside the loads), so the
@@ -773,7 +833,19 @@ int instag_triplane_forward(const float* xyz, const float* table_xy, const float
   TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound, shift, shift_stride, shift_scale};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_GRID_FWD, s);
-  triplane_forward_kernel<<<fwd_blocks(N), GRID_BLOCK, total_params * sizeof(float), s>>>(a, out);
+  const size_t all_bytes = (size_t)3 * total_params * sizeof(float);
+  if (all_bytes <= 150 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(triplane_forward_all_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_set = true;
+    }
+    const unsigned blocks = std::max(1u, std::min(256u, div_up<uint32_t>(3u * N, TPF_BLOCK)));
+    triplane_forward_all_kernel<<<blocks, TPF_BLOCK, all_bytes, s>>>(a, out);
+  } else {
+    triplane_forward_kernel<<<fwd_blocks(N), GRID_BLOCK, total_params * sizeof(float), s>>>(a, out);
+  }
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
