@@ -2,8 +2,9 @@
 
 Counterpart of /root/reference/train_face.py:110-788 restricted to the hot path: render_motion
 (:346-350) -> L1 + 0.2*(1-SSIM) (:450-456) + regularisers (:508-540) -> backward (:625) ->
-densification statistics (:675-686) -> AdamW / Adam steps (:781-788).  LPIPS, the few-shot
-normal/depth priors and logging are out of scope.
+densification statistics / density control (:667-746) -> AdamW / Adam steps (:781-788), in the reference's
+iteration-dependent phases (face_phase: alignment, warm terms, hair iterations, monocular normal / depth
+priors :458-504).  LPIPS and logging are out of scope.
 
 Two execution modes with identical arithmetic:
   * eager  -- every operator is launched from Python (one host round trip per rasterizer pass);
@@ -15,8 +16,9 @@ Two execution modes with identical arithmetic:
 
 Data parallelism over frames (an addition): identical replicas, rank r renders its
 own frame, gradients of [Gaussians | UMF | PMF] are flattened into ONE bucket and all-reduced
-(RCCL over xGMI; gloo in the CPU tests), densification statistics are all-reduced too, so every
-replica applies identical optimizer and densify/prune decisions.
+(RCCL over xGMI; gloo in the CPU tests); densification statistics stay per-rank sums / maxima and are
+exchanged when a densification reads them, so every replica applies identical optimizer and
+densify/prune decisions with one collective per step.
 """
 from __future__ import annotations
 

@@ -1,21 +1,23 @@
 #!/bin/bash
 # Profiles of one round, run on the GPU box from the repo root:  bash scripts/profile_round.sh r01
-# Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ and the summaries that are committed under profiles/.
+# Writes raw rocprofv3 output under gpurun_out/prof_<tag>/ and the summaries under gpurun_out/profiles/ (only
+# gpurun_out/ travels back from the GPU box): copy those into profiles/ and commit them.
 # Counter passes are separate runs (kernel-trace/stats never combined with --pmc; TCC FETCH_SIZE and WRITE_SIZE
 # do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
 set -o pipefail
 TAG=${1:-r01}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p "$OUT" "$ROOT/profiles"
+SUM=$ROOT/gpurun_out/profiles
+mkdir -p "$OUT" "$SUM"
 cd /tmp && export TMPDIR=/tmp
 
 # 1. kernel trace + stats of the default bench command
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run --output-format csv -- python3 "$ROOT/bench.py" \
     > "$OUT/trace.log" 2>&1 || exit 1
-grep '^{"metric"' "$OUT/trace.log" > "$ROOT/profiles/${TAG}_bench_c3_under_rocprof.json"
-cp "$OUT/trace/run_kernel_stats.csv" "$ROOT/profiles/${TAG}_bench_c3_kernel_stats.csv"
-python3 "$ROOT/scripts/category_summary.py" "$OUT/trace" > "$ROOT/profiles/${TAG}_bench_c3_category_summary.txt" || exit 1
+grep '^{"metric"' "$OUT/trace.log" > "$SUM/${TAG}_bench_c3_under_rocprof.json"
+cp "$OUT/trace/run_kernel_stats.csv" "$SUM/${TAG}_bench_c3_kernel_stats.csv"
+python3 "$ROOT/scripts/category_summary.py" "$OUT/trace" > "$SUM/${TAG}_bench_c3_category_summary.txt" || exit 1
 echo "[profile] trace done"
 
 # 2. HBM traffic: two TCC passes
@@ -24,7 +26,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
       --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1 || exit 1
 done
 python3 "$ROOT/scripts/pmc_summary.py" "$OUT/pmc_FETCH_SIZE/run_counter_collection.csv" \
-    "$OUT/pmc_WRITE_SIZE/run_counter_collection.csv" "$ROOT/profiles/${TAG}_pmc_hbm_traffic_c3" || exit 1
+    "$OUT/pmc_WRITE_SIZE/run_counter_collection.csv" "$SUM/${TAG}_pmc_hbm_traffic_c3" || exit 1
 echo "[profile] hbm passes done"
 
 # 3. what the resident waves do: SQ pass (8 slots)
@@ -32,5 +34,5 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_
     SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES -d "$OUT/pmc_sq" -o run --output-format csv -- python3 "$ROOT/bench.py" \
     --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_sq.log" 2>&1 || exit 1
 python3 "$ROOT/scripts/pmc_sq_summary.py" "$OUT/pmc_sq/run_counter_collection.csv" \
-    "$ROOT/profiles/${TAG}_pmc_sq_c3.csv" || exit 1
+    "$SUM/${TAG}_pmc_sq_c3.csv" || exit 1
 echo "[profile] sq pass done"
