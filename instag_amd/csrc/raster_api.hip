@@ -49,38 +49,38 @@ ProfScope::~ProfScope() {
 // tile id: rocPRIM's onesweep radix sort over those bits only.  Merge sort is never chosen (rocPRIM's default picks
 // it below 1 M keys; it compares whole keys and took twice as long at 0.5 M instances).
 namespace {
-template <unsigned Bits>
-using TileSortConfig = rocprim::radix_sort_config<
+// rocPRIM's own tuned gfx950 onesweep parameters for 4-byte keys (device_radix_sort_onesweep.hpp: 1024 x 8 key-only,
+// 1024 x 16 with 4-byte values, 8-bit digits, match ranking) with the merge-sort limit set to zero
+using TileSortKeysConfig = rocprim::radix_sort_config<
     rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<256, 12>, rocprim::kernel_config<256, 12>, Bits,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    0>;
+using TileSortPairsConfig = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 8,
                                         rocprim::block_radix_rank_algorithm::match>,
     0>;
 
-template <unsigned Bits>
-hipError_t tile_sort_bits(void* temp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
-                          uint32_t* vals_out, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t s) {
-  if (vals_in == nullptr && vals_out == nullptr && temp != nullptr)
-    return rocprim::radix_sort_keys<TileSortConfig<Bits>>(temp, bytes, keys_in, keys_out, n, begin_bit, end_bit, s);
+// bits = width of the tile id; vals_* null = key-only form; temp null = size query (the larger of the two forms).
+// 8-bit digits: measured on MI355X (1.5 M keys, 10-bit tile ids) one 10-bit pass costs 56 us + a 17 us histogram
+// against 2 x 17 us + 8 us for two 8-bit passes (the 1024-bin in-block ranking is what grows).
+hipError_t tile_sort(void* temp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
+                     uint32_t* vals_out, size_t n, unsigned begin_bit, unsigned bits, hipStream_t s) {
+  const unsigned end_bit = begin_bit + bits;
   if (temp == nullptr) {
-    // size query: the larger of the key-only and the pair form
     size_t a = 0, b = 0;
-    hipError_t e = rocprim::radix_sort_keys<TileSortConfig<Bits>>(nullptr, a, keys_in, keys_out, n, begin_bit, end_bit, s);
+    hipError_t e = rocprim::radix_sort_keys<TileSortKeysConfig>(nullptr, a, keys_in, keys_out, n, begin_bit, end_bit, s);
     if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs<TileSortConfig<Bits>>(nullptr, b, keys_in, keys_out, vals_in, vals_out, n, begin_bit,
-                                                        end_bit, s);
+    e = rocprim::radix_sort_pairs<TileSortPairsConfig>(nullptr, b, keys_in, keys_out, vals_in, vals_out, n, begin_bit,
+                                                       end_bit, s);
     bytes = std::max(a, b);
     return e;
   }
-  return rocprim::radix_sort_pairs<TileSortConfig<Bits>>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n,
-                                                         begin_bit, end_bit, s);
-}
-
-// bits = width of the tile id; vals_* null = key-only form.  8-bit digits: measured on MI355X (1.5 M keys, 10-bit
-// tile ids) one 10-bit pass costs 56 us + a 17 us histogram against 2 x 17 us + 8 us for two 8-bit passes (the
-// 1024-bin in-block ranking is what grows).
-hipError_t tile_sort(void* temp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
-                     uint32_t* vals_out, size_t n, unsigned begin_bit, unsigned bits, hipStream_t s) {
-  return tile_sort_bits<8>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, begin_bit + bits, s);
+  if (vals_in == nullptr && vals_out == nullptr)
+    return rocprim::radix_sort_keys<TileSortKeysConfig>(temp, bytes, keys_in, keys_out, n, begin_bit, end_bit, s);
+  return rocprim::radix_sort_pairs<TileSortPairsConfig>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit,
+                                                        end_bit, s);
 }
 }  // namespace
 
