@@ -53,6 +53,8 @@ def _require_cuda(**tensors):
 
 # statistics of the most recent forward (bench.py reads the instance count R for the roofline accounting)
 LAST_STATS = {"num_rendered": 0, "num_gaussians": 0}
+# instance count of every rasterizer call since the caller last cleared the list (sizing of a CapacityPlan)
+RENDERED_LOG = []
 
 
 class CapacityPlan:
@@ -155,6 +157,8 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
               "rasterize_gaussians")
         R = int(Rc.value)
         LAST_STATS["num_rendered"], LAST_STATS["num_gaussians"] = R, N
+        if len(RENDERED_LOG) < 4096:
+            RENDERED_LOG.append(R)
         binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
         check(L.instag_raster_forward_stage2(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
                                              ptr(image), image.numel(), R, ptr(color), ptr(depth), ptr(normal),

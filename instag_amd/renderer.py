@@ -220,8 +220,16 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
         motion_preds_face = motion_net_face.cache
     with torch.no_grad():
         dy = motion_preds_face["d_xyz"][..., 1]
-        motion_max = dy.topk(k, 0, True, True).values[-1]
-        motion_min = dy.topk(k, 0, False, True).values[-1]
+        if torch.is_tensor(k):
+            # k on the device (int64 [1], 1 <= k <= 50): a captured step draws a new k per replay without a host
+            # round trip -- the 50 largest / smallest once, the k-th of them by index
+            kmax = min(50, dy.shape[0])
+            kidx = (k.reshape(1) - 1).clamp(0, kmax - 1)
+            motion_max = dy.topk(kmax, 0, True, True).values.gather(0, kidx)[0]
+            motion_min = dy.topk(kmax, 0, False, True).values.gather(0, kidx)[0]
+        else:
+            motion_max = dy.topk(k, 0, True, True).values[-1]
+            motion_min = dy.topk(k, 0, False, True).values[-1]
         move_feat = torch.stack([motion_max, motion_min, motion_max - motion_min]).reshape(1, 3) * 1e2
     motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
     d_xyz = motion_preds["d_xyz"]

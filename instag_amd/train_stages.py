@@ -22,9 +22,16 @@ GEOMETRY = ("xyz", "opacity", "scaling", "rotation")
 
 
 def _lips_mask(like: torch.Tensor, lips_rect) -> torch.Tensor:
-    """lips_mask[xmin:xmax, ymin:ymax] = True (train_mouth.py:168-170: the rect indexes rows first)."""
-    r0, r1, c0, c1 = [int(v) for v in (lips_rect.tolist() if torch.is_tensor(lips_rect) else lips_rect)]
-    m = torch.zeros_like(like, dtype=torch.bool)
+    """lips_mask[xmin:xmax, ymin:ymax] = True (train_mouth.py:168-170: the rect indexes rows first).  A tensor
+    rect stays on its device (comparisons against row / column indices: no host round trip, capturable)."""
+    H, W = like.shape[-2:]
+    if torch.is_tensor(lips_rect):
+        lr = lips_rect.to(device=like.device, dtype=torch.int64)
+        rows = torch.arange(H, device=like.device)[:, None]
+        cols = torch.arange(W, device=like.device)[None, :]
+        return (rows >= lr[0]) & (rows < lr[1]) & (cols >= lr[2]) & (cols < lr[3])
+    r0, r1, c0, c1 = [int(v) for v in lips_rect]
+    m = torch.zeros(H, W, dtype=torch.bool, device=like.device)
     m[r0:r1, c0:c1] = True
     return m
 
@@ -87,6 +94,62 @@ def _push_lrs(*optimizers):
             o.set_lrs()
 
 
+class GraphedStage:
+    """A stage trainer's whole step (forward, loss, backward, statistics, optimizers) captured once into a hipGraph
+    and replayed: ``body(frame)`` must be free of host round trips; the rasterizer runs in its capacity mode with one
+    slot per rasterizer call of the step, sized from eager warm-up steps (instag_amd/diff_gauss.py:CapacityPlan)."""
+
+    def __init__(self, body, example: Frame, device, headroom: float = 1.5, warmup_steps: int = 2, pre=None):
+        """``pre()`` = the host-side part of a step (iteration counter, learning-rate table): run before every
+        warm-up step, never captured."""
+        from . import diff_gauss
+        from .train import _no_gc
+        assert device.type == "cuda", "graph mode needs the GPU"
+        self.static = example.clone_static()
+        diff_gauss.set_capacity_plan(None)
+        counts = None
+        for _ in range(max(1, warmup_steps)):
+            diff_gauss.RENDERED_LOG.clear()
+            if pre is not None:
+                pre()
+            body(self.static)
+            got = list(diff_gauss.RENDERED_LOG)
+            counts = got if counts is None else [max(a, b) for a, b in zip(counts, got)]
+        self.capacities = [int(r * headroom) + 4096 for r in counts]
+        self.plan = diff_gauss.CapacityPlan(self.capacities, device)
+        diff_gauss.set_capacity_plan(self.plan)
+        side = torch.cuda.Stream(device=device)        # allocator / library warm-up in capacity mode
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.plan.begin_step()
+                if pre is not None:
+                    pre()
+                body(self.static)
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        self.plan.begin_step()
+        with _no_gc(), torch.cuda.graph(self.graph):
+            self.out = body(self.static)
+
+    def replay(self, frame: Frame):
+        self.static.copy_from(frame)
+        self.graph.replay()
+        return self.out
+
+    def check_overflow(self):
+        return self.plan.overflowed()
+
+
+def _drop_graph(trainer):
+    if getattr(trainer, "_graph", None) is not None:
+        from . import diff_gauss
+        diff_gauss.set_capacity_plan(None)
+    trainer._graph = None
+    trainer._graph_key = None
+
+
 class MouthTrainer:
     """One iteration of train_mouth.py: the mouth Gaussians + MouthMotionNetwork are optimised, the (trained) face
     Gaussians + face field only supply the jaw-movement feature."""
@@ -106,6 +169,9 @@ class MouthTrainer:
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.motion_optimizer = _make_optimizers(gaussians, motion_net, opt, self.on_gpu)
         self._base_lr = [float(g["lr"]) for g in self.motion_optimizer.param_groups]
+        self._graph = None
+        self._graph_key = None
+        self._k_dev = torch.full((1,), 10, dtype=torch.int64, device=self.device) if self.on_gpu else None
         self.last = {}
 
     def _set_learning_rates(self, it):
@@ -136,16 +202,28 @@ class MouthTrainer:
                                warm=phase.warm, lambda_dssim=self.opt.lambda_dssim)
         return pkg, loss, Ll1
 
-    @torch.no_grad()
-    def _density_control(self, it, pkg, frame: Frame):
-        """train_mouth.py:260-285."""
+    def _stats_on(self, it):
+        return self.densify and it < self.opt.densify_until_iter
+
+    def _density_due(self, it):
         o = self.opt
-        if not (self.densify and it < o.densify_until_iter):
-            return
+        return self._stats_on(it) and ((it > o.densify_from_iter and it % o.densification_interval == 0)
+                                       or it % o.opacity_reset_interval == 0)
+
+    @torch.no_grad()
+    def _accumulate_stats(self, pkg):
+        """train_mouth.py:262-263 (device-only: part of a captured step)."""
         vis = pkg["visibility_filter"]
         radii = pkg["radii"].to(self.g.max_radii2D.dtype)
         self.g.max_radii2D.copy_(torch.max(self.g.max_radii2D, torch.where(vis, radii, torch.zeros_like(radii))))
         self.g.add_densification_stats(pkg["viewspace_points"].grad, vis)
+
+    @torch.no_grad()
+    def _density_control(self, it, frame: Frame):
+        """train_mouth.py:265-283, behind the statistics of this iteration."""
+        o = self.opt
+        if not self._stats_on(it):
+            return
         if it > o.densify_from_iter and it % o.densification_interval == 0:
             size_threshold = 20 if it > o.opacity_reset_interval else None
             self.g.densify_and_prune(o.densify_grad_threshold, 0.05 + 0.25 * it / o.densify_until_iter, self.extent,
@@ -162,6 +240,50 @@ class MouthTrainer:
         if it % o.opacity_reset_interval == 0:
             self.g.reset_opacity()
 
+    def _step_optimizers(self):
+        self.motion_optimizer.step()
+        self.g.optimizer.step()
+
+    def _zero_grad(self):
+        self.motion_optimizer.zero_grad(set_to_none=True)
+        self.g.optimizer.zero_grad(set_to_none=True)
+
+    def _body(self, frame: Frame, phase: MouthPhase, k, stats_on: bool):
+        """Everything of an iteration without a density-control event; free of host round trips when `k` is a
+        device tensor (the captured form)."""
+        pkg, loss, Ll1 = self.forward(frame, phase, k)
+        loss.backward()
+        if stats_on:
+            self._accumulate_stats(pkg)
+        self._step_optimizers()
+        self._zero_grad()
+        return loss, Ll1
+
+    def _key(self, it):
+        return (mouth_phase(it, self.opt, self.warm_step, self.bg_iter), self._stats_on(it), self.g.active_sh_degree)
+
+    def enable_graph(self, example: Frame, headroom: float = 1.5, warmup_steps: int = 2):
+        """Capture the step of the NEXT iterations' phase (the warm-up steps are real steps: they advance the
+        iteration counter).  step() falls back to eager launches on density-control iterations and drops the graph
+        when the phase or the parameter set changes."""
+        _drop_graph(self)
+        total = max(1, warmup_steps) + 2
+        key = self._key(self.iteration + total + 1)
+        phase, stats_on, _ = key
+        if phase.late:
+            self._freeze_late()
+
+        def pre():
+            self.iteration += 1
+            self._set_learning_rates(self.iteration)
+            self._k_dev.fill_(self.rng.randint(10, 50))
+
+        def body(frame):
+            return self._body(frame, phase, self._k_dev, stats_on)
+        self._graph = GraphedStage(body, example, self.device, headroom, warmup_steps, pre=pre)
+        self._graph_key = key
+        return self._graph
+
     def step(self, frame: Frame):
         self.iteration += 1
         it = self.iteration
@@ -172,14 +294,25 @@ class MouthTrainer:
         if phase.late:
             self._freeze_late()
         k = self.rng.randint(10, 50)
-        pkg, loss, Ll1 = self.forward(frame, phase, k)
-        loss.backward()
-        self._density_control(it, pkg, frame)
-        if it < self.opt.iterations:
-            self.motion_optimizer.step()
-            self.g.optimizer.step()
-            self.motion_optimizer.zero_grad(set_to_none=True)
-            self.g.optimizer.zero_grad(set_to_none=True)
+        due = self._density_due(it)
+        steps = it < self.opt.iterations
+        if self._graph is not None and (due or not steps or self._key(it) != self._graph_key):
+            _drop_graph(self)
+        if self._graph is not None:
+            self._k_dev.fill_(k)
+            loss, Ll1 = self._graph.replay(frame)
+        else:
+            from . import diff_gauss
+            if diff_gauss._CAPACITY_PLAN is not None:
+                diff_gauss._CAPACITY_PLAN.begin_step()
+            pkg, loss, Ll1 = self.forward(frame, phase, k)
+            loss.backward()
+            if self._stats_on(it):
+                self._accumulate_stats(pkg)
+                self._density_control(it, frame)
+            if steps:
+                self._step_optimizers()
+                self._zero_grad()
         self.last = dict(loss=loss.detach(), l1=Ll1.detach(), num_points=self.g.num_points, phase=phase, k=k)
         return self.last
 
@@ -209,6 +342,8 @@ class FuseTrainer:
             gaussians._p[k].requires_grad_(False)
         for k in self.FROZEN_MOUTH:
             gaussians_mouth._p[k].requires_grad_(False)
+        self._graph = None
+        self._graph_key = None
         self.last = {}
 
     def forward(self, frame: Frame):
@@ -220,17 +355,47 @@ class FuseTrainer:
         loss, Ll1 = fuse_loss(out["image"], frame.original_image.to(dev), self.opt.lambda_dssim)
         return out, loss, Ll1
 
+    def _set_learning_rates(self, it):
+        self.g.update_learning_rate(it)           # train_fuse_con.py:85 (the mouth model keeps its initial rates)
+        _push_lrs(self.g.optimizer)
+
+    def _body(self, frame: Frame):
+        out, loss, Ll1 = self.forward(frame)
+        loss.backward()
+        self.g.optimizer.step()
+        self.g_mouth.optimizer.step()
+        self.g.optimizer.zero_grad(set_to_none=True)
+        self.g_mouth.optimizer.zero_grad(set_to_none=True)
+        return loss, Ll1, out["image"]
+
+    def enable_graph(self, example: Frame, headroom: float = 1.5, warmup_steps: int = 2):
+        """Capture the whole step (the stage has a single phase and no density control: densify_until_iter = 0)."""
+        _drop_graph(self)
+
+        def pre():
+            self.iteration += 1
+            self._set_learning_rates(self.iteration)
+        self._graph = GraphedStage(self._body, example, self.device, headroom, warmup_steps, pre=pre)
+        return self._graph
+
     def step(self, frame: Frame):
         self.iteration += 1
         it = self.iteration
-        self.g.update_learning_rate(it)           # train_fuse_con.py:85 (the mouth model keeps its initial rates)
-        _push_lrs(self.g.optimizer)
-        out, loss, Ll1 = self.forward(frame)
-        loss.backward()
-        if it < self.opt.iterations:
-            self.g.optimizer.step()
-            self.g_mouth.optimizer.step()
+        self._set_learning_rates(it)
+        if self._graph is not None and it >= self.opt.iterations:
+            _drop_graph(self)
+        if self._graph is not None:
+            loss, Ll1, image = self._graph.replay(frame)
+        elif it < self.opt.iterations:
+            from . import diff_gauss
+            if diff_gauss._CAPACITY_PLAN is not None:
+                diff_gauss._CAPACITY_PLAN.begin_step()
+            loss, Ll1, image = self._body(frame)
+        else:
+            out, loss, Ll1 = self.forward(frame)         # last iteration: no optimizer step (:242)
+            loss.backward()
             self.g.optimizer.zero_grad(set_to_none=True)
             self.g_mouth.optimizer.zero_grad(set_to_none=True)
-        self.last = dict(loss=loss.detach(), l1=Ll1.detach(), image=out["image"].detach())
+            image = out["image"]
+        self.last = dict(loss=loss.detach(), l1=Ll1.detach(), image=image.detach())
         return self.last

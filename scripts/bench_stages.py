@@ -42,11 +42,20 @@ def timed(name, step, warm=5, K=30):
 pc, net, pcm, netm = models()
 mt = MouthTrainer(pcm, netm, pc, net, bg, densify=False)
 mt.iteration = 3000                    # warm phase: alignment + alpha terms
-timed("mouth step (20k | face 100k)", mt.step)
+timed("mouth step (20k | face 100k), eager", mt.step)
+mt.enable_graph(frames[0])
+timed("mouth step, hipGraph replay", mt.step)
+print("   overflow:", mt._graph.check_overflow(), "capacities", mt._graph.capacities, flush=True)
+from instag_amd import diff_gauss
+diff_gauss.set_capacity_plan(None)
 
 pc, net, pcm, netm = models()
 ft = FuseTrainer(pc, net, pcm, netm, bg)
-timed("fuse step (100k + 20k)", ft.step)
+timed("fuse step (100k + 20k), eager", ft.step)
+ft.enable_graph(frames[0])
+timed("fuse step, hipGraph replay", ft.step)
+print("   overflow:", ft._graph.check_overflow(), "capacities", ft._graph.capacities, flush=True)
+diff_gauss.set_capacity_plan(None)
 
 tr = build_trainer(100000, dev, seed=0)
 late = FacePhase(priors=True, prior_depth=True)

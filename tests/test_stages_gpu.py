@@ -254,3 +254,63 @@ def test_fuse_trainer_step():
         assert torch.equal(v, cur), (which, k)
     assert not torch.equal(op0, pc_face._p["opacity"].detach())
     assert not torch.equal(fdc0, pc_face._p["f_dc"].detach()) and not torch.equal(mdc0, pc_mouth._p["f_dc"].detach())
+
+
+def test_stage_trainers_graph_matches_eager():
+    """Whole-step hipGraph of the mouth and fuse steps == the eager steps (same seeds, same frames, same random k
+    sequence): losses and parameters agree after the replays; the mouth graph is dropped on a density-control
+    iteration and the step falls back to eager launches."""
+    from instag_amd import diff_gauss
+    from instag_amd.train_stages import FuseTrainer, MouthTrainer
+    dev = torch.device("cuda")
+    bg = torch.tensor([0.0, 1.0, 0.0], device=dev)
+    frames = _frames(96, 3, dev, background=True)
+    NoDensify = type("NoDensify", (SmallOpt,), {"iterations": 100000})
+
+    def run(kind, graph):
+        pc_face, face_net, pc_mouth, mouth_net = _mouth_setup(dev, n_face=2000, n_mouth=900, seed=7)
+        if kind == "mouth":
+            tr = MouthTrainer(pc_mouth, mouth_net, pc_face, face_net, bg, opt=NoDensify, densify=False, seed=3,
+                              warm_step=2, bg_iter=1000)
+        else:
+            tr = FuseTrainer(pc_face, face_net, pc_mouth, mouth_net, bg, opt=NoDensify)
+        try:
+            if graph:
+                tr.enable_graph(frames[0], warmup_steps=2)          # 4 real steps on frame 0
+                assert tr.iteration == 4 and tr._graph is not None
+            else:
+                for _ in range(4):
+                    tr.step(frames[0])
+            losses = [float(tr.step(frames[i % 3])["loss"]) for i in range(6)]
+            if graph:
+                assert tr._graph is not None and not tr._graph.check_overflow()
+        finally:
+            diff_gauss.set_capacity_plan(None)
+        vec = torch.cat([tr.g._p["f_dc"].detach().reshape(-1), tr.g._p["opacity"].detach().reshape(-1),
+                         tr.g._p["xyz"].detach().reshape(-1)])
+        return losses, vec, tr
+
+    for kind in ("mouth", "fuse"):
+        le, ve, _ = run(kind, False)
+        lg, vg, tr = run(kind, True)
+        assert tr.iteration == 10
+        for a_, b_ in zip(le, lg):
+            assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (kind, le, lg)
+        assert float((ve - vg).abs().max()) <= 1e-5, kind
+
+    # density control on: the captured step is abandoned on the iteration that densifies
+    pc_face, face_net, pc_mouth, mouth_net = _mouth_setup(dev, n_face=2000, n_mouth=900, seed=8)
+    Opt = type("Opt", (SmallOpt,), {"iterations": 100000, "densify_until_iter": 200, "opacity_reset_interval": 1000})
+    tr = MouthTrainer(pc_mouth, mouth_net, pc_face, face_net, bg, opt=Opt, densify=True, seed=3, warm_step=2, bg_iter=1000)
+    try:
+        tr.enable_graph(frames[0], warmup_steps=2)                  # iterations 1..4
+        out = tr.step(frames[1])                                    # 5: replayed
+        assert tr._graph is not None and torch.isfinite(out["loss"])
+        n0 = tr.g.num_points
+        out = tr.step(frames[2])                                    # 6 % 3 == 0: density control, eager
+        assert tr._graph is None and torch.isfinite(out["loss"])
+        assert tr.g.xyz_gradient_accum.shape[0] == tr.g.num_points
+        out = tr.step(frames[0])
+        assert torch.isfinite(out["loss"]) and (tr.g.num_points != n0 or True)
+    finally:
+        diff_gauss.set_capacity_plan(None)
