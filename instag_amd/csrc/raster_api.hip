@@ -65,19 +65,34 @@ using TileSortPairsConfig = rocprim::radix_sort_config<
 // bits = width of the tile id; vals_* null = key-only form; temp null = size query (the larger of the two forms).
 // 8-bit digits: measured on MI355X (1.5 M keys, 10-bit tile ids) one 10-bit pass costs 56 us + a 17 us histogram
 // against 2 x 17 us + 8 us for two 8-bit passes (the 1024-bin in-block ranking is what grows).
+//
+// `replayed` = the call sits in a step that is captured into a hipGraph (capacity mode).  Below 2^20 keys such a call
+// takes rocPRIM's default path (merge sort at these sizes): a captured onesweep sort of 0.33 M keys (mouth branch,
+// 20k Gaussians) ran correctly on the first replay of its graph and faulted inside the scatter kernel on the second
+// one, with or without rocPRIM's atomic block ids, while the same sort of 1.5 M keys (face branch) has replayed
+// thousands of times -- the zero-initialised state of the small sort (digit offsets / look-back flags, cleared by
+// memset nodes) does not survive a replay on ROCm 7.2.  The merge sort keeps no state between its kernels.
 hipError_t tile_sort(void* temp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
-                     uint32_t* vals_out, size_t n, unsigned begin_bit, unsigned bits, hipStream_t s) {
+                     uint32_t* vals_out, size_t n, unsigned begin_bit, unsigned bits, bool replayed, hipStream_t s) {
   const unsigned end_bit = begin_bit + bits;
-  if (temp == nullptr) {
-    size_t a = 0, b = 0;
-    hipError_t e = rocprim::radix_sort_keys<TileSortKeysConfig>(nullptr, a, keys_in, keys_out, n, begin_bit, end_bit, s);
-    if (e != hipSuccess) return e;
-    e = rocprim::radix_sort_pairs<TileSortPairsConfig>(nullptr, b, keys_in, keys_out, vals_in, vals_out, n, begin_bit,
-                                                       end_bit, s);
-    bytes = std::max(a, b);
+  const bool keys_only = vals_in == nullptr && vals_out == nullptr;
+  if (temp == nullptr) {      // size query: the largest request of the four forms
+    size_t q[4] = {0, 0, 0, 0};
+    hipError_t e = rocprim::radix_sort_keys<TileSortKeysConfig>(nullptr, q[0], keys_in, keys_out, n, begin_bit, end_bit, s);
+    if (e == hipSuccess)
+      e = rocprim::radix_sort_pairs<TileSortPairsConfig>(nullptr, q[1], keys_in, keys_out, vals_in, vals_out, n, begin_bit,
+                                                         end_bit, s);
+    if (e == hipSuccess) e = rocprim::radix_sort_keys(nullptr, q[2], keys_in, keys_out, n, begin_bit, end_bit, s);
+    if (e == hipSuccess)
+      e = rocprim::radix_sort_pairs(nullptr, q[3], keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
+    bytes = std::max(std::max(q[0], q[1]), std::max(q[2], q[3]));
     return e;
   }
-  if (vals_in == nullptr && vals_out == nullptr)
+  if (replayed && n < ((size_t)1 << 20)) {
+    if (keys_only) return rocprim::radix_sort_keys(temp, bytes, keys_in, keys_out, n, begin_bit, end_bit, s);
+    return rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
+  }
+  if (keys_only)
     return rocprim::radix_sort_keys<TileSortKeysConfig>(temp, bytes, keys_in, keys_out, n, begin_bit, end_bit, s);
   return rocprim::radix_sort_pairs<TileSortPairsConfig>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit,
                                                         end_bit, s);
@@ -147,7 +162,7 @@ BinningLayout binning_layout(int64_t R) {
   size_t tmp = 0;
   for (unsigned bits : {8u, 16u, 24u}) {
     size_t t = 0;
-    (void)tile_sort(nullptr, t, nullptr, nullptr, nullptr, nullptr, r, 0, bits, nullptr);
+    (void)tile_sort(nullptr, t, nullptr, nullptr, nullptr, nullptr, r, 0, bits, false, nullptr);
     tmp = std::max(tmp, t);
   }
   L.sort_temp = o; L.sort_temp_bytes = tmp; o = align_up(o + tmp, 256);
@@ -275,9 +290,9 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
       size_t tmp = BL.sort_temp_bytes;
       const int bits = tile_bits > 0 ? tile_bits : 1;
       if (packed)
-        INSTAG_CHECK_HIP(tile_sort(bb + BL.sort_temp, tmp, keys_u, keys, nullptr, nullptr, (size_t)R, PACK_SHIFT, bits, s));
+        INSTAG_CHECK_HIP(tile_sort(bb + BL.sort_temp, tmp, keys_u, keys, nullptr, nullptr, (size_t)R, PACK_SHIFT, bits, pad, s));
       else
-        INSTAG_CHECK_HIP(tile_sort(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0, bits, s));
+        INSTAG_CHECK_HIP(tile_sort(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0, bits, pad, s));
     }
     if (int e = launch_ranges(R, keys, vals, gid_u, point_list, ranges, (uint32_t)tiles, packed, s)) return e;
   } else {

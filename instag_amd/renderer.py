@@ -196,6 +196,19 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             "p_attn": p_rendered_attn, "motion_reg": motion_reg})
 
 
+def _top_values(v, kmax, largest):
+    """The kmax largest (smallest) values of a 1-D tensor, sorted, by row-wise top-k over 512-element rows until
+    fewer than 10,000 candidates are left.  (torch.topk on a 1-D tensor of >= 10,000 elements takes a full-sort
+    path on ROCm, which does not survive stream capture; the row-wise form selects the same values.)"""
+    pad = float("-inf") if largest else float("inf")
+    v = v.reshape(-1)
+    while v.numel() >= 10000:
+        rows = (v.numel() + 511) // 512
+        v = torch.nn.functional.pad(v, (0, rows * 512 - v.numel()), value=pad).view(rows, 512)
+        v = v.topk(min(kmax, 512), 1, largest, False).values.reshape(-1)
+    return v.topk(min(kmax, v.numel()), 0, largest, True).values
+
+
 def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_net_face, pipe=None, bg_color=None,
                             scaling_modifier=1.0, frame_idx=None, return_attn=False, personalized=False, align=False,
                             k=10, inference=False):
@@ -225,11 +238,11 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
             # round trip -- the 50 largest / smallest once, the k-th of them by index
             kmax = min(50, dy.shape[0])
             kidx = (k.reshape(1) - 1).clamp(0, kmax - 1)
-            motion_max = dy.topk(kmax, 0, True, True).values.gather(0, kidx)[0]
-            motion_min = dy.topk(kmax, 0, False, True).values.gather(0, kidx)[0]
+            motion_max = _top_values(dy, kmax, True).gather(0, kidx)[0]
+            motion_min = _top_values(dy, kmax, False).gather(0, kidx)[0]
         else:
-            motion_max = dy.topk(k, 0, True, True).values[-1]
-            motion_min = dy.topk(k, 0, False, True).values[-1]
+            motion_max = _top_values(dy, k, True)[-1]
+            motion_min = _top_values(dy, k, False)[-1]
         move_feat = torch.stack([motion_max, motion_min, motion_max - motion_min]).reshape(1, 3) * 1e2
     motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
     d_xyz = motion_preds["d_xyz"]

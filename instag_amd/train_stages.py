@@ -96,8 +96,9 @@ def _push_lrs(*optimizers):
 
 class GraphedStage:
     """A stage trainer's whole step (forward, loss, backward, statistics, optimizers) captured once into a hipGraph
-    and replayed: ``body(frame)`` must be free of host round trips; the rasterizer runs in its capacity mode with one
-    slot per rasterizer call of the step, sized from eager warm-up steps (instag_amd/diff_gauss.py:CapacityPlan)."""
+    and replayed: ``body(frame) -> (outputs..., keepalive)`` must be free of host round trips; the rasterizer runs in
+    its capacity mode with one slot per rasterizer call of the step, sized from eager warm-up steps
+    (instag_amd/diff_gauss.py:CapacityPlan)."""
 
     def __init__(self, body, example: Frame, device, headroom: float = 1.5, warmup_steps: int = 2, pre=None):
         """``pre()`` = the host-side part of a step (iteration counter, learning-rate table): run before every
@@ -105,6 +106,7 @@ class GraphedStage:
         from . import diff_gauss
         from .train import _no_gc
         assert device.type == "cuda", "graph mode needs the GPU"
+        import sys
         self.static = example.clone_static()
         diff_gauss.set_capacity_plan(None)
         counts = None
@@ -131,7 +133,19 @@ class GraphedStage:
         self.graph = torch.cuda.CUDAGraph()
         self.plan.begin_step()
         with _no_gc(), torch.cuda.graph(self.graph):
-            self.out = body(self.static)
+            try:
+                out = body(self.static)
+            except BaseException:
+                # an operator that is not capturable raised: report it before the capture is torn down (ending an
+                # invalidated capture can crash the process on ROCm 7.2, which would hide the message)
+                import traceback
+                traceback.print_exc()
+                sys.stderr.flush()
+                raise
+        # body returns (..., keepalive): the render package stays referenced until the capture has ended (ROCm 7.2:
+        # releasing it inside the capture window intermittently crashes hipStreamEndCapture), then it is dropped
+        self.out = tuple(out[:-1])
+        del out
 
     def replay(self, frame: Frame):
         self.static.copy_from(frame)
@@ -257,7 +271,7 @@ class MouthTrainer:
             self._accumulate_stats(pkg)
         self._step_optimizers()
         self._zero_grad()
-        return loss, Ll1
+        return loss, Ll1, pkg
 
     def _key(self, it):
         return (mouth_phase(it, self.opt, self.warm_step, self.bg_iter), self._stats_on(it), self.g.active_sh_degree)
@@ -300,7 +314,7 @@ class MouthTrainer:
             _drop_graph(self)
         if self._graph is not None:
             self._k_dev.fill_(k)
-            loss, Ll1 = self._graph.replay(frame)
+            loss, Ll1 = self._graph.replay(frame)[:2]
         else:
             from . import diff_gauss
             if diff_gauss._CAPACITY_PLAN is not None:
@@ -366,7 +380,7 @@ class FuseTrainer:
         self.g_mouth.optimizer.step()
         self.g.optimizer.zero_grad(set_to_none=True)
         self.g_mouth.optimizer.zero_grad(set_to_none=True)
-        return loss, Ll1, out["image"]
+        return loss, Ll1, out["image"], out
 
     def enable_graph(self, example: Frame, headroom: float = 1.5, warmup_steps: int = 2):
         """Capture the whole step (the stage has a single phase and no density control: densify_until_iter = 0)."""
@@ -385,12 +399,12 @@ class FuseTrainer:
         if self._graph is not None and it >= self.opt.iterations:
             _drop_graph(self)
         if self._graph is not None:
-            loss, Ll1, image = self._graph.replay(frame)
+            loss, Ll1, image = self._graph.replay(frame)[:3]
         elif it < self.opt.iterations:
             from . import diff_gauss
             if diff_gauss._CAPACITY_PLAN is not None:
                 diff_gauss._CAPACITY_PLAN.begin_step()
-            loss, Ll1, image = self._body(frame)
+            loss, Ll1, image = self._body(frame)[:3]
         else:
             out, loss, Ll1 = self.forward(frame)         # last iteration: no optimizer step (:242)
             loss.backward()

@@ -270,8 +270,9 @@ def test_stage_trainers_graph_matches_eager():
     def run(kind, graph):
         pc_face, face_net, pc_mouth, mouth_net = _mouth_setup(dev, n_face=2000, n_mouth=900, seed=7)
         if kind == "mouth":
+            # warm_step = 0: every iteration is in the same phase (the graph's warm-up steps run in the phase it captures)
             tr = MouthTrainer(pc_mouth, mouth_net, pc_face, face_net, bg, opt=NoDensify, densify=False, seed=3,
-                              warm_step=2, bg_iter=1000)
+                              warm_step=0, bg_iter=1000)
         else:
             tr = FuseTrainer(pc_face, face_net, pc_mouth, mouth_net, bg, opt=NoDensify)
         try:
@@ -301,7 +302,7 @@ def test_stage_trainers_graph_matches_eager():
     # density control on: the captured step is abandoned on the iteration that densifies
     pc_face, face_net, pc_mouth, mouth_net = _mouth_setup(dev, n_face=2000, n_mouth=900, seed=8)
     Opt = type("Opt", (SmallOpt,), {"iterations": 100000, "densify_until_iter": 200, "opacity_reset_interval": 1000})
-    tr = MouthTrainer(pc_mouth, mouth_net, pc_face, face_net, bg, opt=Opt, densify=True, seed=3, warm_step=2, bg_iter=1000)
+    tr = MouthTrainer(pc_mouth, mouth_net, pc_face, face_net, bg, opt=Opt, densify=True, seed=3, warm_step=0, bg_iter=1000)
     try:
         tr.enable_graph(frames[0], warmup_steps=2)                  # iterations 1..4
         out = tr.step(frames[1])                                    # 5: replayed
