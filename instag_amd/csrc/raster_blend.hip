@@ -146,7 +146,8 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
 // feature fragments (B operands) are fixed for the whole tile and live in 64 VGPRs.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BB = 32;          // Gaussians per backward batch
+constexpr int BB = 16;          // Gaussians per backward batch (one MFMA row block): 40 KB of LDS per workgroup, so that
+                                // three to four workgroups fit a CU and one's MFMA phase overlaps another's VALU phase
 constexpr int WROW = 68;        // floats per (pixel-quarter, Gaussian) row of the w / t matrices (64 + 4 pad)
 
 template <bool FULL>            // FULL: depth / normal / extra channels carry gradient too; else rgb only
@@ -160,7 +161,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   __shared__ float4 s_rec[BB][4];
   __shared__ __align__(16) float s_W[4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
   __shared__ __align__(16) float s_T[4 * BB * WROW];
-  __shared__ float s_res[BB][2][16];
+  __shared__ float s_res[BB][2][2][16];               // [gaussian][matrix][pixel half][feature]
   __shared__ int s_max[4];
   const int tile = blockIdx.x;
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
@@ -212,8 +213,8 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   // ---- B-operand fragments of phase B (fixed per tile).  MFMA step s of pixel quarter kk = lane>>4 covers
   // pixel p = 64 kk + s; feature f = lane & 15.  Waves 0/2 multiply the w matrix with dL/dpixel[f] (f < 8),
   // waves 1/3 the t matrix with the moments (1, lx, ly, lx^2, lx ly, ly^2) of the pixel's in-tile coordinates.
-  const int mat = wave & 1, grp = wave >> 1;
-  float bfrag[64];
+  const int mat = wave & 1, khalf = wave >> 1;         // wave = (matrix, half of every quarter's 64 pixels)
+  float bfrag[32];
   {
     float* s_F = s_W;                       // staging: dL/dpixel of all 256 pixels, [pixel][8]
 #pragma unroll
@@ -221,8 +222,8 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     __syncthreads();
     const int kk = lane >> 4, f = lane & 15;
 #pragma unroll
-    for (int s_ = 0; s_ < 64; ++s_) {
-      const int p = 64 * kk + s_;
+    for (int s_ = 0; s_ < 32; ++s_) {
+      const int p = 64 * kk + 32 * khalf + s_;
       float v;
       if (mat == 0) {
         v = f < NCH ? s_F[p * NCH + f] : 0.f;
@@ -305,10 +306,10 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     __syncthreads();
     // ---- phase B: [16 Gaussians x 256 pixels] x [256 pixels x 16 features] on the matrix cores ------------
     {
-      const float* M = (mat == 0 ? s_W : s_T) + ((lane >> 4) * BB + 16 * grp + (lane & 15)) * WROW;
+      const float* M = (mat == 0 ? s_W : s_T) + ((lane >> 4) * BB + (lane & 15)) * WROW + 32 * khalf;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) {
+      for (int s4 = 0; s4 < 8; ++s4) {
         const float4 a4 = *reinterpret_cast<const float4*>(M + 4 * s4);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bfrag[4 * s4 + 0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bfrag[4 * s4 + 1], acc, 0, 0, 0);
@@ -317,14 +318,17 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       }
       // D[g = 4*(lane>>4) + r][f = lane&15]
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s_res[16 * grp + 4 * (lane >> 4) + r][mat][lane & 15] = acc[r];
+      for (int r = 0; r < 4; ++r) s_res[4 * (lane >> 4) + r][mat][khalf][lane & 15] = acc[r];
     }
     __syncthreads();
     // ---- one 64-byte gradient row per (tile, Gaussian) instance -------------------------------------------------
     if (tid < cnt) {
       const float4 ra = s_rec[tid][0], rb = s_rec[tid][1];
-      const float* Dw = s_res[tid][0];
-      const float* Dt = s_res[tid][1];
+      float Dw[NCH], Dt[6];
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) Dw[k] = s_res[tid][0][0][k] + s_res[tid][0][1][k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Dt[k] = s_res[tid][1][0][k] + s_res[tid][1][1][k];
       const float X = ra.x - tile_x0, Y = ra.y - tile_y0;
       const float A = ra.z, B = ra.w, Cc = rb.x, op = rb.y;
       const float S0 = Dt[0], Sx = Dt[1], Sy = Dt[2], Sxx = Dt[3], Sxy = Dt[4], Syy = Dt[5];
