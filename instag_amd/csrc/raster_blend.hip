@@ -140,10 +140,10 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
 // kept minimal: phase A (one pixel per lane) only advances the recurrence and emits two numbers per
 // (Gaussian, pixel) -- w = alpha*T and t = G*dL/dalpha -- into LDS; the 14 gradient components of a
 // Gaussian are sums over the tile's 256 pixels of w*dL/dpixel[ch] and of t times the pixel-coordinate
-// moments (1, x, y, x^2, xy, y^2), i.e. two small GEMMs [32 Gaussians x 256 pixels] x [256 pixels x 16],
+// moments (1, x, y, x^2, xy, y^2), i.e. two small GEMMs [16 Gaussians x 256 pixels] x [256 pixels x 16],
 // which phase B runs on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) instead of 14 x 6
-// cross-lane DPP adds per Gaussian per wave.  One wave per (16-Gaussian group, matrix); the per-pixel
-// feature fragments (B operands) are fixed for the whole tile and live in 64 VGPRs.
+// cross-lane DPP adds per Gaussian per wave.  One wave per (matrix, half of every pixel quarter); the per-pixel
+// feature fragments (B operands) are fixed for the whole tile and live in 32 VGPRs.
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BB = 16;          // Gaussians per backward batch (one MFMA row block): 40 KB of LDS per workgroup, so that
