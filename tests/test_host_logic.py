@@ -249,3 +249,39 @@ def test_frame_packs_optional_tensors():
     for k in ("normal", "depth", "background", "auds", "face_mask"):
         assert torch.equal(rich.talking_dict[k], other.talking_dict[k]), k
     assert torch.equal(rich.original_image, other.original_image)
+
+
+def _stats_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.grid_torch import GridEncoder as CpuGrid
+        from instag_amd.train import build_trainer
+        tr = build_trainer(64, torch.device("cpu"), seed=0, encoder_cls=CpuGrid)
+        g = tr.g
+        # per-rank accumulations of the frames this rank rendered since the last densification
+        g.xyz_gradient_accum = torch.full((64, 1), float(rank + 1))
+        g.denom = torch.full((64, 1), float(2 * rank + 1))
+        g.max_radii2D = torch.arange(64, dtype=torch.float32) * (1.0 if rank == 0 else -1.0) + 5.0 * rank
+        tr.sync_densification_stats()
+        results[rank] = dict(acc=g.xyz_gradient_accum.clone(), den=g.denom.clone(), rad=g.max_radii2D.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_densification_stats_are_exchanged_when_read_gloo_world2():
+    """Several ranks keep the densification statistics as per-rank sums / maxima and exchange them only when a
+    densification reads them (FaceTrainer.sync_densification_stats): SUM of the gradient norms and visibility counts,
+    MAX of the screen radii, identical on every rank afterwards."""
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_stats_worker, args=(world, port, results), nprocs=world, join=True)
+    r0, r1 = results[0], results[1]
+    for k in ("acc", "den", "rad"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert torch.equal(r0["acc"], torch.full((64, 1), 3.0)) and torch.equal(r0["den"], torch.full((64, 1), 4.0))
+    want = torch.max(torch.arange(64, dtype=torch.float32), 5.0 - torch.arange(64, dtype=torch.float32))
+    assert torch.equal(r0["rad"], want)
