@@ -375,6 +375,13 @@ int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* imag
  * gradient) before use.
  * ------------------------------------------------------------------------------------------ */
 int instag_adam_chunk_elems(void);
+/* the same with the gradient pointers as a HOST array (uint64[n_tensors], 0 = no gradient this step; n_tensors <=
+ * instag_adam_grads_max()): they travel in the kernel arguments and the `g` field of the device records is ignored, so
+ * no copy precedes the launch and the device table is uploaded only when the parameter set changes */
+int instag_adam_grads_max(void);
+int instag_adam_step_grads(const void* tensors, const void* host_grads, int32_t n_tensors, const void* groups,
+                           const float* lrs, const int32_t* chunks, int32_t n_chunks, float* step,
+                           instag_stream_t stream);
 int instag_adam_step(const void* tensors, int32_t n_tensors, const void* groups, const float* lrs,
                      const int32_t* chunks, int32_t n_chunks, float* step, instag_stream_t stream);
 

@@ -8,6 +8,8 @@
 //   AdamW: p *= 1 - lr*wd;  Adam: g += wd*p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // Learning rates and the step counter live in device memory so that a captured hipGraph can be replayed.
+#include <cstring>
+
 #include "common.hpp"
 
 namespace instag {
@@ -62,6 +64,45 @@ adam_step_kernel(const AdamTensor* __restrict__ tensors, const AdamGroup* __rest
   }
 }
 
+// The same two kernels with the GRADIENT pointers passed by value in the kernel arguments (<= 384 tensors = 3 KB):
+// parameter / moment pointers change only when the parameter set is rebuilt and stay in the device table, the
+// gradient pointers change every step -- this way no host-to-device copy precedes the launch, and in a captured step
+// the pointers are part of the kernel node instead of a memcpy node that has to land before the optimizer can start.
+constexpr int ADAM_GRADS_MAX = 384;
+struct AdamGrads { const float* g[ADAM_GRADS_MAX]; };
+
+__global__ void adam_tick_grads_kernel(AdamGrads gr, int n, float* __restrict__ steps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && gr.g[i] != nullptr) steps[i] += 1.0f;
+}
+
+__global__ void __launch_bounds__(ADAM_BLOCK)
+adam_step_grads_kernel(const AdamTensor* __restrict__ tensors, AdamGrads grads, const AdamGroup* __restrict__ groups,
+                       const float* __restrict__ lrs, const int2* __restrict__ chunks, const float* __restrict__ step) {
+  const int2 ch = chunks[blockIdx.x];            // (tensor index, chunk index)
+  const float* __restrict__ tg = grads.g[ch.x];
+  if (tg == nullptr) return;
+  const AdamTensor t = tensors[ch.x];
+  const AdamGroup gr = groups[t.group];
+  const float lr = lrs[t.group];
+  const float tstep = step[ch.x];
+  const float bc1 = 1.0f - powf(gr.beta1, tstep);
+  const float bc2_sqrt = sqrtf(1.0f - powf(gr.beta2, tstep));
+  const float step_size = lr / bc1;
+  const int64_t base = (int64_t)ch.y * ADAM_CHUNK;
+  const int64_t end = min(t.n, base + ADAM_CHUNK);
+  for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) {
+    float p = t.p[i], g = tg[i], m = t.m[i], v = t.v[i];
+    if (gr.decoupled) p *= 1.0f - lr * gr.weight_decay;
+    else if (gr.weight_decay != 0.f) g += gr.weight_decay * p;
+    m = gr.beta1 * m + (1.0f - gr.beta1) * g;
+    v = gr.beta2 * v + (1.0f - gr.beta2) * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + gr.eps;
+    p -= step_size * (m / denom);
+    t.p[i] = p; t.m[i] = m; t.v[i] = v;
+  }
+}
+
 }  // namespace
 }  // namespace instag
 
@@ -85,6 +126,29 @@ int instag_adam_step(const void* tensors, int32_t n_tensors, const void* groups,
   INSTAG_CHECK_LAUNCH();
   adam_step_kernel<<<n_chunks, ADAM_BLOCK, 0, s>>>((const AdamTensor*)tensors, (const AdamGroup*)groups, lrs,
                                                    (const int2*)chunks, step);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_adam_grads_max(void) { return ADAM_GRADS_MAX; }
+
+/* As instag_adam_step, but the gradient pointers come as a HOST array `host_grads` (uint64[n_tensors], 0 = the tensor
+ * has no gradient this step; n_tensors <= instag_adam_grads_max()) and travel in the kernel arguments; the `g` field of
+ * the device records is ignored, so the device table only has to be uploaded when the parameter set changes. */
+int instag_adam_step_grads(const void* tensors, const void* host_grads, int32_t n_tensors, const void* groups,
+                           const float* lrs, const int32_t* chunks, int32_t n_chunks, float* step,
+                           instag_stream_t stream) {
+  INSTAG_REQUIRE(tensors && host_grads && groups && lrs && chunks && step, "adam_step: NULL argument");
+  INSTAG_REQUIRE(n_tensors <= ADAM_GRADS_MAX, "adam_step_grads: more tensors than instag_adam_grads_max()");
+  if (n_chunks <= 0 || n_tensors <= 0) return INSTAG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  AdamGrads gr;
+  memset(&gr, 0, sizeof(gr));
+  memcpy(gr.g, host_grads, (size_t)n_tensors * sizeof(const float*));
+  adam_tick_grads_kernel<<<(n_tensors + 63) / 64, 64, 0, s>>>(gr, n_tensors, step);
+  INSTAG_CHECK_LAUNCH();
+  adam_step_grads_kernel<<<n_chunks, ADAM_BLOCK, 0, s>>>((const AdamTensor*)tensors, gr, (const AdamGroup*)groups, lrs,
+                                                         (const int2*)chunks, step);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

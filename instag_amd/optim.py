@@ -88,7 +88,8 @@ class MultiTensorAdam:
         dev = tensors[0][0].device
         chunk = L.instag_adam_chunk_elems()
         key = tuple((t[0].data_ptr(), t[0].numel(), t[2].data_ptr()) for t in tensors)
-        if self._dev != dev or key != self._layout_key:
+        relayout = self._dev != dev or key != self._layout_key
+        if relayout:
             # static part: chunk table, group table, pinned staging buffers
             chunks = [(ti, c) for ti, t in enumerate(tensors) for c in range((t[0].numel() + chunk - 1) // chunk)]
             self._chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
@@ -111,10 +112,26 @@ class MultiTensorAdam:
                 self._state_of(t[0])["step"] = steps[i:i + 1]
             self._dev, self._layout_key = dev, key
             self.set_lrs()
+        self._keep = [t[1] for t in tensors]          # keep contiguous grad copies alive until the launch ran
+        if len(tensors) <= L.instag_adam_grads_max():
+            # parameter / moment pointers sit in the device table (uploaded when the layout changes); the gradient
+            # pointers, new every step, travel in the kernel arguments: nothing to copy in front of the launch
+            if relayout:
+                tarr = self._tensors_host.numpy().view(_TENSOR_DT)
+                for i, (p, grad, m, v, gi) in enumerate(tensors):
+                    tarr[i] = (p.data_ptr(), 0, m.data_ptr(), v.data_ptr(), p.numel(), gi, 0)
+                self._tensors_dev.copy_(self._tensors_host, non_blocking=True)
+                self._grads_host = np.zeros(len(tensors), dtype=np.uint64)
+            gh = self._grads_host
+            for i, t in enumerate(tensors):
+                gh[i] = 0 if t[1] is None else t[1].data_ptr()
+            check(L.instag_adam_step_grads(ptr(self._tensors_dev), gh.ctypes.data, len(tensors), ptr(self._groups_dev),
+                                           ptr(self._lr_dev), ptr(self._chunks), self._chunks.shape[0],
+                                           ptr(self._step), _lib.current_stream()), "adam_step")
+            return
         tarr = self._tensors_host.numpy().view(_TENSOR_DT)
         for i, (p, grad, m, v, gi) in enumerate(tensors):
             tarr[i] = (p.data_ptr(), 0 if grad is None else grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), gi, 0)
-        self._keep = [t[1] for t in tensors]          # keep contiguous grad copies alive until the launch ran
         self._tensors_dev.copy_(self._tensors_host, non_blocking=True)
         check(L.instag_adam_step(ptr(self._tensors_dev), len(tensors), ptr(self._groups_dev), ptr(self._lr_dev),
                                  ptr(self._chunks), self._chunks.shape[0], ptr(self._step), _lib.current_stream()),
