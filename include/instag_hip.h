@@ -222,6 +222,13 @@ int instag_mlp_forward(const float* x, const float* w1, const float* w2, const f
 int instag_mlp_backward(const float* dy, const float* a1, const float* a2, const float* w1,
                         const float* w2, const float* w3, float* dz1, float* dz2, float* dx, int32_t N,
                         int32_t K0, int32_t H, int32_t O, int32_t NL, instag_stream_t stream);
+/* as instag_mlp_backward with dx = dX + dx_add ([N,K0], may be dx itself or NULL): when the MLP's input feeds other
+ * consumers too (scene/motion_net.py:281-306: enc_x goes to both attention MLPs and into sigma_net's input), their
+ * gradient is summed inside this kernel instead of by an elementwise launch in between */
+int instag_mlp_backward_add(const float* dy, const float* a1, const float* a2, const float* w1,
+                            const float* w2, const float* w3, float* dz1, float* dz2, float* dx,
+                            const float* dx_add, int32_t N, int32_t K0, int32_t H, int32_t O, int32_t NL,
+                            instag_stream_t stream);
 size_t instag_linear_weight_grad_workspace_bytes(int32_t N, int32_t O, int32_t K);
 int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void* workspace,
                               size_t workspace_bytes, int32_t N, int32_t O, int32_t K,

@@ -80,6 +80,7 @@ _PROTOS = {
                                              vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "instag_mlp_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "instag_mlp_backward_add": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_linear_weight_grad_batched": (C.c_int, [vp, i32, vp, sz, vp]),
     "instag_linear_weight_grad_workspace_bytes": (sz, [i32, i32, i32]),
     "instag_linear_weight_grad": (C.c_int, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),

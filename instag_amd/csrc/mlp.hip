@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(MLP_BLOCK)
 mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __restrict__ A1,
                     const float* __restrict__ A2, const float* __restrict__ W1, const float* __restrict__ W2,
                     const float* __restrict__ W3, float* __restrict__ dZ1, float* __restrict__ dZ2,
-                    float* __restrict__ dX) {
+                    float* dX, const float* dXadd /* [N,K0] added to the input gradient, may alias dX, or null */) {
   extern __shared__ __align__(16) float s_w[];
   constexpr int KB0 = (KQ0 + 3) / 4, HB = (HQ + 3) / 4;
   constexpr int KP0 = KB0 * 32, HP = HB * 32;
@@ -262,6 +262,16 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
     if (dX) {
       f32x16 gx[KB0];
       layer_backward<HQ, HB, KB0>(w1, g1, gx, l31, h);
+      if (dXadd) {
+        // the input has other consumers: their gradient is summed here instead of by a separate elementwise launch
+        // (every element is read and written by the same lane, so dXadd may be dX itself)
+#pragma unroll
+        for (int b = 0; b < KB0; ++b) {
+          f32x16 prev;
+          load_block(dXadd, row, valid, d.K0, b, h, prev);
+          gx[b] += prev;
+        }
+      }
 #pragma unroll
       for (int b = 0; b < KB0; ++b) store_block(dX, row, valid, d.K0, b, h, gx[b]);
     }
@@ -428,12 +438,12 @@ int run_fwd(const MlpDims& d, const float* x, const float* w1, const float* w2, 
 }
 template <int KQ0, int HQ, int OQ, int NL>
 int run_bwd(const MlpDims& d, const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
-            const float* w3, float* dz1, float* dz2, float* dx, hipStream_t s) {
+            const float* w3, float* dz1, float* dz2, float* dx, const float* dx_add, hipStream_t s) {
   const int ntiles = (d.N + 31) / 32;
   const int blocks = mlp_blocks(ntiles);
   ProfScope p(K_MLP_BWD, s);
   mlp_backward_kernel<KQ0, HQ, OQ, NL><<<blocks, MLP_BLOCK, mlp_lds_bytes<(KQ0 + 3) / 4, (HQ + 3) / 4, NL>(), s>>>(
-      d, dy, a1, a2, w1, w2, w3, dz1, dz2, dx);
+      d, dy, a1, a2, w1, w2, w3, dz1, dz2, dx, dx_add);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -508,17 +518,24 @@ int instag_mlp_forward(const float* x, const float* w1, const float* w2, const f
   return INSTAG_E_ARG;
 }
 
-int instag_mlp_backward(const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
-                        const float* w3, float* dz1, float* dz2, float* dx, int32_t N, int32_t K0, int32_t H,
-                        int32_t O, int32_t NL, instag_stream_t stream) {
+int instag_mlp_backward_add(const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
+                            const float* w3, float* dz1, float* dz2, float* dx, const float* dx_add, int32_t N,
+                            int32_t K0, int32_t H, int32_t O, int32_t NL, instag_stream_t stream) {
   if (int e = check_dims(N, K0, H, O, NL)) return e;
   INSTAG_REQUIRE(dy && a1 && w1 && w2 && dz1 && (NL == 2 || (w3 && a2 && dz2)), "mlp_backward: NULL tensor");
+  INSTAG_REQUIRE(dx_add == nullptr || dx != nullptr, "mlp_backward: dx_add needs dx");
   if (N == 0) return INSTAG_OK;
   const MlpDims d{N, K0, H, O};
   hipStream_t s = (hipStream_t)stream;
-  MLP_DISPATCH(run_bwd, d, dy, a1, a2, w1, w2, w3, dz1, dz2, dx, s);
+  MLP_DISPATCH(run_bwd, d, dy, a1, a2, w1, w2, w3, dz1, dz2, dx, dx_add, s);
   set_error("mlp_backward: unsupported shape");
   return INSTAG_E_ARG;
+}
+
+int instag_mlp_backward(const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
+                        const float* w3, float* dz1, float* dz2, float* dx, int32_t N, int32_t K0, int32_t H,
+                        int32_t O, int32_t NL, instag_stream_t stream) {
+  return instag_mlp_backward_add(dy, a1, a2, w1, w2, w3, dz1, dz2, dx, nullptr, N, K0, H, O, NL, stream);
 }
 
 size_t instag_linear_weight_grad_workspace_bytes(int32_t N, int32_t O, int32_t K) {

@@ -89,6 +89,81 @@ class _FusedMLP(torch.autograd.Function):
         return dx, dw1, dw2, dw3
 
 
+class _SharedInputMLPs(torch.autograd.Function):
+    """Two 2-layer MLPs over the SAME input x plus x itself as a third output (for the input's other consumers):
+    (MLP_a(x), MLP_b(x), x).  The reference runs aud_ch_att_net(enc_x), eye_att_net(enc_x) and then concatenates
+    enc_x into sigma_net's input (scene/motion_net.py:281-306), so autograd sums three gradients of enc_x with two
+    elementwise launches; here the sum happens inside the two backward kernels (instag_mlp_backward_add)."""
+
+    @staticmethod
+    def forward(ctx, x, wa1, wa2, wb1, wb2):
+        L = _lib.lib()
+        x = x.contiguous().float()
+        N, K0 = x.shape
+        outs, saved, dims = [], [x], []
+        for w1, w2 in ((wa1, wa2), (wb1, wb2)):
+            w1c, w2c = w1.contiguous().float(), w2.contiguous().float()
+            H, O = w1c.shape[0], w2c.shape[0]
+            y = torch.empty(N, O, dtype=torch.float32, device=x.device)
+            a1 = torch.empty(N, H, dtype=torch.float32, device=x.device)
+            check(L.instag_mlp_forward(ptr(x), ptr(w1c), ptr(w2c), None, ptr(y), ptr(a1), None, N, K0, H, O, 2,
+                                       _lib.current_stream()), "mlp_forward")
+            STATS["fwd_flops"] += 2 * N * (K0 * H + H * O)
+            outs.append(y)
+            saved += [w1c, w2c, a1]
+            dims.append((H, O))
+        ctx.save_for_backward(*saved)
+        ctx.weights = (wa1, wa2, wb1, wb2)
+        ctx.dims = (N, K0, dims)
+        return outs[0], outs[1], x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dya, dyb, dx_other):
+        from . import deferred
+        L = _lib.lib()
+        x = ctx.saved_tensors[0]
+        N, K0, dims = ctx.dims
+        dev = x.device
+        stream = _lib.current_stream()
+        want_dx = ctx.needs_input_grad[0]
+        dx = torch.empty(N, K0, dtype=torch.float32, device=dev) if want_dx else None
+        add = None if dx_other is None else dx_other.contiguous().float()
+        jobs = []
+        for k, dy in enumerate((dya, dyb)):
+            if dy is None:
+                continue
+            w1, w2, a1 = ctx.saved_tensors[1 + 3 * k:4 + 3 * k]
+            H, O = dims[k]
+            dy = dy.contiguous().float()
+            dz1 = torch.empty(N, H, dtype=torch.float32, device=dev)
+            check(L.instag_mlp_backward_add(ptr(dy), ptr(a1), None, ptr(w1), ptr(w2), None, ptr(dz1), None, ptr(dx),
+                                            ptr(add) if want_dx else None, N, K0, H, O, 2, stream), "mlp_backward")
+            STATS["bwd_flops"] += 2 * N * (H * O + (K0 * H if want_dx else 0))
+            if want_dx:
+                add = dx                      # the next kernel adds onto what is already there
+            jobs += [(dz1, x, 1 + 2 * k, (H, K0)), (dy, a1, 2 + 2 * k, (O, H))]
+        if want_dx and add is not dx:         # neither head carried a gradient
+            dx = torch.zeros(N, K0, dtype=torch.float32, device=dev) if dx_other is None else dx_other
+        jobs = [(dz, inp, idx, shp) for dz, inp, idx, shp in jobs if ctx.needs_input_grad[idx]]
+        grads = [None] * 4
+        if deferred.active() and all(w.is_leaf for w in ctx.weights):
+            for dz, inp, idx, shp in jobs:
+                deferred.defer_weight_grad(dz, inp, ctx.weights[idx - 1])
+        else:
+            for dz, inp, idx, shp in jobs:
+                dw = torch.empty(*shp, dtype=torch.float32, device=dev)
+                ws = torch.empty(L.instag_linear_weight_grad_workspace_bytes(N, shp[0], shp[1]), dtype=torch.uint8,
+                                 device=dev)
+                _weight_grad(L, dz, inp, dw, ws)
+                grads[idx - 1] = dw
+        return (dx, *grads)
+
+
+def shared_input_mlps(x, weights_a, weights_b):
+    """(MLP_a(x), MLP_b(x), x_for_other_consumers) for two 2-layer bias-free ReLU MLPs: see _SharedInputMLPs."""
+    return _SharedInputMLPs.apply(x, weights_a[0], weights_a[1], weights_b[0], weights_b[1])
+
+
 def fused_mlp(x, weights):
     """x [N, K0] on the GPU; weights = list of 2 or 3 torch.nn.Linear weights ([out, in])."""
     w3 = weights[2] if len(weights) == 3 else None

@@ -133,3 +133,36 @@ def test_deferred_batched_weight_grads_match_autograd():
     for wr, wg in zip(ref, got):
         for a, b in zip(wr, wg):
             assert torch.allclose(2 * a.grad, b.grad, rtol=1e-6, atol=0)
+
+
+def test_shared_input_mlps_match_separate_mlps():
+    """(MLP_a(x), MLP_b(x), x) with the three gradients of x summed inside the backward kernels == two fused_mlp calls
+    and autograd's own sum (scene/motion_net.py:281-306: both attention MLPs and sigma_net's input read enc_x)."""
+    from instag_amd.mlp import fused_mlp, shared_input_mlps
+    torch.manual_seed(3)
+    N = 5003
+    x0 = torch.randn(N, 36, device="cuda")
+    wa = [torch.randn(32, 36, device="cuda") * 0.3, torch.randn(32, 32, device="cuda") * 0.3]
+    wb = [torch.randn(16, 36, device="cuda") * 0.3, torch.randn(6, 16, device="cuda") * 0.3]
+    ga, gb, gx = torch.randn(N, 32, device="cuda"), torch.randn(N, 6, device="cuda"), torch.randn(N, 36, device="cuda")
+
+    def run(shared):
+        x = x0.clone().requires_grad_(True)
+        ws = [w.clone().requires_grad_(True) for w in wa + wb]
+        if shared:
+            ya, yb, xo = shared_input_mlps(x, ws[:2], ws[2:])
+        else:
+            ya, yb, xo = fused_mlp(x, ws[:2]), fused_mlp(x, ws[2:]), x
+        ((ya * ga).sum() + (yb * gb).sum() + (xo * gx).sum()).backward()
+        return [ya.detach(), yb.detach(), x.grad] + [w.grad for w in ws]
+
+    ref, got = run(False), run(True)
+    names = ["ya", "yb", "dx", "dwa1", "dwa2", "dwb1", "dwb2"]
+    for n_, r, g in zip(names, ref, got):
+        scale = float(r.abs().max())
+        assert float((r - g).abs().max()) <= 2e-5 * scale + 1e-6, (n_, float((r - g).abs().max()), scale)
+    # only some outputs used: the unused heads' gradients are zeros, the pass-through still arrives
+    x = x0.clone().requires_grad_(True)
+    ya, yb, xo = shared_input_mlps(x, wa, wb)
+    (xo * gx).sum().backward()
+    assert torch.equal(x.grad, gx)
