@@ -11,7 +11,7 @@ with open(f) as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
 rows.sort()
-ends = [i for i, r in enumerate(rows) if 'adam_step_kernel' in r[2]]
+ends = [i for i, r in enumerate(rows) if 'adam_step' in r[2]]
 steps = []
 for a, b in zip(ends[:-1], ends[1:]):
     sub = rows[a + 1:b + 1]

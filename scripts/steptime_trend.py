@@ -10,7 +10,7 @@ with open(f) as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:200]))
 rows.sort()
-ends = [i for i, r in enumerate(rows) if 'adam_step_kernel' in r[2]]
+ends = [i for i, r in enumerate(rows) if 'adam_step' in r[2]]
 names = ['blend_backward_kernel', 'blend_forward_kernel', 'mlp_forward_kernel', 'preprocess_kernel', 'adam_step_kernel']
 print('steps', len(ends))
 print('chunk  step_window_us  kernel_sum_us  ' + '  '.join(n[:14] for n in names))

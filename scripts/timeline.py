@@ -6,7 +6,7 @@ d = sys.argv[1]; step = int(sys.argv[2])
 f = (glob.glob(f'{d}/*/*_kernel_trace.csv') + glob.glob(f'{d}/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-ends = [i for i, r in enumerate(rows) if 'adam_step_kernel' in r['Kernel_Name']]      # one launch per step
+ends = [i for i, r in enumerate(rows) if 'adam_step' in r['Kernel_Name']]      # one launch per step
 a = ends[step - 1] + 1 if step > 0 else 0
 b = ends[step] + 1
 sub = rows[a:b]
