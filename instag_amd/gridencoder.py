@@ -190,6 +190,12 @@ class _tri_plane_encode(Function):
                                           ptr(dxyz), ptr(dt[0]), ptr(dt[1]), ptr(dt[2]), ptr(ws), ws_bytes,
                                           ptr(shift), 0 if shift is None else shift.shape[1], shift_scale, ptr(dshift),
                                           N, L, S, H, bound, T, _lib.current_stream()), "triplane_backward")
+        if shift is None:
+            # a field's encoder backward is the last kernel of that field: the weight gradients its MLPs queued
+            # (instag_amd/deferred.py) start on the side stream beside it instead of after it.  (Not for the field
+            # evaluated at a shifted position: another field's backward chain follows it, see render_motion.)
+            from . import deferred
+            deferred.flush_async(xyz.device)
         return (dxyz if ctx.needs_input_grad[0] else None), dt[0], dt[1], dt[2], None, None, None, None, dshift, None
 
 
