@@ -163,7 +163,7 @@ def main():
             log(f"step captured into a hipGraph (instance capacity {graph.capacity})")
         except Exception as exc:       # e.g. a collective library that cannot coexist with stream capture
             log(f"graph capture failed ({type(exc).__name__}: {exc}); running the same HIP operators eagerly")
-            trainer._graph = None
+            trainer._drop_graph()
             diff_gauss.set_capacity_plan(None)
             use_graph = False
     run(args.warmup)
@@ -198,7 +198,7 @@ def main():
         # Events cannot bracket kernels inside a replayed graph, so the per-kernel durations are measured
         # right after the timed region on the SAME trainer state: the same number of steps run eagerly with
         # HIP events around every kernel of the C ABI (the kernels and their inputs are the same).
-        trainer._graph = None
+        trainer._drop_graph()
         diff_gauss.set_capacity_plan(None)
         L.instag_prof_enable(-1)
         L.instag_prof_reset()

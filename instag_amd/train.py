@@ -194,6 +194,8 @@ class FaceTrainer:
         self._setup_optimizers()
         self.last = {}
         self._graph = None
+        self._graph_phase = None
+        self._graph_cache = {}
 
     # ---- optimizers: learning rates are device scalars on the GPU so a captured step can be replayed -------
     def _setup_optimizers(self):
@@ -377,11 +379,13 @@ class FaceTrainer:
         return True
 
     def _drop_graph(self):
-        if self._graph is not None:
+        """Forget every captured step (the parameter set changed, or the caller wants eager launches)."""
+        if self._graph is not None or getattr(self, "_graph_cache", None):
             from . import diff_gauss
             diff_gauss.set_capacity_plan(None)
         self._graph = None
         self._graph_phase = None
+        self._graph_cache = {}
 
     def step(self, frame: Frame):
         self.iteration += 1
@@ -389,10 +393,19 @@ class FaceTrainer:
         self._set_learning_rates(it)
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         phase = self.phase_of(it)
-        if self._graph is not None and (self._densify_due(it) or phase != getattr(self, "_graph_phase", phase)):
-            # the captured launches belong to another phase / another parameter set: run this step eagerly
-            # (enable_graph() captures the new phase when the caller asks for it again)
-            self._drop_graph()
+        cache = getattr(self, "_graph_cache", None) or {}
+        if self._densify_due(it):
+            self._drop_graph()              # the parameter set is about to change: every captured step is stale
+        elif cache or self._graph is not None:
+            # one captured step per phase (FacePhase): the schedule alternates between a few of them (the hair
+            # iterations toggle six times out of seven); a phase nobody captured runs eagerly
+            g = cache.get(phase)
+            if g is None and self._graph is not None and getattr(self, "_graph_phase", phase) == phase:
+                g = self._graph
+            if g is None and self._graph is not None:
+                from . import diff_gauss
+                diff_gauss.set_capacity_plan(None)
+            self._graph, self._graph_phase = g, (phase if g is not None else None)
         if self._graph is not None:
             self._graph.replay(frame)
             loss, Ll1 = self._graph.loss, self._graph.l1
@@ -408,15 +421,21 @@ class FaceTrainer:
 
     # ---- graph mode --------------------------------------------------------------------------------------------
     def enable_graph(self, example_frame: Frame, headroom: float = 1.4, warmup_steps: int = 3,
-                     split_for_allreduce: Optional[bool] = None):
+                     split_for_allreduce: Optional[bool] = None, phase: Optional[FacePhase] = None):
         """Capture the whole step into a hipGraph.  Runs `warmup_steps` eager steps plus two capacity-mode steps
         first (they advance the iteration counter like any other step) to measure the instance counts and warm
-        every library.  The graph holds the launches of the NEXT iteration's phase (FacePhase); step() falls back
-        to eager launches when the schedule moves to another phase or the parameter set changes."""
+        every library.  The graph holds the launches of one phase (FacePhase): `phase`, or the phase of the iteration
+        right after the capture.  Captured steps are kept per phase, so a schedule that alternates between phases
+        replays whichever was captured; step() launches eagerly in a phase nobody captured, and every captured step
+        is dropped when the parameter set changes (densify / prune / opacity reset)."""
+        if not hasattr(self, "_graph_cache"):
+            self._graph_cache = {}
         self._graph = None
-        phase = self.phase_of(self.iteration + max(1, warmup_steps) + 3)       # the iteration right after capture
+        if phase is None:
+            phase = self.phase_of(self.iteration + max(1, warmup_steps) + 3)   # the iteration right after capture
         self._graph = GraphedStep(self, example_frame, headroom, warmup_steps, split_for_allreduce, phase)
         self._graph_phase = phase
+        self._graph_cache[phase] = self._graph
         return self._graph
 
 

@@ -315,3 +315,48 @@ def test_stage_trainers_graph_matches_eager():
         assert torch.isfinite(out["loss"]) and (tr.g.num_points != n0 or True)
     finally:
         diff_gauss.set_capacity_plan(None)
+
+
+def test_face_schedule_replays_one_graph_per_phase():
+    """schedule="reference" around the hair iterations (six of seven iterations paint the hair to background,
+    train_face.py:340): one captured step per phase, step() replays whichever matches the iteration, and a replayed
+    step's loss == the eager loss of the same phase on the same state."""
+    from instag_amd import diff_gauss
+    from instag_amd.gaussian_model import GaussianModel
+    from instag_amd.motion_net import MotionNetwork, PersonalizedMotionNetwork
+    from instag_amd.scene_synth import synthetic_gaussians
+    from instag_amd.train import FacePhase, FaceTrainer, face_phase
+    dev = torch.device("cuda")
+    torch.manual_seed(11)
+    args = SimpleNamespace(audio_extractor="deepspeech", type="face")
+    g = GaussianModel(1, neural_motion_grid=PersonalizedMotionNetwork(args=args).to(dev))
+    g.load_raw(synthetic_gaussians(3000, sh_degree=1, seed=5), dev)
+    tr = FaceTrainer(g, MotionNetwork(args=args).to(dev), torch.tensor([0.0, 1.0, 0.0], device=dev), densify=False,
+                     schedule="reference")
+    frames = _frames(96, 3, dev)
+    tr.iteration = 3100
+    hair, plain = FacePhase(hair_mask_iter=True), FacePhase()
+    assert face_phase(3108) == plain and face_phase(3109) == hair          # 3108 = 7 * 444
+    try:
+        tr.enable_graph(frames[0], warmup_steps=1, phase=hair)             # iterations 3101..3103
+        tr.enable_graph(frames[0], warmup_steps=1, phase=plain)            # iterations 3104..3106
+        assert tr.iteration == 3106 and set(tr._graph_cache) == {hair, plain}
+        seen = set()
+        for it in range(3107, 3118):
+            frame = frames[it % 3]
+            phase = face_phase(it)
+            diff_gauss.set_capacity_plan(None)
+            _, want, _ = tr._forward_backward(frame, phase)                # eager loss of this phase on this state
+            want = float(want)
+            tr._zero_grad()
+            out = tr.step(frame)
+            assert tr.iteration == it and out["phase"] == phase
+            assert tr._graph is tr._graph_cache[phase], it                 # replayed, not launched eagerly
+            assert not tr._graph.check_overflow()
+            assert abs(float(out["loss"]) - want) <= 1e-5 * max(1.0, abs(want)), (it, float(out["loss"]), want)
+            seen.add(phase)
+        assert seen == {hair, plain}
+        tr._drop_graph()
+        assert tr._graph is None and not tr._graph_cache
+    finally:
+        diff_gauss.set_capacity_plan(None)
