@@ -373,6 +373,23 @@ int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* imag
                               instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Monocular geometry priors of the face branch (csrc/prior.hip); replaces train_face.py:458-504 with
+ * utils/loss_utils.py:17-20 (normalize):
+ *   loss = w_normal * mean_{(face|hair) ^ mouth} sum_c (1 - gt_normal[c] * normal[c])
+ *        + w_depth  * mean_{face ^ mouth} | normalize(depth) - normalize(gt_depth) |        (when use_depth)
+ * normal / gt_normal [3,H,W], depth / gt_depth [H,W], masks uint8 [H,W].  Workspaces (floats): stat 8H, parts 4H,
+ * rowb 2H; out[5] = [loss, S_depth, N_sel, S_normal, N_m].  backward: g_loss = device scalar. */
+int instag_geometry_prior_forward(const float* normal, const float* depth, const float* gt_normal,
+                                  const float* gt_depth, const uint8_t* face_mask, const uint8_t* hair_mask,
+                                  const uint8_t* mouth_mask, int32_t H, int32_t W, int32_t use_depth, float w_normal,
+                                  float w_depth, float* stat, float* parts, float* out, instag_stream_t stream);
+int instag_geometry_prior_backward(const float* g_loss, const float* depth, const float* gt_normal,
+                                   const float* gt_depth, const uint8_t* face_mask, const uint8_t* hair_mask,
+                                   const uint8_t* mouth_mask, int32_t H, int32_t W, int32_t use_depth, float w_normal,
+                                   float w_depth, const float* stat, const float* out, float* rowb, float* d_normal,
+                                   float* d_depth, instag_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Multi-tensor Adam / AdamW in one launch (csrc/adam.hip); replaces motion_optimizer.step() and
  * gaussians.optimizer.step() of train_face.py:781-788.  tensors: device array of 48-byte records
  * {float* p, const float* g (NULL = skip), float* m, float* v, int64 n, int32 group, int32 pad}; groups: device array

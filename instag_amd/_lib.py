@@ -104,6 +104,10 @@ _PROTOS = {
     "instag_face_loss_num_partials": (C.c_int64, [i32, i32]),
     "instag_face_loss_forward": (C.c_int, [vp] * 11 + [i32] + [vp] * 4),
     "instag_face_loss_backward": (C.c_int, [vp] * 16),
+    "instag_geometry_prior_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float,
+                                                vp, vp, vp, vp]),
+    "instag_geometry_prior_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float,
+                                                 vp, vp, vp, vp, vp, vp]),
     "instag_adam_chunk_elems": (C.c_int, []),
     "instag_adam_step": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp]),
     "instag_adam_grads_max": (C.c_int, []),

@@ -41,6 +41,7 @@ SOURCES = {
     "adam.hip": [],
     "audio.hip": [],
     "knn.hip": [],
+    "prior.hip": [],
 }
 
 

@@ -59,12 +59,67 @@ def normalize(input, mean=None, std=None):
     return (input - input_mean) / (input_std + 1e-2 * torch.std(input.reshape(-1)))
 
 
+class _GeometryPrior(torch.autograd.Function):
+    """geometry_prior_loss on the device: five launches instead of ~100 (csrc/prior.hip)."""
+
+    @staticmethod
+    def forward(ctx, normal, depth, gt_normal, gt_depth, face_mask, hair_mask, mouth_mask, use_depth, w_normal, w_depth):
+        from . import _lib
+        from ._lib import check, ptr
+        L = _lib.lib()
+        normal = normal.contiguous().float()
+        H, W = normal.shape[-2:]
+        dev = normal.device
+        d = depth.contiguous().float() if use_depth else None
+        gtn = gt_normal.contiguous().float()
+        gtd = gt_depth.contiguous().float() if use_depth else None
+        masks = [m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.contiguous().to(torch.uint8)
+                 for m in (face_mask, hair_mask, mouth_mask)]
+        ws = torch.empty(14 * H + 5, dtype=torch.float32, device=dev)      # stat 8H | parts 4H | rowb 2H | out 5
+        stat, parts, rowb, out = ws[:8 * H], ws[8 * H:12 * H], ws[12 * H:14 * H], ws[14 * H:]
+        check(L.instag_geometry_prior_forward(ptr(normal), ptr(d), ptr(gtn), ptr(gtd), ptr(masks[0]), ptr(masks[1]),
+                                              ptr(masks[2]), H, W, int(use_depth), float(w_normal), float(w_depth),
+                                              ptr(stat), ptr(parts), ptr(out), _lib.current_stream()),
+              "geometry_prior_forward")
+        ctx.save_for_backward(d, gtn, gtd, *masks, ws)
+        ctx.cfg = (H, W, bool(use_depth), float(w_normal), float(w_depth), tuple(depth.shape) if use_depth else None)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        from ._lib import check, ptr
+        L = _lib.lib()
+        d, gtn, gtd, face, hair, mouth, ws = ctx.saved_tensors
+        H, W, use_depth, w_normal, w_depth, dshape = ctx.cfg
+        stat, rowb, out = ws[:8 * H], ws[12 * H:14 * H], ws[14 * H:]
+        g = g.contiguous().float().reshape(1)
+        d_normal = torch.empty(3, H, W, dtype=torch.float32, device=gtn.device)
+        d_depth = torch.empty(dshape, dtype=torch.float32, device=gtn.device) if use_depth else None
+        check(L.instag_geometry_prior_backward(ptr(g), ptr(d), ptr(gtn), ptr(gtd), ptr(face), ptr(hair), ptr(mouth), H, W,
+                                               int(use_depth), w_normal, w_depth, ptr(stat), ptr(out), ptr(rowb),
+                                               ptr(d_normal), ptr(d_depth), _lib.current_stream()),
+              "geometry_prior_backward")
+        return d_normal, d_depth, None, None, None, None, None, None, None, None
+
+
 def geometry_prior_loss(normal, depth, gt_normal, gt_depth, face_mask, hair_mask, mouth_mask, use_depth=True,
                         w_normal=0.01, w_depth=1e-2):
     """Few-shot geometry priors of the face branch after warm_step + 2000 (train_face.py:458-504): the rendered
     normal against the monocular normal (1 - n_gt * n per channel, summed over channels, mean over head minus
     mouth) and, outside the 100 iterations after an opacity reset, the standardised rendered depth against the
-    standardised monocular depth (mean |.| over face minus mouth).  normal [3,H,W], depth [1,H,W] or [H,W]."""
+    standardised monocular depth (mean |.| over face minus mouth).  normal [3,H,W], depth [1,H,W] or [H,W].
+    Fused HIP kernels on the device (instag_geometry_prior_*), the torch formulation below otherwise."""
+    if normal.is_cuda and normal.dim() == 3 and normal.shape[0] == 3:
+        return _GeometryPrior.apply(normal, depth if use_depth else None, gt_normal, gt_depth if use_depth else None,
+                                    face_mask, hair_mask, mouth_mask, bool(use_depth), w_normal, w_depth)
+    return geometry_prior_loss_torch(normal, depth, gt_normal, gt_depth, face_mask, hair_mask, mouth_mask, use_depth,
+                                     w_normal, w_depth)
+
+
+def geometry_prior_loss_torch(normal, depth, gt_normal, gt_depth, face_mask, hair_mask, mouth_mask, use_depth=True,
+                              w_normal=0.01, w_depth=1e-2):
+    """Plain-torch statement of the same lines (host-side tests, parity reference of the fused kernels)."""
     head = face_mask | hair_mask
     m = (head ^ mouth_mask).to(normal.dtype)
     per_px = (1.0 - gt_normal * normal).sum(0)

@@ -65,7 +65,12 @@ def face_late(frame):
     pkg, _, _ = tr._forward_backward(frame, late)
     tr._stats_and_optimizers(pkg, False)
     tr._zero_grad()
-timed("face step, normal+depth priors", face_late)
+timed("face step, normal+depth priors, eager", face_late)
 def face_c3(frame):
     tr.step(frame)
-timed("face step, C3 phase (eager)", face_c3)
+timed("face step, C3 phase, eager", face_c3)
+tr.phase_of = lambda it: late                 # every iteration in the late phase (the schedule's iterations > 5000)
+tr.enable_graph(frames[0], phase=late)
+timed("face step, normal+depth priors, hipGraph", tr.step)
+print("   overflow:", tr._graph.check_overflow(), flush=True)
+tr._drop_graph()

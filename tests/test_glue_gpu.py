@@ -389,3 +389,40 @@ def test_multi_tensor_adam_state_dict_roundtrip():
             o.step()
     for p, q in zip(pa, pb):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("use_depth,size", [(True, (96, 80)), (False, (70, 53)), (True, (33, 517))])
+def test_geometry_prior_matches_torch(use_depth, size):
+    """Fused normal / depth prior (csrc/prior.hip) == the plain-torch statement of train_face.py:458-504 with
+    utils/loss_utils.py:17-20, value and gradients (fp64 reference)."""
+    from instag_amd.losses import geometry_prior_loss, geometry_prior_loss_torch
+    H, W = size
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    normal = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0)
+    depth = 0.8 + 0.1 * torch.rand(1, H, W, generator=g)
+    gt_normal = torch.nn.functional.normalize(torch.randn(3, H, W, generator=g), dim=0)
+    gt_depth = 0.5 + 0.3 * torch.rand(H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    face = ((yy - H / 2) ** 2 + (xx - W / 2) ** 2) < (0.35 * min(H, W)) ** 2
+    hair = (yy < 0.3 * H) & ~face
+    mouth = ((yy - 0.65 * H) ** 2 + (xx - W / 2) ** 2) < (0.08 * min(H, W)) ** 2
+
+    n64 = normal.double().requires_grad_(True)
+    d64 = depth.double().requires_grad_(True)
+    want = geometry_prior_loss_torch(n64, d64, gt_normal.double(), gt_depth.double(), face, hair, mouth, use_depth)
+    (want * 3.0).backward()
+
+    nd = normal.cuda().requires_grad_(True)
+    dd = depth.cuda().requires_grad_(True)
+    got = geometry_prior_loss(nd, dd, gt_normal.cuda(), gt_depth.cuda(), face.cuda(), hair.cuda(), mouth.cuda(),
+                              use_depth)
+    (got * 3.0).backward()
+    assert abs(float(got) - float(want)) <= 2e-5 * max(1.0, abs(float(want))), (float(got), float(want))
+    n_scale = float(n64.grad.abs().max())
+    assert float((nd.grad.cpu().double() - n64.grad).abs().max()) <= 1e-4 * n_scale
+    if use_depth:
+        scale = float(d64.grad.abs().max())
+        err = float((dd.grad.cpu().double() - d64.grad).abs().max())
+        assert err <= 2e-3 * scale, (err, scale)
+    else:
+        assert dd.grad is None
