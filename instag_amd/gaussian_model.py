@@ -170,6 +170,23 @@ class GaussianModel:
         return self._p["f_dc"], self._p["f_rest"]
 
     @property
+    def get_identity(self):
+        return self._identity
+
+    def get_covariance(self, scaling_modifier=1):
+        """Upper triangle (xx, xy, xz, yy, yz, zz) of R S S^T R^T per Gaussian (scene/gaussian_model.py:33-41, 196-197;
+        utils/general_utils.py:71-117), from the activated scales and the raw (un-normalised) rotation."""
+        R = quat_to_rotmat(self._rotation)
+        L = R * (scaling_modifier * self.get_scaling).unsqueeze(1)          # R @ diag(s)
+        cov = L @ L.transpose(1, 2)
+        return torch.stack((cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]), dim=1)
+
+    def oneupSHdegree(self):
+        """scene/gaussian_model.py:201-203."""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    @property
     def num_points(self):
         return self._p["xyz"].shape[0]
 

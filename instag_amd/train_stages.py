@@ -303,7 +303,7 @@ class MouthTrainer:
         it = self.iteration
         self._set_learning_rates(it)
         if it % 1000 == 0:
-            self.g.active_sh_degree = min(self.g.active_sh_degree + 1, self.g.max_sh_degree)      # oneupSHdegree, :111
+            self.g.oneupSHdegree()                                                                # train_mouth.py:110-111
         phase = mouth_phase(it, self.opt, self.warm_step, self.bg_iter)
         if phase.late:
             self._freeze_late()

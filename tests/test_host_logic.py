@@ -285,3 +285,26 @@ def test_dp_densification_stats_are_exchanged_when_read_gloo_world2():
     assert torch.equal(r0["acc"], torch.full((64, 1), 3.0)) and torch.equal(r0["den"], torch.full((64, 1), 4.0))
     want = torch.max(torch.arange(64, dtype=torch.float32), 5.0 - torch.arange(64, dtype=torch.float32))
     assert torch.equal(r0["rad"], want)
+
+
+def test_gaussian_model_small_api_surface():
+    """get_identity / get_covariance / oneupSHdegree (scene/gaussian_model.py:189-203): the covariance is
+    R S S^T R^T (fp64 check), the SH degree saturates at max_sh_degree."""
+    g = _model(50)
+    assert g.get_identity.shape == (50, 1)
+    cov = g.get_covariance(scaling_modifier=1.5)
+    q = torch.nn.functional.normalize(g._rotation.detach().double())
+    r, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).view(-1, 3, 3)
+    S = torch.diag_embed(1.5 * g.get_scaling.detach().double())
+    full = R @ S @ S @ R.transpose(1, 2)
+    want = torch.stack((full[:, 0, 0], full[:, 0, 1], full[:, 0, 2], full[:, 1, 1], full[:, 1, 2], full[:, 2, 2]), 1)
+    assert float((cov.double() - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    g.active_sh_degree = 0
+    g.oneupSHdegree()
+    assert g.active_sh_degree == min(1, g.max_sh_degree)
+    for _ in range(5):
+        g.oneupSHdegree()
+    assert g.active_sh_degree == g.max_sh_degree
