@@ -148,6 +148,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BB = 16;          // Gaussians per backward batch (one MFMA row block): 40 KB of LDS per workgroup, so that
                                 // three to four workgroups fit a CU and one's MFMA phase overlaps another's VALU phase
+constexpr int SB = 32;          // records staged per round (two batches)
 constexpr int WROW = 68;        // floats per (pixel-quarter, Gaussian) row of the w / t matrices (64 + 4 pad)
 
 template <bool FULL>            // FULL: depth / normal / extra channels carry gradient too; else rgb only
@@ -158,11 +159,13 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dnormal,
                       const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
                       float* __restrict__ inst_grad, const float* __restrict__ color_override /*[N,3] or null*/) {
-  __shared__ float4 s_rec[BB][4];
+  // 40 KB in all (four workgroups per CU).  Records are staged 32 at a time -- two batches -- so that their two
+  // dependent global loads are issued a full two batches (~3 us) before they are needed
+  __shared__ float4 s_rec[SB][4];
   __shared__ __align__(16) float s_W[4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
   __shared__ __align__(16) float s_T[4 * BB * WROW];
   __shared__ float s_res[BB][2][2][16];               // [gaussian][matrix][pixel half][feature]
-  __shared__ int s_max[4];
+  int* s_max = reinterpret_cast<int*>(&s_res[0][0][0][0]);   // (used once, before the first batch)
   const int tile = blockIdx.x;
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
   const int tid = threadIdx.x;
@@ -243,47 +246,40 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   const float tf_tail = T_final * tail;
 
   const float tile_x0 = (float)(tx * TILE_X), tile_y0 = (float)(ty * TILE_Y);
-  const int rounds = (n + BB - 1) / BB;
-  // the records of batch i+1 are fetched (two dependent global loads) while batch i is being processed
+  const int rounds = (n + SB - 1) / SB;
+  // the records of round i+1 are fetched (two dependent global loads) while round i is being processed
   float4 nrec0 = make_float4(0.f, 0.f, 0.f, 0.f), nrec1 = nrec0, nrec2 = nrec0, nrec3 = nrec0;
-  if (tid < min(BB, n)) {
-    const uint32_t gid = point_list[start + (n - 1) - tid];
+  auto fetch = [&](int pos) {
+    const uint32_t gid = point_list[start + pos];
     const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
     nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
-    nrec3.z = __uint_as_float(slot_list[start + (n - 1) - tid]);   // the instance's gradient row
+    nrec3.z = __uint_as_float(slot_list[start + pos]);   // the instance's gradient row
     if (color_override) {
       nrec1.z = color_override[3 * (size_t)gid]; nrec1.w = color_override[3 * (size_t)gid + 1];
       nrec2.x = color_override[3 * (size_t)gid + 2];
     }
-  }
-  for (int i = 0; i < rounds; ++i) {
-    __syncthreads();                          // previous batch fully consumed (s_rec, s_W/s_T, s_res, s_F)
-    const int base = n - 1 - i * BB;          // list index of batch element 0 (walks backwards)
-    const int cnt = min(BB, n - i * BB);
-    if (tid < cnt) {
+  };
+  if (tid < min(SB, n)) fetch((n - 1) - tid);
+  for (int si = 0; si < rounds; ++si) {
+    __syncthreads();                          // previous round fully consumed (s_rec, s_W/s_T, s_res, s_F)
+    const int sbase = n - 1 - si * SB;        // list index of round element 0 (walks backwards)
+    const int scnt = min(SB, n - si * SB);
+    if (tid < scnt) {
       s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
     }
     __syncthreads();
-    {
-      const int nbase = base - BB;
-      if (tid < min(BB, nbase + 1)) {
-        const uint32_t gid = point_list[start + nbase - tid];
-        const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
-        nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
-        nrec3.z = __uint_as_float(slot_list[start + nbase - tid]);
-        if (color_override) {
-          nrec1.z = color_override[3 * (size_t)gid]; nrec1.w = color_override[3 * (size_t)gid + 1];
-          nrec2.x = color_override[3 * (size_t)gid + 2];
-        }
-      }
-    }
+    if (tid < min(SB, sbase - SB + 1)) fetch(sbase - SB - tid);
+   for (int off = 0; off < scnt; off += BB) {
+    const int base = sbase - off;             // list index of batch element 0
+    const int cnt = min(BB, scnt - off);
+    const float4 (*rec)[4] = s_rec + off;
     // ---- phase A: advance the per-pixel recurrence, emit w and t (branch-free, unrolled) ------------------
 #pragma unroll 4
     for (int j = 0; j < cnt; ++j) {
       const int idx = base - j;
-      const float4 a = s_rec[j][0];   // x y conA conB
-      const float4 b = s_rec[j][1];   // conC op r g
-      const float4 cc = s_rec[j][2];  // b depth nx ny
+      const float4 a = rec[j][0];   // x y conA conB
+      const float4 b = rec[j][1];   // conC op r g
+      const float4 cc = rec[j][2];  // b depth nx ny
       const float dx = a.x - pxf, dy = a.y - pyf;
       const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
       const float G = __expf(power);
@@ -291,7 +287,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       const bool valid = (idx < last_contributor) && !(power > 0.0f) && !(alpha < ALPHA_MIN);
       float cd = b.z * dpix[0] + b.w * dpix[1] + cc.x * dpix[2];
       if (FULL) {
-        const float4 dd = s_rec[j][3];  // nz extra . .
+        const float4 dd = rec[j][3];  // nz extra . .
         cd += cc.y * dpix[3] + cc.z * dpix[4] + cc.w * dpix[5] + dd.x * dpix[6] + dd.y * dpix[7];
       }
       const float alpha_e = valid ? alpha : 0.f;
@@ -323,7 +319,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     __syncthreads();
     // ---- one 64-byte gradient row per (tile, Gaussian) instance -------------------------------------------------
     if (tid < cnt) {
-      const float4 ra = s_rec[tid][0], rb = s_rec[tid][1];
+      const float4 ra = rec[tid][0], rb = rec[tid][1];
       float Dw[NCH], Dt[6];
 #pragma unroll
       for (int k = 0; k < NCH; ++k) Dw[k] = s_res[tid][0][0][k] + s_res[tid][0][1][k];
@@ -341,10 +337,11 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       r4[1] = make_float4(-0.5f * op * tdyy, S0, Dw[0], Dw[1]);
       r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);
       r4[3] = make_float4(Dw[6], Dw[7], 0.f, 0.f);
-      const uint32_t slot = __float_as_uint(s_rec[tid][3].z);
+      const uint32_t slot = __float_as_uint(rec[tid][3].z);
       float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)slot * REC_FLOATS);
       dst[0] = r4[0]; dst[1] = r4[1]; dst[2] = r4[2]; dst[3] = r4[3];
     }
+   }
   }
 }
 
