@@ -248,6 +248,12 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
 // the published (tile<<32 | depth) key is implied by the emission order + a stable sort).  The sorted value
 // is the instance's own unsorted slot u (also the row of its gradient in blend-backward); gid_unsorted[u] maps
 // the slot back to the Gaussian.  The exclusive instance offset is recorded in the blend record.
+// SIXTEEN lanes per Gaussian: lane q tests tile q, q+16, ... of the Gaussian's rectangle (row-major, the emission
+// order), the kept ones are compacted with a ballot.  (One thread per Gaussian walked ~16 rectangle tiles with four
+// divisions each in series, on 1.5 waves per SIMD.)
+constexpr int DUP_LANES = 16;
+constexpr int DUP_PER_BLOCK = 256 / DUP_LANES;
+
 __global__ void __launch_bounds__(256)
 duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ order,
                  const uint32_t* __restrict__ point_offsets,
@@ -255,8 +261,8 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ gid_unsorted,
                  uint32_t capacity, uint32_t pad_to, int32_t* __restrict__ ranges, uint32_t nranges, int packed,
                  int32_t* __restrict__ status) {
-  const int i = blockIdx.x * 256 + threadIdx.x;      // rank in depth order
-  if (status != nullptr && i == 0) {
+  const uint32_t gtid = blockIdx.x * 256u + threadIdx.x;
+  if (status != nullptr && gtid == 0) {
     // capacity mode: publish the instance count and the overflow flag without a host round trip
     const uint32_t R = point_offsets[N - 1];
     status[0] = (int32_t)R;
@@ -267,34 +273,49 @@ duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* _
   {
     const uint32_t total = gridDim.x * 256u;
     const uint32_t used = min(point_offsets[N - 1], capacity);
-    for (uint32_t k = used + (uint32_t)i; k < pad_to; k += total) keys[k] = 0xFFFFFFFFu;
-    for (uint32_t k = (uint32_t)i; k < nranges; k += total) ranges[k] = 0;
+    for (uint32_t k = used + gtid; k < pad_to; k += total) keys[k] = 0xFFFFFFFFu;
+    for (uint32_t k = gtid; k < nranges; k += total) ranges[k] = 0;
   }
-  if (i >= N) return;
-  const uint32_t tt = point_offsets[i] - (i > 0 ? point_offsets[i - 1] : 0u);   // kept tiles of this Gaussian
-  if (tt == 0) return;
-  if (point_offsets[i] > capacity) return;   // capacity mode: instances beyond the buffer are dropped (flagged)
-  const uint32_t g = order[i];
-  uint32_t off = point_offsets[i] - tt;
-  float* rec = rec2d + (size_t)g * REC_FLOATS;
-  const uint32_t rect = __float_as_uint(rec[R_RECT]);
-  rec[R_OFFSET] = __uint_as_float(off);
-  const int rminx = (int)(rect & 1023u), rminy = (int)((rect >> 10) & 1023u), rw = (int)(rect >> 20);
-  const int rh = (int)(flags[g] >> 16);
-  const float px = rec[R_X], py = rec[R_Y], A = rec[R_CA], B = rec[R_CB], C = rec[R_CC], thr = cull_thr[g];
-  for (int y = rminy; y < rminy + rh; ++y) {
-    for (int x = rminx; x < rminx + rw; ++x) {
-      if (!tile_kept(px, py, A, B, C, thr, x, y)) continue;
+  const int i = blockIdx.x * DUP_PER_BLOCK + (threadIdx.x / DUP_LANES);      // rank in depth order
+  const int q = threadIdx.x % DUP_LANES;
+  const int grp_shift = ((threadIdx.x & 63) / DUP_LANES) * DUP_LANES;        // position of the group's bits in a ballot
+  uint32_t tt = 0, off = 0, g = 0;
+  bool work = i < N;
+  if (work) {
+    tt = point_offsets[i] - (i > 0 ? point_offsets[i - 1] : 0u);            // kept tiles of this Gaussian
+    // capacity mode: instances beyond the buffer are dropped (flagged)
+    work = tt != 0 && point_offsets[i] <= capacity;
+  }
+  int rminx = 0, rminy = 0, rw = 1, ntiles = 0;
+  float px = 0.f, py = 0.f, A = 0.f, B = 0.f, C = 0.f, thr = -1.f;
+  if (work) {
+    g = order[i];
+    off = point_offsets[i] - tt;
+    float* rec = rec2d + (size_t)g * REC_FLOATS;
+    const uint32_t rect = __float_as_uint(rec[R_RECT]);
+    if (q == 0) rec[R_OFFSET] = __uint_as_float(off);
+    rminx = (int)(rect & 1023u); rminy = (int)((rect >> 10) & 1023u); rw = (int)(rect >> 20);
+    ntiles = rw * (int)(flags[g] >> 16);
+    px = rec[R_X]; py = rec[R_Y]; A = rec[R_CA]; B = rec[R_CB]; C = rec[R_CC]; thr = cull_thr[g];
+  }
+  // (all 16 lanes of a group share `ntiles`; groups of one wave may differ: a finished group's ballot bits are 0)
+  for (int t0 = 0; t0 < ntiles; t0 += DUP_LANES) {
+    const int t = t0 + q;
+    const int y = rminy + t / rw, x = rminx + t % rw;
+    const bool kept = t < ntiles && tile_kept(px, py, A, B, C, thr, x, y);
+    const uint32_t bits = (uint32_t)(__builtin_amdgcn_ballot_w64(kept) >> grp_shift) & ((1u << DUP_LANES) - 1u);
+    if (kept) {
+      const uint32_t o = off + (uint32_t)__builtin_popcount(bits & ((1u << q) - 1u));
       const uint32_t tile = (uint32_t)(y * grid_x + x);
       if (packed) {
-        keys[off] = (tile << PACK_SHIFT) | off;          // key-only sort: the slot rides in the low bits
+        keys[o] = (tile << PACK_SHIFT) | o;              // key-only sort: the slot rides in the low bits
       } else {
-        keys[off] = tile;
-        vals[off] = off;
+        keys[o] = tile;
+        vals[o] = o;
       }
-      gid_unsorted[off] = g;
-      ++off;
+      gid_unsorted[o] = g;
     }
+    off += (uint32_t)__builtin_popcount(bits);
   }
 }
 
@@ -373,7 +394,7 @@ int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order,
                      bool packed, int32_t* status, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_DUPLICATE, s);
-  duplicate_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c.N, c.grid_x, rec2d, order, point_offsets, flags,
+  duplicate_kernel<<<div_up(c.N, DUP_PER_BLOCK), 256, 0, s>>>(c.N, c.grid_x, rec2d, order, point_offsets, flags,
                                                      cull_thr, keys, vals, gid_unsorted, capacity, pad ? capacity : 0u,
                                                      ranges, (uint32_t)(2 * c.grid_x * c.grid_y), packed ? 1 : 0, status);
   INSTAG_CHECK_LAUNCH();
