@@ -203,6 +203,13 @@ int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* 
                                float* final_T /*[H*W]*/, float* rec2d /*[N,16]*/,
                                instag_stream_t stream);
 
+/* Per-Gaussian flag word of the forward state (device copy on `stream`): bits 0-2 SH clamp, 3-4 normal axis, 5 normal
+ * sign, 6-7 cov2D clamp, bits 16-31 = HEIGHT of the Gaussian's tile rectangle.  Together with rec2d[15] (min x |
+ * min y << 10 | width << 20) this is the bounding rectangle of the published binning, compared bit for bit with the
+ * oracle's cull="rect" mode.  Only entries of Gaussians with radii > 0 are defined. */
+int instag_raster_debug_export_flags(const void* geom, size_t geom_bytes, int32_t N, uint32_t* flags /*[N]*/,
+                                     instag_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bias-free ReLU MLP over N rows on the f32 matrix cores (exact fp32).
  * Replaces the per-Gaussian `MLP` modules of scene/motion_net.py:152-173 (sigma_net, aud_ch_att_net,

@@ -220,7 +220,7 @@ using namespace instag;
 extern "C" {
 
 const char* instag_last_error(void) { return g_err.c_str(); }
-int instag_abi_version(void) { return 3; }
+int instag_abi_version(void) { return 4; }
 
 size_t instag_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t instag_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
@@ -440,6 +440,17 @@ int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* 
     INSTAG_CHECK_HIP(cp(n_contrib, ib + IL.n_contrib, P * 4));
     INSTAG_CHECK_HIP(cp(final_T, ib + IL.final_T, P * 4));
   }
+  return INSTAG_OK;
+}
+
+int instag_raster_debug_export_flags(const void* geom, size_t geom_bytes, int32_t N, uint32_t* flags,
+                                     instag_stream_t stream_) {
+  const GeomLayout GL = geom_layout(N);
+  INSTAG_REQUIRE(geom != nullptr && flags != nullptr, "debug_export_flags: NULL pointer");
+  if (geom_bytes < GL.total) { set_error("geom buffer too small"); return INSTAG_E_SPACE; }
+  if (N > 0)
+    INSTAG_CHECK_HIP(hipMemcpyAsync(flags, (const char*)geom + GL.flags, (size_t)N * 4, hipMemcpyDeviceToDevice,
+                                    (hipStream_t)stream_));
   return INSTAG_OK;
 }
 

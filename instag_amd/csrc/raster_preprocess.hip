@@ -44,6 +44,24 @@ __device__ __forceinline__ bool tile_kept(float px, float py, float A, float B, 
   return fminf(fminf(e1, e2), fminf(e3, e4)) <= thr;
 }
 
+// ln(x), x > 0, from IEEE + - * / only (this TU is compiled with -ffp-contract=off): the CPU oracle evaluates the same
+// expression tree (oracle/rasterize_ref.py::_det_ln), so the culling threshold -- and with it the kept set -- is
+// bit-identical on any host, whatever its libm's log() rounds to.  x = m 2^e with m in [sqrt(1/2), sqrt(2)),
+// ln m = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716: fourteen terms of the odd series reach 1e-17.
+__device__ __forceinline__ double det_ln(double x) {
+  int e;
+  double m = frexp(x, &e);
+  if (m < 0.7071067811865476) { m = m * 2.0; e -= 1; }
+  const double s = (m - 1.0) / (m + 1.0);
+  const double t = s * s;
+  double p = 1.0 / 27.0;
+  p = p * t + 1.0 / 25.0; p = p * t + 1.0 / 23.0; p = p * t + 1.0 / 21.0; p = p * t + 1.0 / 19.0;
+  p = p * t + 1.0 / 17.0; p = p * t + 1.0 / 15.0; p = p * t + 1.0 / 13.0; p = p * t + 1.0 / 11.0;
+  p = p * t + 1.0 / 9.0;  p = p * t + 1.0 / 7.0;  p = p * t + 1.0 / 5.0;  p = p * t + 1.0 / 3.0;
+  p = p * t + 1.0;
+  return (double)e * 0.6931471805599453 + (2.0 * s) * p;
+}
+
 struct PreIn {
   const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *extra, *shs_rest;
 };
@@ -222,7 +240,7 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
 
   // instances = tiles of the rectangle that the alpha >= 1/255 ellipse can reach
   const float op = in.opac[g];
-  const float thr = (float)(2.0 * log(255.0 * (double)op) * 1.001 + 0.001);
+  const float thr = (float)((2.0 * det_ln(255.0 * (double)op)) * 1.001 + 0.001);
   int kept = 0;
   if (thr >= 0.0f) {
     for (int ty_ = rminy; ty_ < rmaxy; ++ty_)

@@ -385,6 +385,12 @@ def debug_export(st: _State):
                                        ptr(out["point_list"]), ptr(out["ranges"]), ptr(out["n_contrib"]),
                                        ptr(out["final_T"]), ptr(out["rec2d"]), _lib.current_stream()),
           "debug_export")
+    flags = torch.zeros(N, dtype=torch.int32, device=dev)
+    check(L.instag_raster_debug_export_flags(ptr(st.geom), st.geom.numel(), N, ptr(flags), _lib.current_stream()),
+          "debug_export_flags")
+    rect = out["rec2d"][:, 15].contiguous().view(torch.int32)
+    # bounding tile rectangle (min x, min y, width, height) of the published binning; defined where radii > 0
+    out["rect"] = torch.stack([rect & 1023, (rect >> 10) & 1023, (rect >> 20) & 4095, (flags >> 16) & 0xFFFF], dim=1)
     out["R"] = R
     out["radii"] = st.radii
     return out

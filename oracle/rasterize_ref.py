@@ -282,6 +282,23 @@ def preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotatio
     )
 
 
+def _det_ln(x: np.ndarray) -> np.ndarray:
+    """ln(x) in fp64 from + - * / only, same expression tree as csrc/raster_preprocess.hip::det_ln, so that the
+    culling threshold does not depend on any libm (numpy never contracts a*b+c into an FMA)."""
+    x = np.asarray(x, dtype=np.float64)
+    m, e = np.frexp(x)
+    lo = m < 0.7071067811865476
+    m = np.where(lo, m * 2.0, m)
+    e = np.where(lo, e - 1, e)
+    s = (m - 1.0) / (m + 1.0)
+    t = s * s
+    p = np.full_like(t, 1.0 / 27.0)
+    for k in (25.0, 23.0, 21.0, 19.0, 17.0, 15.0, 13.0, 11.0, 9.0, 7.0, 5.0, 3.0):
+        p = p * t + 1.0 / k
+    p = p * t + 1.0
+    return e.astype(np.float64) * 0.6931471805599453 + (2.0 * s) * p
+
+
 def tile_keep_mask(px, py, A, B, C, thr, tx, ty):
     """Exact tile culling (numpy fp32, same operation order as csrc/raster_preprocess.hip::tile_kept).
 
@@ -308,9 +325,18 @@ def tile_keep_mask(px, py, A, B, C, thr, tx, ty):
     return (thr >= 0) & (inside | (qmin <= thr))
 
 
-def bin_and_sort(pre: dict):
-    """Emit one instance per KEPT tile of each visible Gaussian's rectangle (row-major inside the rectangle),
-    stable-sort by (tile<<32 | depth bits)."""
+def bin_and_sort(pre: dict, cull: str = "exact"):
+    """Emit one instance per tile of each visible Gaussian's rectangle (row-major inside the rectangle),
+    stable-sort by (tile<<32 | depth bits).
+
+    cull="rect"  : the PUBLISHED binning -- every tile of the bounding rectangle gets an instance
+                   (duplicateWithKeys of the published rasterizer; the contract the reference's call
+                   sites gaussian_renderer/__init__.py:111-121 rely on).
+    cull="exact" : only the tiles the alpha >= 1/255 ellipse can reach (tile_keep_mask) -- what the HIP
+                   kernels emit.  Dropped instances never pass the blend loop's own alpha test, so
+                   images, final_T and gradients are those of cull="rect"
+                   (tests/test_oracle_golden.py::test_exact_tile_culling_changes_nothing)."""
+    assert cull in ("exact", "rect")
     grid_x, grid_y = pre["grid"]
     depth, rect = pre["depth"], pre["rect"]
     area = pre["tiles_touched"].numpy().astype(np.int64)            # rectangle area of visible Gaussians
@@ -326,10 +352,13 @@ def bin_and_sort(pre: dict):
     con = pre["conic"].detach().numpy().astype(np.float32)
     op64 = pre["opacity"].detach().numpy().astype(np.float64)
     with np.errstate(all="ignore"):
-        thr = (2.0 * np.log(255.0 * op64) * 1.001 + 0.001).astype(np.float32)
+        thr = ((2.0 * _det_ln(255.0 * op64)) * 1.001 + 0.001).astype(np.float32)
     thr = np.where(np.isfinite(thr), thr, np.float32(-1.0))
-    keep = tile_keep_mask(xy[cand_g, 0], xy[cand_g, 1], con[cand_g, 0], con[cand_g, 1], con[cand_g, 2],
-                          thr[cand_g], txx, ty)
+    if cull == "rect":
+        keep = np.ones(len(cand_g), dtype=bool)
+    else:
+        keep = tile_keep_mask(xy[cand_g, 0], xy[cand_g, 1], con[cand_g, 0], con[cand_g, 1], con[cand_g, 2],
+                              thr[cand_g], txx, ty)
     gids = cand_g[keep]
     tt = np.bincount(gids, minlength=n).astype(np.int64)           # instances per Gaussian after culling
     offsets = np.cumsum(tt)                                         # inclusive scan, like the device scan
@@ -347,19 +376,24 @@ def bin_and_sort(pre: dict):
     ranges = np.stack([starts_t, ends_t], axis=1).astype(np.int32)
     ranges[starts_t == ends_t] = 0                 # tiles with no instance keep the zero-filled range
     return dict(R=R, offsets=offsets.astype(np.int64), keys_unsorted=keys, keys=keys_sorted,
-                point_list=point_list, ranges=ranges, tiles_touched=tt, candidates=int(len(cand_g)))
+                point_list=point_list, ranges=ranges, tiles_touched=tt, candidates=int(len(cand_g)),
+                cand_gid=cand_g, cand_tile=(ty * grid_x + txx), cand_keep=keep)
 
 
 ALPHA_MIN = float(F32(1.0) / F32(255.0))
 T_MIN = _f(0.0001)
 
 
-def blend(pre: dict, binning: dict, s: RasterSettings, chunk: int = 512):
+def blend(pre: dict, binning: dict, s: RasterSettings, chunk: int = 512, decide: Optional[dict] = None):
     """Front-to-back compositing, vectorised over the 256 pixels of each tile.
 
     The tile's depth-sorted list is consumed in chunks; a tile stops as soon as every pixel has
     terminated (T(1-alpha) < 1e-4), exactly like the per-batch early exit of the kernels.  Within and
-    across chunks T is the plain sequential product T <- T*(1-alpha) (cumprod seeded with the carry)."""
+    across chunks T is the plain sequential product T <- T*(1-alpha) (cumprod seeded with the carry).
+
+    ``decide`` (fp64 mode): the fp32 per-Gaussian record.  The loop's three discrete decisions -- skip power > 0,
+    skip alpha < 1/255, stop at T(1-alpha) < 1e-4 -- are then taken from an fp32 shadow of the recurrence (they are part
+    of the specification), the values they gate are computed from ``pre`` in its own precision."""
     H, W = int(s.image_height), int(s.image_width)
     grid_x, grid_y = pre["grid"]
     E = pre["extra"].shape[1]
@@ -371,6 +405,25 @@ def blend(pre: dict, binning: dict, s: RasterSettings, chunk: int = 512):
     n_contrib = torch.zeros(H, W, dtype=torch.int32)
     point_list = torch.from_numpy(binning["point_list"].astype(np.int64))
     ranges = binning["ranges"]
+    shadow = decide is not None
+    if shadow:
+        d_xy, d_con, d_op = decide["xy"].detach(), decide["conic"].detach(), decide["opacity"].detach()
+        ddt = d_xy.dtype
+
+    def masks(xy, con, op, pxf, pyf, T_cur, alive):
+        """-> power, alpha (straight-through clamp), contrib, keep, T_excl, T_incl for one chunk."""
+        dx = xy[:, 0:1] - pxf[None, :]
+        dy = xy[:, 1:2] - pyf[None, :]
+        power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
+        G = torch.exp(power)
+        raw = op[:, None] * G
+        alpha = raw - (raw - raw.clamp_max(_f(0.99))).detach()      # straight-through min(.99, .)
+        contrib = (power.detach() <= 0) & (alpha.detach() >= ALPHA_MIN)
+        a_eff = torch.where(contrib, alpha, torch.zeros_like(alpha))
+        T_all = torch.cumprod(torch.cat([T_cur[None, :], 1.0 - a_eff], dim=0), dim=0)
+        keep = alive[None, :] & (T_all[1:].detach() >= T_MIN)   # prefix mask per pixel
+        return alpha, contrib, keep
+
     pieces = []
     for t in range(grid_x * grid_y):
         a, b = int(ranges[t, 0]), int(ranges[t, 1])
@@ -387,23 +440,21 @@ def blend(pre: dict, binning: dict, s: RasterSettings, chunk: int = 512):
         alive = torch.ones(npix, dtype=torch.bool)
         acc = torch.zeros(npix, CH, dtype=dtype)
         nc = torch.zeros(npix, dtype=torch.int32)
+        if shadow:
+            T_sh = torch.ones(npix, dtype=ddt)
         for c0 in range(a, b, chunk):
             ids = point_list[c0:min(b, c0 + chunk)]
-            xy = pre["xy"][ids]
-            con = pre["conic"][ids]
-            op = pre["opacity"][ids]
-            dx = xy[:, 0:1] - pxf[None, :]
-            dy = xy[:, 1:2] - pyf[None, :]
-            power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
-            G = torch.exp(power)
-            raw = op[:, None] * G
-            alpha = raw - (raw - raw.clamp_max(_f(0.99))).detach()      # straight-through min(.99, .)
-            contrib = (power.detach() <= 0) & (alpha.detach() >= ALPHA_MIN)
+            alpha, contrib, keep = masks(pre["xy"][ids], pre["conic"][ids], pre["opacity"][ids], pxf, pyf, T_cur, alive)
+            if shadow:
+                with torch.no_grad():
+                    al_s, contrib, keep = masks(d_xy[ids], d_con[ids], d_op[ids], pxf.to(ddt), pyf.to(ddt), T_sh, alive)
+                    T_s = torch.cumprod(torch.cat([T_sh[None, :], 1.0 - torch.where(contrib, al_s, torch.zeros_like(al_s))],
+                                                  dim=0), dim=0)[1:]
+                    nk = keep.sum(0)
+                    T_sh = torch.where(nk > 0, T_s.gather(0, (nk - 1).clamp_min(0)[None, :])[0], T_sh)
             a_eff = torch.where(contrib, alpha, torch.zeros_like(alpha))
-            one_minus = 1.0 - a_eff
-            T_all = torch.cumprod(torch.cat([T_cur[None, :], one_minus], dim=0), dim=0)
+            T_all = torch.cumprod(torch.cat([T_cur[None, :], 1.0 - a_eff], dim=0), dim=0)
             T_excl, T_incl = T_all[:-1], T_all[1:]
-            keep = alive[None, :] & (T_incl.detach() >= T_MIN)   # prefix mask per pixel
             wgt = a_eff * T_excl * keep
             acc = acc + wgt.t() @ feat[ids]
             n_keep = keep.sum(0)
@@ -427,18 +478,46 @@ def blend(pre: dict, binning: dict, s: RasterSettings, chunk: int = 512):
 
 
 def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-              cov3Ds_precomp, extra_attrs, settings: RasterSettings, return_aux: bool = False):
-    """Oracle counterpart of ``GaussianRasterizer.forward`` -> 6-tuple (+aux)."""
+              cov3Ds_precomp, extra_attrs, settings: RasterSettings, return_aux: bool = False,
+              cull: str = "exact", precision: str = "fp32"):
+    """Oracle counterpart of ``GaussianRasterizer.forward`` -> 6-tuple (+aux).  ``cull``: see bin_and_sort.
+
+    precision="fp64": every DISCRETE decision of the per-Gaussian stage (visibility, radii, tile rectangles, kept
+    tiles, depth order) is taken from the fp32 evaluation -- it is part of the specification, bit for bit -- while the
+    differentiable arithmetic (projection, conics, colours, blending and, through autograd, the whole backward) runs
+    in double precision on the same values.  Gradient parity tests compare the fp32 kernels against this, so that
+    the oracle's own fp32 rounding leaves the comparison."""
     if (shs is None) == (colors_precomp is None):
         raise Exception("Please provide excatly one of either SHs or precomputed colors!")
     if ((scales is None or rotations is None) and cov3Ds_precomp is None) or \
        ((scales is not None or rotations is not None) and cov3Ds_precomp is not None):
         raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-    pre = preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                     cov3Ds_precomp, extra_attrs, settings)
-    binning = bin_and_sort(pre)
-    image, depth, normal, alpha, extra, final_T, n_contrib = blend(pre, binning, settings)
-    outs = (image, depth, normal, alpha, pre["radii"], extra)
+    assert precision in ("fp32", "fp64")
+    if precision == "fp32":
+        pre = preprocess(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                         cov3Ds_precomp, extra_attrs, settings)
+        binning = bin_and_sort(pre, cull)
+        radii = pre["radii"]
+    else:
+        def det(t):
+            return None if t is None else t.detach()
+
+        def dbl(t):
+            return None if t is None else t.double()
+        with torch.no_grad():
+            pre32 = preprocess(det(means3D), det(means2D), det(shs), det(colors_precomp), det(opacities), det(scales),
+                               det(rotations), det(cov3Ds_precomp), det(extra_attrs), settings)
+        binning = bin_and_sort(pre32, cull)
+        pre = preprocess(dbl(means3D), dbl(means2D), dbl(shs), dbl(colors_precomp), dbl(opacities), dbl(scales),
+                         dbl(rotations), dbl(cov3Ds_precomp), dbl(extra_attrs), settings)
+        # branch decisions that may differ between the two evaluations (SH clamp at exactly 0, ...): reported
+        binning["fp64_branch_flips"] = int((pre["clamped"] != pre32["clamped"]).sum())
+        for k in ("radii", "tiles_touched", "visible", "rect"):
+            pre[k] = pre32[k]
+        radii = pre32["radii"]
+    image, depth, normal, alpha, extra, final_T, n_contrib = blend(pre, binning, settings,
+                                                                   decide=pre32 if precision == "fp64" else None)
+    outs = (image, depth, normal, alpha, radii, extra)
     if return_aux:
         aux = dict(pre=pre, binning=binning, final_T=final_T, n_contrib=n_contrib)
         return outs, aux

@@ -1,5 +1,6 @@
 """CPU: pin the oracles and the host-side restatements against the golden vectors produced from the
 reference's own importable code / source tables (tests/golden/make_golden.py)."""
+import pytest
 import numpy as np
 import torch
 
@@ -190,3 +191,86 @@ def test_rasterizer_oracle_properties():
     assert torch.equal(r0, r1) and int((r0 > 0).sum()) == 2000
     assert float(d0.max()) < 1.1 and float(d0.min()) >= 0       # blended view-space z, camera ~0.87 away
     assert float(n0.norm(dim=0).max()) <= 1.0 + 1e-5
+
+
+def _oracle_run(a, settings, cull, seed=5):
+    from tests.helpers import leaf, oracle_settings
+    s = oracle_settings(settings)
+    n = a["means3D"].shape[0]
+    inp = {k: leaf(v) for k, v in a.items()}
+    m2 = torch.zeros(n, 3, requires_grad=True)
+    outs, aux = rasterize_ref.rasterize(inp["means3D"], m2, inp["shs"], None, inp["opacities"], inp["scales"],
+                                        inp["rotations"], None, inp["extra"], s, return_aux=True, cull=cull)
+    g = torch.Generator().manual_seed(seed)
+    ws = [torch.randn(o.shape, generator=g) if o.is_floating_point() else None for o in outs]
+    sum((o * w).sum() for o, w in zip(outs, ws) if w is not None).backward()
+    inp["means2D"] = m2
+    return outs, aux, inp
+
+
+@pytest.mark.parametrize("n,size,deg", [(2000, 128, 1), (6000, 200, 3)], ids=["C1-2k-128", "6k-200-sh3-ragged"])
+def test_exact_tile_culling_changes_nothing(n, size, deg):
+    """The spec is the PUBLISHED binning: one instance per tile of a Gaussian's bounding rectangle (cull="rect").
+    The kernels emit fewer instances (cull="exact").  This test backs the claim that the optimisation is invisible:
+      (1) every dropped (Gaussian, tile) pair fails the blend loop's own test -- power > 0 or alpha < 1/255 -- at
+          EVERY pixel centre of its tile, evaluated with the blend's fp32 formula: it is a no-op of the published loop;
+      (2) final_T, alpha, radii are bit-identical, the images agree to fp32 summation order (the oracle's per-chunk
+          matmul partitions a longer list differently), gradients likewise;
+      (3) n_contrib of the exact lists, mapped through the kept positions, is n_contrib of the rectangle lists."""
+    from tests.helpers import make_scene
+    a, settings = make_scene(n, size, sh_degree=deg)
+    o_r, x_r, i_r = _oracle_run(a, settings, "rect")
+    o_e, x_e, i_e = _oracle_run(a, settings, "exact")
+    b_r, b_e = x_r["binning"], x_e["binning"]
+    pre = x_r["pre"]
+    assert b_r["R"] == int(pre["tiles_touched"].sum()) == b_r["candidates"]        # rect: the whole rectangle
+    assert b_e["R"] < b_r["R"] and b_e["candidates"] == b_r["candidates"]
+    assert np.array_equal(b_e["cand_gid"], b_r["cand_gid"]) and np.array_equal(b_e["cand_tile"], b_r["cand_tile"])
+    # (1) dropped pairs never contribute
+    drop = ~b_e["cand_keep"]
+    gid = torch.from_numpy(b_e["cand_gid"][drop])
+    tile = torch.from_numpy(b_e["cand_tile"][drop])
+    gx = pre["grid"][0]
+    lx, ly = torch.meshgrid(torch.arange(16), torch.arange(16), indexing="xy")
+    pxf = ((tile % gx) * 16)[:, None].float() + lx.reshape(1, -1).float()
+    pyf = ((tile // gx) * 16)[:, None].float() + ly.reshape(1, -1).float()
+    xy, con, op = pre["xy"].detach()[gid], pre["conic"].detach()[gid], pre["opacity"].detach()[gid]
+    dx, dy = xy[:, 0:1] - pxf, xy[:, 1:2] - pyf
+    power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
+    alpha = torch.clamp_max(op[:, None] * torch.exp(power), 0.99)
+    contributes = (power <= 0) & (alpha >= rasterize_ref.ALPHA_MIN)
+    assert int(drop.sum()) > 0 and not bool(contributes.any())
+    # margin of the predicate: the largest alpha any dropped pair reaches stays below the 1/255 cut
+    assert float(torch.where(power <= 0, alpha, torch.zeros_like(alpha)).max()) < rasterize_ref.ALPHA_MIN
+    # (2) results
+    assert torch.equal(x_r["final_T"], x_e["final_T"])
+    assert torch.equal(o_r[3], o_e[3]) and torch.equal(o_r[4], o_e[4])
+    for name, p, q in zip(("image", "depth", "normal", "alpha", "radii", "extra"), o_r, o_e):
+        if p.is_floating_point():
+            assert float((p - q).abs().max()) <= 1e-6, name
+    for k in i_r:
+        gr, ge = i_r[k].grad, i_e[k].grad
+        assert float((gr - ge).abs().max()) <= 1e-6 * float(gr.abs().max()), k
+    # (3) last contributor: position in the exact list -> position in the rectangle list of the same tile
+    nc_r, nc_e = x_r["n_contrib"].numpy(), x_e["n_contrib"].numpy()
+    H, W = nc_r.shape
+    for t in range(pre["grid"][0] * pre["grid"][1]):
+        a0, a1 = b_r["ranges"][t]
+        e0, e1 = b_e["ranges"][t]
+        if e1 <= e0:
+            continue
+        lst_r, lst_e = b_r["point_list"][a0:a1], b_e["point_list"][e0:e1]
+        pos = np.flatnonzero(np.isin(lst_r, lst_e))             # a Gaussian appears once per tile
+        assert np.array_equal(lst_r[pos], lst_e)                 # same relative (depth) order
+        ty0, tx0 = (t // gx) * 16, (t % gx) * 16
+        blk_e = nc_e[ty0:ty0 + 16, tx0:tx0 + 16]
+        blk_r = nc_r[ty0:ty0 + 16, tx0:tx0 + 16]
+        mapped = np.where(blk_e > 0, pos[np.maximum(blk_e, 1) - 1] + 1, 0)
+        assert np.array_equal(mapped, blk_r)
+
+
+def test_culling_threshold_is_libm_free():
+    """The culling threshold's logarithm is evaluated from + - * / only (same tree on the device), to 1e-15."""
+    x = np.concatenate([np.linspace(1e-3, 255.0, 20001), 10.0 ** np.linspace(-30, 30, 2001)])
+    got = rasterize_ref._det_ln(x)
+    assert np.abs(got - np.log(x)).max() <= 4e-14 and np.abs((got - np.log(x)))[np.abs(np.log(x)) > 1].max() <= 4e-14

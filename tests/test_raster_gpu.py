@@ -71,6 +71,16 @@ def test_binning_bit_exact(n, size, deg):
     assert np.array_equal(d["tiles_touched"].cpu().numpy().astype(np.int64), binning["tiles_touched"])
     assert binning["R"] < binning["candidates"]          # exact tile culling removed some rectangle tiles
     assert d["R"] == binning["R"]
+    # the bounding rectangle = the PUBLISHED binning (oracle cull="rect"): min tile, width, height bit for bit, so the
+    # rectangle lists the kernels cull FROM are the published ones; that culling changes no result is
+    # tests/test_oracle_golden.py::test_exact_tile_culling_changes_nothing
+    vis_r = pre["radii"] > 0
+    rect_o = pre["rect"]                                # min x, min y, max x, max y (exclusive)
+    rect_h = d["rect"].cpu()
+    assert torch.equal(rect_h[vis_r, 0], rect_o[vis_r, 0]) and torch.equal(rect_h[vis_r, 1], rect_o[vis_r, 1])
+    assert torch.equal(rect_h[vis_r, 2], (rect_o[:, 2] - rect_o[:, 0])[vis_r])
+    assert torch.equal(rect_h[vis_r, 3], (rect_o[:, 3] - rect_o[:, 1])[vis_r])
+    assert int((rect_h[vis_r, 2] * rect_h[vis_r, 3]).sum()) == binning["candidates"] == int(pre["tiles_touched"].sum())
     assert np.array_equal(d["keys"].cpu().numpy().view(np.uint64), binning["keys"])
     assert np.array_equal(d["point_list"].cpu().numpy(), binning["point_list"])
     assert np.array_equal(d["ranges"].cpu().numpy(), binning["ranges"])
@@ -101,31 +111,90 @@ def test_forward_images(n, size, deg):
         assert err <= 1e-4, f"{name}: max abs err {err}"
 
 
-def _grad_check(go, gh, name, rtol=2e-3):
-    go, gh = go.detach(), gh.detach().cpu()
+PARITY_LOG = {}
+
+
+def _record(case, name, **numbers):
+    """Measured parity errors of this test session -> gpurun_out/parity_errors.json (copied to profiles/ per round)."""
+    import json
+    import os
+    PARITY_LOG.setdefault(case, {})[name] = {k: float(v) for k, v in numbers.items()}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_errors.json"), "w") as f:
+        json.dump(PARITY_LOG, f, indent=1, sort_keys=True)
+
+
+# Gradient bars, against the oracle evaluated in DOUBLE precision on the fp32 binning (oracle precision="fp64"):
+#   (1) max |dg| <= 5e-5 * max |g| per tensor                       (measured: <= 2.8e-5, profiles/r02_parity_errors.json);
+#   (2) entries with |g| > 1e-3 * max |g|: relative error <= 1e-3 at the 99.9th percentile (measured <= 6.2e-4) and
+#       <= 5e-3 at the worst entry (measured <= 2.7e-3): __expf / v_rcp_f32 in the blend recurrence and fp32 summation
+#       over lists of up to ~2,600 entries are what is left once the oracle's own rounding is out of the comparison.
+G_MAX, G_REL_Q999, G_REL_WORST = 5e-5, 1e-3, 5e-3
+
+
+def _grad_check(go, gh, name, case="", max_tol=G_MAX):
+    go, gh = go.detach().double(), gh.detach().cpu().double()
     scale = go.abs().max().item()
-    err = (go - gh).abs().max().item()
-    assert err <= rtol * scale + 1e-7, f"{name}: err {err} vs scale {scale}"
+    d = (go - gh).abs()
+    err = d.max().item()
+    big = go.abs() > 1e-3 * scale
+    rel = (d[big] / go.abs()[big]) if bool(big.any()) else torch.zeros(1, dtype=torch.float64)
+    q999 = torch.quantile(rel[:2_000_000], 0.999).item()
+    _record(case, name, max_abs_over_max=err / max(scale, 1e-300), rel_q999=q999, rel_worst=rel.max().item(),
+            grad_max=scale, entries_checked_rel=int(big.sum()))
+    assert err <= max_tol * scale + 1e-9, f"{name}: max err {err} vs scale {scale} ({err / scale:.2e})"
+    assert q999 <= G_REL_Q999, f"{name}: 99.9th percentile of the relative error {q999:.2e}"
+    assert rel.max().item() <= G_REL_WORST, f"{name}: worst relative error {rel.max().item():.2e}"
 
 
-@pytest.mark.parametrize("use_sh,use_cov", [(True, False), (False, False), (True, True)],
-                         ids=["sh+scale_rot", "colors_precomp", "cov3D_precomp"])
-def test_backward_gradients(use_sh, use_cov):
-    a, settings = make_scene(3000, 128, sh_degree=2 if use_sh else 0, seed=3)
-    outs_o, aux, inp_o = run_oracle(a, settings, use_sh, use_cov)
+GRAD_CASES = [
+    pytest.param(3000, 128, True, False, 3, id="3k-128-sh2-scale_rot"),
+    pytest.param(3000, 128, False, False, 3, id="3k-128-colors_precomp"),
+    pytest.param(3000, 128, True, True, 3, id="3k-128-cov3D_precomp"),
+    pytest.param(6000, 200, True, False, 0, id="6k-200-sh3-ragged"),
+    pytest.param(20000, 256, True, False, 0, id="20k-256-sh1"),
+]
+
+
+@pytest.mark.parametrize("n,size,use_sh,use_cov,seed", GRAD_CASES)
+def test_backward_gradients(n, size, use_sh, use_cov, seed, request):
+    """All-output upstream gradient (image, depth, normal, alpha, extra weighted by unit normals) -> every input
+    gradient of the HIP backward against the fp64 oracle; forward images against it too (<= 1e-4)."""
+    deg = {3000: 2 if use_sh else 0, 6000: 3, 20000: 1}[n]
+    a, settings = make_scene(n, size, sh_degree=deg, seed=seed)
+    from oracle import rasterize_ref as R
+    s = oracle_settings(settings)
+    inp_o = {k: leaf(v) for k, v in a.items()}
+    m2 = torch.zeros(n, 3, requires_grad=True)
+    cov = None
+    if use_cov:
+        cov = leaf(R.build_cov3d(a["scales"], a["rotations"], 1.0)[0])
+    colors = None if use_sh else leaf(torch.sigmoid(a["shs"][:, 0, :]))
+    outs_o, aux = R.rasterize(inp_o["means3D"], m2, inp_o["shs"] if use_sh else None, colors, inp_o["opacities"],
+                              None if use_cov else inp_o["scales"], None if use_cov else inp_o["rotations"], cov,
+                              inp_o["extra"], s, return_aux=True, precision="fp64")
+    inp_o["means2D"], inp_o["cov3D"], inp_o["colors"] = m2, cov, colors
     outs_h, inp_h = run_hip(a, settings, use_sh, use_cov)
     g = torch.Generator().manual_seed(5)
     ws = [torch.randn(o.shape, generator=g) if o.is_floating_point() else None for o in outs_o]
-    loss_o = sum((o * w).sum() for o, w in zip(outs_o, ws) if w is not None)
+    loss_o = sum((o * w.double()).sum() for o, w in zip(outs_o, ws) if w is not None)
     loss_h = sum((o * w.cuda()).sum() for o, w in zip(outs_h, ws) if w is not None)
     loss_o.backward()
     loss_h.backward()
+    case = request.node.callspec.id
+    for name, o, h in zip(("image", "depth", "normal", "alpha", "radii", "extra"), outs_o, outs_h):
+        if o.is_floating_point():
+            err = (h.detach().cpu().double() - o.detach()).abs().max().item()
+            _record(case, "fwd_" + name, max_abs=err)
+            assert err <= 1e-5, f"{name}: max abs err {err}"       # north_star's bar is 1e-4; measured <= 3.5e-6
     keys = ["means3D", "means2D", "opacities", "extra"]
     keys += ["shs"] if use_sh else ["colors"]
     keys += ["cov3D"] if use_cov else ["scales", "rotations"]
     for k in keys:
         assert inp_h[k].grad is not None, k
-        _grad_check(inp_o[k].grad, inp_h[k].grad, k)
+        _grad_check(inp_o[k].grad, inp_h[k].grad, k, case)
 
 
 def test_backward_deterministic():
@@ -462,3 +531,57 @@ def test_dp_two_ranks_share_one_gpu():
            "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "dp_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
     assert r.returncode == 0 and "DP-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_full_c3_train_step_100k_512():
+    """Config C3 at FULL size through the whole train step (not only its raster pass): 100k Gaussians, 512x512, SH 1,
+    PMF + UMF, image + attention map, loss block, backward, statistics, Adam -- eager launches against the replayed
+    hipGraph over three frames: same losses, same parameters, no capacity overflow, finite everywhere; and the
+    gradients of a repeated frame are bitwise reproducible."""
+    from instag_amd import diff_gauss
+    from instag_amd.scene_synth import synthetic_frame, toy_cameras
+    from instag_amd.train import C3_PHASE, build_trainer, make_frame
+    dev = torch.device("cuda")
+    N, size = 100000, 512
+    cams = toy_cameras(size)
+    frames = [make_frame(cams[i].to(dev), synthetic_frame(size, i, dev)) for i in range(3)]
+    losses, params = {}, {}
+    for mode in ("eager", "graph"):
+        tr = build_trainer(N, dev, seed=0)
+        try:
+            if mode == "graph":
+                g = tr.enable_graph(frames[0], warmup_steps=2)        # 2 eager + 2 capacity-mode steps on frame 0
+                assert g.capacity >= diff_gauss.LAST_STATS["num_rendered"] > N
+            else:
+                for _ in range(4):
+                    tr.step(frames[0])
+            ls = [float(tr.step(frames[i % 3])["loss"]) for i in range(6)]
+            if mode == "graph":
+                assert tr._graph is not None and tr._graph.check_overflow() == []
+                need = tr._graph.plan.needed()
+                # (two planned slots; the attention map rides along the main pass, so one rasterizer call per step)
+                assert need[0] > N and all(r <= g.capacity for r in need), need
+        finally:
+            diff_gauss.set_capacity_plan(None)
+        assert tr.iteration == 10 and all(np.isfinite(ls)), ls
+        losses[mode] = ls
+        params[mode] = torch.cat([p.detach().reshape(-1) for p in tr._all_params()])
+        assert bool(torch.isfinite(params[mode]).all())
+        if mode == "eager":
+            # bitwise reproducible gradients: the same frame twice, no optimizer step in between
+            grads = []
+            for _ in range(2):
+                tr._forward_backward(frames[1], C3_PHASE)
+                grads.append([None if p.grad is None else p.grad.clone() for p in tr._all_params()])
+                tr._zero_grad()
+            some = 0
+            for a_, b_ in zip(*grads):
+                assert (a_ is None) == (b_ is None)
+                if a_ is not None:
+                    assert torch.equal(a_, b_)
+                    some += int(a_.abs().max() > 0)
+            assert some >= 10
+        del tr
+    for a_, b_ in zip(losses["eager"], losses["graph"]):
+        assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (losses["eager"], losses["graph"])
+    assert float((params["eager"] - params["graph"]).abs().max()) <= 1e-5
