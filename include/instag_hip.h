@@ -157,8 +157,14 @@ int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t
 /* Sync-free forward (hipGraph-capturable): stage1 + stage2 in one call with a caller-chosen instance
  * capacity instead of the host round trip.  binning / backward workspace are sized for `capacity`
  * (instag_raster_binning_bytes(capacity), instag_raster_backward_workspace_bytes(N, capacity)) and
- * backward is called with R = capacity.  status (device int32[2]): [0] = instances needed R,
- * [1] = 1 if R > capacity (instances beyond the capacity were dropped: re-run with a larger one). */
+ * backward is called with R = capacity.  status (device int32[4], zero-initialised by the caller):
+ *   [0] = instances this call needed (R);
+ *   [1] = STICKY overflow flag: set to 1 by any call with R > capacity, never cleared by the library -- a caller that
+ *         replays a captured step checks it now and then and clears it itself;
+ *   [2] = largest R seen since the caller last cleared it (what to size the next capacity from);
+ *   [3] = instances this call binned: R, or, on overflow, the instances of the Gaussians (in depth order) in front of
+ *         the first one whose instances would cross the capacity.  Dropped Gaussians are not rendered and get zero
+ *         gradients; nothing is read or written outside the buffers. */
 int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size_t geom_bytes,
                                    void* binning, size_t binning_bytes, void* image, size_t image_bytes,
                                    int64_t capacity, int32_t* radii, int32_t* status, float* out_color,
@@ -209,6 +215,13 @@ int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* 
  * oracle's cull="rect" mode.  Only entries of Gaussians with radii > 0 are defined. */
 int instag_raster_debug_export_flags(const void* geom, size_t geom_bytes, int32_t N, uint32_t* flags /*[N]*/,
                                      instag_stream_t stream);
+
+/* Diagnostics (scripts/bench_sort.py): the depth sort of the Gaussians alone, on `stream`.  stamps (device, may be
+ * NULL): uint64[4 passes][instag_debug_depth_sort_blocks(N)][8], 100 MHz timestamps of every block's phases.
+ * order_out (device, may be NULL): uint32[N], Gaussian indices in (depth bits, index) order. */
+int instag_debug_depth_sort(const instag_raster_args* a, void* geom, size_t geom_bytes, uint64_t* stamps,
+                            uint32_t* order_out, instag_stream_t stream);
+uint32_t instag_debug_depth_sort_blocks(int32_t N);
 
 /* ------------------------------------------------------------------------------------------
  * Bias-free ReLU MLP over N rows on the f32 matrix cores (exact fp32).

@@ -79,6 +79,8 @@ _PROTOS = {
     "instag_raster_debug_export": (C.c_int, [vp, sz, vp, sz, vp, sz, i32, i64, i32, i32,
                                              vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "instag_raster_debug_export_flags": (C.c_int, [vp, sz, i32, vp, vp]),
+    "instag_debug_depth_sort": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, vp, vp]),
+    "instag_debug_depth_sort_blocks": (C.c_uint32, [i32]),
     "instag_mlp_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward_add": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

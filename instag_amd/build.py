@@ -33,6 +33,7 @@ SOURCES = {
     "raster_blend.hip": [],
     "raster_backward.hip": [],
     "raster_api.hip": [],
+    "raster_sort.hip": [],
     "grid.hip": [],
     "sh.hip": [],
     "mlp.hip": [],

@@ -63,8 +63,15 @@ enum RecSlot { R_X = 0, R_Y, R_CA, R_CB, R_CC, R_OP, R_R, R_G, R_B, R_DEPTH, R_N
 
 // flags[g]: bit0..2 rgb clamped, bit3..4 normal axis, bit5 normal flipped, bit6 tx clamped, bit7 ty clamped
 struct GeomLayout {
-  size_t rec2d, cov3d, tiles_touched, point_offsets, flags, cull_thr, depth_key, order_in, depth_key_sorted, order,
-      tt_sorted, scan_temp, scan_temp_bytes, sort_temp, sort_temp_bytes, total;
+  size_t rec2d, cov3d, tiles_touched, point_offsets, flags, cull_thr;
+  // depth sort: keys ping-pong K0 -> KA -> K0 -> KA, values (index) -> VA -> VB -> VA -> VB = `order`
+  size_t depth_key, depth_key_alt, order_a, order;
+  size_t dsort_zero, dsort_zero_words;      // [16 words: one ticket per pass][4 passes x blocks x 256 look-back words]
+  size_t dsort_digit_base;                  // [4][256]
+  size_t dsort_partials;                    // [blocks][4][256]
+  size_t scan_state, scan_state_words;      // u64 [1 + blocks] as 32-bit words; cleared by the preprocess kernel
+  uint32_t dsort_blocks, dkey_blocks;
+  size_t total;
 };
 GeomLayout geom_layout(int32_t N);
 
@@ -74,7 +81,14 @@ struct ImageLayout {
 ImageLayout image_layout(int32_t H, int32_t W);
 
 struct BinningLayout {
-  size_t keys_unsorted, vals_unsorted, keys, vals, gid_unsorted, point_list, sort_temp, sort_temp_bytes, total;
+  // instance sort: keys K0 = keys_unsorted -> (ktmp) -> keys, values likewise (pair form only)
+  size_t keys_unsorted, vals_unsorted, keys, vals, ktmp, vtmp, gid_unsorted, point_list;
+  size_t tsort_zero, tsort_zero_words;      // [16 words: tickets][3 passes x blocks x 256 look-back words]
+  size_t tsort_digit_base;                  // [3][256]
+  size_t tsort_partials;                    // [1024][3][256]
+  size_t sort_count;                        // u32: instances actually binned
+  uint32_t tsort_blocks;
+  size_t total;
 };
 BinningLayout binning_layout(int64_t R);
 

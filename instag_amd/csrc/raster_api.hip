@@ -1,8 +1,5 @@
 // C-ABI entry points of the rasterizer (see include/instag_hip.h) + buffer layouts, scan and sort.
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include <mutex>
 #include <vector>
@@ -44,68 +41,40 @@ ProfScope::~ProfScope() {
   p.pending[kernel_].push_back({start_, stop});
 }
 
-// ---- instance sort by tile id -----------------------------------------------------------------------
-// The instances arrive in depth order, so the (tile, depth) sort is a stable sort on the ceil(log2 tiles) bits of the
-// tile id: rocPRIM's onesweep radix sort over those bits only.  Merge sort is never chosen (rocPRIM's default picks
-// it below 1 M keys; it compares whole keys and took twice as long at 0.5 M instances).
+// ---- second stream for the depth sort ------------------------------------------------------------------------------
+// The depth sort needs means3D and the view matrix only, so it runs beside the preprocess kernel: forked from the
+// caller's stream with an event, joined with another.  Stream and events belong to the calling THREAD (forward runs on
+// the caller's thread, backward on autograd's: no sharing, no lock) and are created on a call that is not being captured
+// into a graph (stream / event creation is not capturable); until then the sort simply stays on the caller's stream.
 namespace {
-// rocPRIM's own tuned gfx950 onesweep parameters for 4-byte keys (device_radix_sort_onesweep.hpp: 1024 x 8 key-only,
-// 1024 x 16 with 4-byte values, 8-bit digits, match ranking) with the merge-sort limit set to zero
-using TileSortKeysConfig = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8,
-                                        rocprim::block_radix_rank_algorithm::match>,
-    0>;
-using TileSortPairsConfig = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 8,
-                                        rocprim::block_radix_rank_algorithm::match>,
-    0>;
-
-// bits = width of the tile id; vals_* null = key-only form; temp null = size query (the larger of the two forms).
-// 8-bit digits: measured on MI355X (1.5 M keys, 10-bit tile ids) one 10-bit pass costs 56 us + a 17 us histogram
-// against 2 x 17 us + 8 us for two 8-bit passes (the 1024-bin in-block ranking is what grows).
-//
-// `replayed` = the call sits in a step that is captured into a hipGraph (capacity mode).  Below 2^20 keys such a call
-// takes rocPRIM's default path (merge sort at these sizes): a captured onesweep sort of 0.33 M keys (mouth branch,
-// 20k Gaussians) ran correctly on the first replay of its graph and faulted inside the scatter kernel on the second
-// one, with or without rocPRIM's atomic block ids, while the same sort of 1.5 M keys (face branch) has replayed
-// thousands of times -- the zero-initialised state of the small sort (digit offsets / look-back flags, cleared by
-// memset nodes) does not survive a replay on ROCm 7.2.  The merge sort keeps no state between its kernels.
-hipError_t tile_sort(void* temp, size_t& bytes, uint32_t* keys_in, uint32_t* keys_out, uint32_t* vals_in,
-                     uint32_t* vals_out, size_t n, unsigned begin_bit, unsigned bits, bool replayed, hipStream_t s) {
-  const unsigned end_bit = begin_bit + bits;
-  const bool keys_only = vals_in == nullptr && vals_out == nullptr;
-  if (temp == nullptr) {      // size query: the largest request of the four forms
-    size_t q[4] = {0, 0, 0, 0};
-    hipError_t e = rocprim::radix_sort_keys<TileSortKeysConfig>(nullptr, q[0], keys_in, keys_out, n, begin_bit, end_bit, s);
-    if (e == hipSuccess)
-      e = rocprim::radix_sort_pairs<TileSortPairsConfig>(nullptr, q[1], keys_in, keys_out, vals_in, vals_out, n, begin_bit,
-                                                         end_bit, s);
-    if (e == hipSuccess) e = rocprim::radix_sort_keys(nullptr, q[2], keys_in, keys_out, n, begin_bit, end_bit, s);
-    if (e == hipSuccess)
-      e = rocprim::radix_sort_pairs(nullptr, q[3], keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
-    bytes = std::max(std::max(q[0], q[1]), std::max(q[2], q[3]));
-    return e;
-  }
-  if (replayed && n < ((size_t)1 << 20)) {
-    if (keys_only) return rocprim::radix_sort_keys(temp, bytes, keys_in, keys_out, n, begin_bit, end_bit, s);
-    return rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, s);
-  }
-  if (keys_only)
-    return rocprim::radix_sort_keys<TileSortKeysConfig>(temp, bytes, keys_in, keys_out, n, begin_bit, end_bit, s);
-  return rocprim::radix_sort_pairs<TileSortPairsConfig>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit,
-                                                        end_bit, s);
-}
-}  // namespace
-
-// scan input: kept-tile count of the Gaussian at depth rank i, gathered on the fly (no materialised permutation)
-namespace {
-struct CountAtRank {
-  const uint32_t* tiles_touched;
-  __host__ __device__ uint32_t operator()(uint32_t g) const { return tiles_touched[g]; }
+struct SideLane {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
 };
-using RankedCounts = rocprim::transform_iterator<const uint32_t*, CountAtRank, uint32_t>;
+thread_local SideLane g_side;
+
+SideLane* side_lane(hipStream_t caller) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (g_side.stream != nullptr && g_side.device == dev) return &g_side;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (g_side.stream != nullptr) {            // the thread moved to another device: rebuild
+    (void)hipEventDestroy(g_side.fork); (void)hipEventDestroy(g_side.join); (void)hipStreamDestroy(g_side.stream);
+    g_side = SideLane();
+  }
+  SideLane l;
+  if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipStreamDestroy(l.stream);
+    return nullptr;
+  }
+  l.device = dev;
+  g_side = l;
+  return &g_side;
+}
 }  // namespace
 
 // ---- layouts ----------------------------------------------------------------------------------------
@@ -120,18 +89,17 @@ GeomLayout geom_layout(int32_t N) {
   L.flags = o; o = align_up(o + n * sizeof(uint32_t), 256);
   L.cull_thr = o; o = align_up(o + n * sizeof(float), 256);
   L.depth_key = o; o = align_up(o + n * sizeof(uint32_t), 256);
-  L.order_in = o; o = align_up(o + n * sizeof(uint32_t), 256);
-  L.depth_key_sorted = o; o = align_up(o + n * sizeof(uint32_t), 256);
+  L.depth_key_alt = o; o = align_up(o + n * sizeof(uint32_t), 256);
+  L.order_a = o; o = align_up(o + n * sizeof(uint32_t), 256);
   L.order = o; o = align_up(o + n * sizeof(uint32_t), 256);
-  L.tt_sorted = o; o = align_up(o + n * sizeof(uint32_t), 256);
-  size_t tmp = 0;
-  (void)rocprim::inclusive_scan(nullptr, tmp, RankedCounts((const uint32_t*)nullptr, CountAtRank{nullptr}),
-                                (uint32_t*)nullptr, n, rocprim::plus<uint32_t>());
-  L.scan_temp = o; L.scan_temp_bytes = tmp; o = align_up(o + tmp, 256);
-  size_t tmp2 = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp2, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, n, 0, 32);
-  L.sort_temp = o; L.sort_temp_bytes = tmp2; o = align_up(o + tmp2, 256);
+  L.dsort_blocks = sort_blocks((uint32_t)n, SORT_IPT_DEPTH);
+  L.dsort_zero_words = 16 + (size_t)4 * L.dsort_blocks * 256;
+  L.dsort_zero = o; o = align_up(o + L.dsort_zero_words * sizeof(uint32_t), 256);
+  L.dsort_digit_base = o; o = align_up(o + (size_t)HIST_SLICES * 4 * 256 * sizeof(uint32_t), 256);
+  L.dkey_blocks = depth_key_blocks((int32_t)n);
+  L.dsort_partials = o; o = align_up(o + (size_t)L.dkey_blocks * 4 * 256 * sizeof(uint32_t), 256);
+  L.scan_state_words = 2 * (1 + (size_t)div_up<size_t>(n, 1024));
+  L.scan_state = o; o = align_up(o + L.scan_state_words * sizeof(uint32_t), 256);
   L.total = o;
   return L;
 }
@@ -156,16 +124,16 @@ BinningLayout binning_layout(int64_t R) {
   L.vals_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.keys = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.vals = o; o = align_up(o + r * sizeof(uint32_t), 256);
+  L.ktmp = o; o = align_up(o + r * sizeof(uint32_t), 256);
+  L.vtmp = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.gid_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.point_list = o; o = align_up(o + r * sizeof(uint32_t), 256);
-  // the largest request over the radix widths tile_sort() may pick (the tile count is not known here)
-  size_t tmp = 0;
-  for (unsigned bits : {8u, 16u, 24u}) {
-    size_t t = 0;
-    (void)tile_sort(nullptr, t, nullptr, nullptr, nullptr, nullptr, r, 0, bits, false, nullptr);
-    tmp = std::max(tmp, t);
-  }
-  L.sort_temp = o; L.sort_temp_bytes = tmp; o = align_up(o + tmp, 256);
+  L.tsort_blocks = sort_blocks((uint32_t)r, SORT_IPT_TILE);
+  L.tsort_zero_words = 16 + (size_t)3 * L.tsort_blocks * 256;
+  L.tsort_zero = o; o = align_up(o + L.tsort_zero_words * sizeof(uint32_t), 256);
+  L.tsort_digit_base = o; o = align_up(o + (size_t)HIST_SLICES * 3 * 256 * sizeof(uint32_t), 256);
+  L.tsort_partials = o; o = align_up(o + (size_t)1024 * 3 * 256 * sizeof(uint32_t), 256);
+  L.sort_count = o; o = align_up(o + sizeof(uint32_t), 256);
   L.total = o;
   return L;
 }
@@ -189,28 +157,60 @@ static int validate(const instag_raster_args* a) {
   return INSTAG_OK;
 }
 
-// preprocess -> depth order of the Gaussians -> instance offsets in depth order.
+// preprocess || depth sort of the Gaussians -> instance offsets in depth order.
 // Emitting the instances in depth order makes the (tile, depth) sort a STABLE sort by tile id alone
 // (10-12 key bits instead of 42-44): same final order, a third of the radix passes on half the bytes.
+static int depth_sort(const Camera& c, const instag_raster_args* a, char* gb, const GeomLayout& L, hipStream_t s,
+                      uint64_t* stamps = nullptr) {
+  uint32_t* zero = (uint32_t*)(gb + L.dsort_zero);
+  uint32_t* digit_base = (uint32_t*)(gb + L.dsort_digit_base);
+  uint32_t* partials = (uint32_t*)(gb + L.dsort_partials);
+  uint32_t* K0 = (uint32_t*)(gb + L.depth_key);
+  uint32_t* KA = (uint32_t*)(gb + L.depth_key_alt);
+  uint32_t* VA = (uint32_t*)(gb + L.order_a);
+  uint32_t* VB = (uint32_t*)(gb + L.order);
+  ProfScope p(K_SORT, s);
+  if (int e = launch_depth_keys(c, a->means3D, K0, partials, zero, (uint32_t)L.dsort_zero_words, s)) return e;
+  // per-block digit histograms [blocks][4][256]: the pass kernels sum them directly while they are few
+  const uint32_t* hist = partials;
+  int n_hist = (int)L.dkey_blocks;
+  if (n_hist > 320) {
+    if (int e = launch_hist_reduce(partials, n_hist, 4, HIST_SLICES, digit_base, s)) return e;
+    hist = digit_base; n_hist = HIST_SLICES;
+  }
+  const uint32_t n = (uint32_t)a->N;
+  const uint32_t* kin[4] = {K0, KA, K0, KA};
+  uint32_t* kout[4] = {KA, K0, KA, nullptr};
+  const uint32_t* vin[4] = {nullptr, VA, VB, VA};
+  uint32_t* vout[4] = {VA, VB, VA, VB};
+  for (int pass = 0; pass < 4; ++pass) {
+    if (int e = launch_radix_pass(SORT_IPT_DEPTH, true, pass < 3, kin[pass], kout[pass], vin[pass], vout[pass], nullptr,
+                                  n, 8 * pass, 8, hist + 256 * pass, n_hist, 4 * 256, zero + pass,
+                                  zero + 16 + (size_t)pass * L.dsort_blocks * 256, s,
+                                  stamps ? stamps + (size_t)pass * L.dsort_blocks * 8 : nullptr)) return e;
+  }
+  return INSTAG_OK;
+}
+
 static int per_gaussian_stage(const instag_raster_args* a, const Camera& c, char* gb, const GeomLayout& L, int32_t* radii,
                               hipStream_t s) {
   uint32_t* tiles_touched = (uint32_t*)(gb + L.tiles_touched);
   uint32_t* point_offsets = (uint32_t*)(gb + L.point_offsets);
-  if (int e = launch_preprocess(c, a, (float*)(gb + L.rec2d), (float*)(gb + L.cov3d), tiles_touched,
-                                (uint32_t*)(gb + L.flags), (float*)(gb + L.cull_thr), (uint32_t*)(gb + L.depth_key),
-                                (uint32_t*)(gb + L.order_in), radii, s)) return e;
-  {
-    ProfScope p(K_SORT, s);
-    size_t tmp = L.sort_temp_bytes;
-    INSTAG_CHECK_HIP(rocprim::radix_sort_pairs(gb + L.sort_temp, tmp, (uint32_t*)(gb + L.depth_key),
-                                               (uint32_t*)(gb + L.depth_key_sorted), (uint32_t*)(gb + L.order_in),
-                                               (uint32_t*)(gb + L.order), (size_t)a->N, 0, 32, s));
+  SideLane* lane = side_lane(s);
+  if (lane != nullptr) {
+    INSTAG_CHECK_HIP(hipEventRecord(lane->fork, s));
+    INSTAG_CHECK_HIP(hipStreamWaitEvent(lane->stream, lane->fork, 0));
+    if (int e = depth_sort(c, a, gb, L, lane->stream)) return e;
+    INSTAG_CHECK_HIP(hipEventRecord(lane->join, lane->stream));
+  } else {
+    if (int e = depth_sort(c, a, gb, L, s)) return e;
   }
-  size_t tmp = L.scan_temp_bytes;
-  INSTAG_CHECK_HIP(rocprim::inclusive_scan(gb + L.scan_temp, tmp,
-                                           RankedCounts((const uint32_t*)(gb + L.order), CountAtRank{tiles_touched}),
-                                           point_offsets, (size_t)a->N, rocprim::plus<uint32_t>(), s));
-  return INSTAG_OK;
+  if (int e = launch_preprocess(c, a, (float*)(gb + L.rec2d), (float*)(gb + L.cov3d), tiles_touched,
+                                (uint32_t*)(gb + L.flags), (float*)(gb + L.cull_thr), radii,
+                                (uint32_t*)(gb + L.scan_state), (uint32_t)L.scan_state_words, s)) return e;
+  if (lane != nullptr) INSTAG_CHECK_HIP(hipStreamWaitEvent(s, lane->join, 0));
+  return launch_scan_counts(a->N, (const uint32_t*)(gb + L.order), tiles_touched, point_offsets,
+                            (uint64_t*)(gb + L.scan_state), s);
 }
 
 }  // namespace instag
@@ -250,16 +250,15 @@ int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t
   return INSTAG_OK;
 }
 
-// duplicate -> sort -> ranges -> blend over `R` instance slots.  In capacity mode (pad=true) R is the
-// caller's capacity: the unsorted keys are pre-filled with all-ones so that unused slots sort last
-// and own no tile range.
+// duplicate -> sort -> ranges -> blend over `R` instance slots.  In capacity mode R is the caller's capacity; how many
+// of the slots are in use is a device word written by the duplicate kernel and read by the sort and the range kernel.
 static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
-                        size_t binning_bytes, void* image, size_t image_bytes, int64_t R, bool pad,
+                        size_t binning_bytes, void* image, size_t image_bytes, int64_t R,
                         float* out_color, float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
                         const float* aux_colors, float* out_aux, int32_t* status, hipStream_t s) {
   INSTAG_REQUIRE(out_color && out_depth && out_normal && out_alpha, "output images must not be NULL");
   INSTAG_REQUIRE((aux_colors == nullptr) == (out_aux == nullptr), "aux_colors and out_aux go together");
-  INSTAG_REQUIRE(R >= 0 && R < (int64_t)1 << 31, "instance count out of range");
+  INSTAG_REQUIRE(R >= 0 && R < (int64_t)1 << 30, "instance count out of range (2^30 - 1 at most)");
   const GeomLayout GL = geom_layout(a->N);
   const ImageLayout IL = image_layout(a->image_height, a->image_width);
   const BinningLayout BL = binning_layout(R);
@@ -270,31 +269,43 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   const Camera c = make_camera(a);
   const int tiles = c.grid_x * c.grid_y;
   int32_t* ranges = (int32_t*)(ib + IL.ranges);
-  uint32_t* keys_u = (uint32_t*)(bb + BL.keys_unsorted);
-  uint32_t* vals_u = (uint32_t*)(bb + BL.vals_unsorted);
-  uint32_t* keys = (uint32_t*)(bb + BL.keys);
-  uint32_t* vals = (uint32_t*)(bb + BL.vals);
+  uint32_t* K0 = (uint32_t*)(bb + BL.keys_unsorted);
+  uint32_t* V0 = (uint32_t*)(bb + BL.vals_unsorted);
+  uint32_t* K1 = (uint32_t*)(bb + BL.keys);
+  uint32_t* V1 = (uint32_t*)(bb + BL.vals);
+  uint32_t* K2 = (uint32_t*)(bb + BL.ktmp);
+  uint32_t* V2 = (uint32_t*)(bb + BL.vtmp);
   uint32_t* gid_u = (uint32_t*)(bb + BL.gid_unsorted);
   uint32_t* point_list = (uint32_t*)(bb + BL.point_list);
+  uint32_t* zero = (uint32_t*)(bb + BL.tsort_zero);
+  uint32_t* digit_base = (uint32_t*)(bb + BL.tsort_digit_base);
+  uint32_t* partials = (uint32_t*)(bb + BL.tsort_partials);
+  uint32_t* sort_count = (uint32_t*)(bb + BL.sort_count);
   const bool packed = use_packed_keys(R, tiles);
   if (R > 0 && a->N > 0) {
-    // the duplicate kernel also clears the tile ranges and (capacity mode) pads the unused key slots
+    const TilePasses tp = tile_passes(tiles);
     if (int e = launch_duplicate(c, (float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.order),
                                  (const uint32_t*)(gb + GL.point_offsets), (const uint32_t*)(gb + GL.flags),
-                                 (const float*)(gb + GL.cull_thr), keys_u,
-                                 vals_u, gid_u, (uint32_t)R, pad, ranges, packed, status, s)) return e;
-    int tile_bits = 0;
-    while ((1 << tile_bits) < tiles) ++tile_bits;
+                                 (const float*)(gb + GL.cull_thr), K0, V0, gid_u, (uint32_t)R, ranges, packed, status,
+                                 sort_count, tp, partials, zero, (uint32_t)BL.tsort_zero_words, s)) return e;
     {
       ProfScope p(K_SORT, s);
-      size_t tmp = BL.sort_temp_bytes;
-      const int bits = tile_bits > 0 ? tile_bits : 1;
-      if (packed)
-        INSTAG_CHECK_HIP(tile_sort(bb + BL.sort_temp, tmp, keys_u, keys, nullptr, nullptr, (size_t)R, PACK_SHIFT, bits, pad, s));
-      else
-        INSTAG_CHECK_HIP(tile_sort(bb + BL.sort_temp, tmp, keys_u, keys, vals_u, vals, (size_t)R, 0, bits, pad, s));
+      if (int e = launch_hist_reduce(partials, (int)duplicate_blocks(a->N), tp.npass, HIST_SLICES, digit_base, s))
+        return e;
+      // K0 -> [K2 ->] [K1 -> K2 ->] K1: the last pass always lands in `keys` / `vals`
+      const uint32_t *kin = K0, *vin = packed ? nullptr : V0;
+      for (int pass = 0; pass < tp.npass; ++pass) {
+        const bool to_final = ((tp.npass - 1 - pass) % 2) == 0;
+        uint32_t* kout = to_final ? K1 : K2;
+        uint32_t* vout = packed ? nullptr : (to_final ? V1 : V2);
+        if (int e = launch_radix_pass(SORT_IPT_TILE, !packed, true, kin, kout, vin, vout, sort_count, (uint32_t)R,
+                                      (packed ? PACK_SHIFT : 0) + pass * tp.bits_per, tp.nbits[pass],
+                                      digit_base + 256 * pass, HIST_SLICES, tp.npass * 256, zero + pass,
+                                      zero + 16 + (size_t)pass * BL.tsort_blocks * 256, s)) return e;
+        kin = kout; vin = vout;
+      }
     }
-    if (int e = launch_ranges(R, keys, vals, gid_u, point_list, ranges, (uint32_t)tiles, packed, s)) return e;
+    if (int e = launch_ranges(R, sort_count, K1, V1, gid_u, point_list, ranges, (uint32_t)tiles, packed, s)) return e;
   } else {
     INSTAG_CHECK_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(int32_t), s));
   }
@@ -309,7 +320,7 @@ int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t
                                  float* out_extra, const float* aux_colors, float* out_aux,
                                  instag_stream_t stream_) {
   if (int e = validate(a)) return e;
-  return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, R, false, out_color,
+  return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, R, out_color,
                       out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux, nullptr, (hipStream_t)stream_);
 }
 
@@ -329,10 +340,10 @@ int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size
   if (a->N > 0) {
     if (int e = per_gaussian_stage(a, c, gb, L, radii, s)) return e;
   } else {
-    INSTAG_CHECK_HIP(hipMemsetAsync(status, 0, 2 * sizeof(int32_t), s));
+    INSTAG_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), s));       // [0] = instances needed = 0
   }
-  // [R needed, overflow] is written by the duplicate kernel
-  return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, capacity, true, out_color,
+  // the status words are written by the duplicate kernel
+  return forward_tail(a, geom, geom_bytes, binning, binning_bytes, image, image_bytes, capacity, out_color,
                       out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux, status, s);
 }
 
@@ -453,6 +464,23 @@ int instag_raster_debug_export_flags(const void* geom, size_t geom_bytes, int32_
                                     (hipStream_t)stream_));
   return INSTAG_OK;
 }
+
+/* diagnostics: the depth sort alone on the caller's stream, with per-block phase timestamps (100 MHz ticks, [4 passes]
+ * [blocks][8]: block start, keys loaded, ranked, local scans done, look-back done, -, stores issued) */
+int instag_debug_depth_sort(const instag_raster_args* a, void* geom, size_t geom_bytes, uint64_t* stamps,
+                            uint32_t* order_out, instag_stream_t stream_) {
+  INSTAG_REQUIRE(a != nullptr && a->N > 0, "debug_depth_sort: N must be positive");
+  const GeomLayout L = geom_layout(a->N);
+  if (geom_bytes < L.total) { set_error("geom buffer too small"); return INSTAG_E_SPACE; }
+  const Camera c = make_camera(a);
+  if (int e = depth_sort(c, a, (char*)geom, L, (hipStream_t)stream_, stamps)) return e;
+  if (order_out)
+    INSTAG_CHECK_HIP(hipMemcpyAsync(order_out, (char*)geom + L.order, (size_t)a->N * 4, hipMemcpyDeviceToDevice,
+                                    (hipStream_t)stream_));
+  return INSTAG_OK;
+}
+
+uint32_t instag_debug_depth_sort_blocks(int32_t N) { return geom_layout(N).dsort_blocks; }
 
 int instag_prof_enable(int mask) {
   ProfState& p = prof();

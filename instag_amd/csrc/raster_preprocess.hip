@@ -69,12 +69,12 @@ struct PreIn {
 __global__ void __launch_bounds__(256)
 preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restrict__ cov3d,
                   uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ flags_out,
-                  float* __restrict__ cull_thr, uint32_t* __restrict__ depth_key, uint32_t* __restrict__ order_in,
-                  int32_t* __restrict__ radii) {
+                  float* __restrict__ cull_thr, int32_t* __restrict__ radii,
+                  uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
   const int g = blockIdx.x * 256 + threadIdx.x;
+  // housekeeping for a later launch: the look-back state of the instance-offset scan starts out zero
+  for (uint32_t k = (uint32_t)g; k < n_zero_words; k += gridDim.x * 256u) zero_words[k] = 0u;
   if (g >= c.N) return;
-  depth_key[g] = 0xFFFFFFFFu;      // Gaussians without instances sort last
-  order_in[g] = (uint32_t)g;
   radii[g] = 0;
   tiles_touched[g] = 0;
   const float* __restrict__ V = c.view;
@@ -249,7 +249,6 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
   cull_thr[g] = thr;
   radii[g] = radius;
   tiles_touched[g] = (uint32_t)kept;
-  if (kept > 0) depth_key[g] = __float_as_uint(tz);
   flags_out[g] = flags | ((uint32_t)(rmaxy - rminy) << 16);   // bits 16..31: rectangle height in tiles
   float* c3 = cov3d + (size_t)g * 6;
   c3[0] = S00; c3[1] = S01; c3[2] = S02; c3[3] = S11; c3[4] = S12; c3[5] = S22;
@@ -262,79 +261,152 @@ preprocess_kernel(Camera c, PreIn in, float* __restrict__ rec2d, float* __restri
   rec[3] = make_float4(nvz, (c.E > 0 && in.extra) ? in.extra[g] : 0.0f, 0.0f, __uint_as_float(rect));
 }
 
-// One thread per Gaussian, in DEPTH ORDER: emit the tile id of every KEPT tile of its rectangle (the depth half of
-// the published (tile<<32 | depth) key is implied by the emission order + a stable sort).  The sorted value
-// is the instance's own unsorted slot u (also the row of its gradient in blend-backward); gid_unsorted[u] maps
-// the slot back to the Gaussian.  The exclusive instance offset is recorded in the blend record.
-// SIXTEEN lanes per Gaussian: lane q tests tile q, q+16, ... of the Gaussian's rectangle (row-major, the emission
-// order), the kept ones are compacted with a ballot.  (One thread per Gaussian walked ~16 rectangle tiles with four
-// divisions each in series, on 1.5 waves per SIMD.)
+// Depth keys of ALL Gaussians (the float bits of view-space z, the same expression as in preprocess_kernel: this TU is
+// compiled without FMA contraction) + the per-block digit histograms of the four 8-bit passes of the depth sort + the
+// clearing of that sort's tickets and look-back words.  It depends on means3D and the view matrix only, so the whole
+// depth sort runs BESIDE preprocess_kernel on a second stream.  Culled Gaussians (z <= 0.2, no kept tile) take part in
+// the sort, wherever they land: they emit no instance, so the instance order -- Gaussians with instances by
+// (depth bits, index) -- is that of the published (tile << 32 | depth) key sort.
+constexpr int DK_IPT = 4, DK_THREADS = 1024;   // 4,096 keys per block: 25 partial histograms for 100k Gaussians
+__global__ void __launch_bounds__(DK_THREADS)
+depth_key_kernel(int N, const float* __restrict__ view, const float* __restrict__ means3D,
+                 uint32_t* __restrict__ depth_key, uint32_t* __restrict__ partials,
+                 uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
+  __shared__ uint32_t s_h[4][256];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < 4 * 256; k += DK_THREADS) (&s_h[0][0])[k] = 0u;
+  for (uint32_t k = blockIdx.x * DK_THREADS + tid; k < n_zero_words; k += gridDim.x * DK_THREADS) zero_words[k] = 0u;
+  __syncthreads();
+  const float v2 = view[2], v6 = view[6], v10 = view[10], v14 = view[14];
+  float pos[DK_IPT][3];
+#pragma unroll
+  for (int k = 0; k < DK_IPT; ++k) {                      // unconditional loads (index clamped), back to back
+    const int g = min((blockIdx.x * DK_IPT + k) * DK_THREADS + tid, N - 1);
+    pos[k][0] = means3D[3 * g + 0]; pos[k][1] = means3D[3 * g + 1]; pos[k][2] = means3D[3 * g + 2];
+  }
+#pragma unroll
+  for (int k = 0; k < DK_IPT; ++k) {
+    const int g = (blockIdx.x * DK_IPT + k) * DK_THREADS + tid;
+    if (g < N) {
+      const float tz = ((v2 * pos[k][0] + v6 * pos[k][1]) + v10 * pos[k][2]) + v14;
+      const uint32_t key = __float_as_uint(tz);
+      depth_key[g] = key;
+      atomicAdd(&s_h[0][key & 255u], 1u);
+      atomicAdd(&s_h[1][(key >> 8) & 255u], 1u);
+      atomicAdd(&s_h[2][(key >> 16) & 255u], 1u);
+      atomicAdd(&s_h[3][key >> 24], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* out = partials + (size_t)blockIdx.x * 4 * 256;
+  for (int k = tid; k < 4 * 256; k += DK_THREADS) out[k] = (&s_h[0][0])[k];
+}
+
+// Sixteen lanes per Gaussian, Gaussians in DEPTH ORDER: emit the tile id of every KEPT tile of its rectangle (the
+// depth half of the published (tile<<32 | depth) key is implied by the emission order + a stable sort).  Lane q tests
+// tile q, q+16, ... of the rectangle (row-major, the emission order), the kept ones are compacted with a ballot.
+// The sorted value is the instance's own unsorted slot u (also the row of its gradient in blend-backward);
+// gid_unsorted[u] maps the slot back to the Gaussian.  The exclusive instance offset is recorded in the blend record.
+//
+// The kernel also prepares the instance sort that follows it: per-block histograms of the tile-id digits (LDS integer
+// atomics, written out with plain stores: the sort needs no zero-initialised global counters), the clearing of the
+// sort's tickets / look-back words and of the tile ranges, the number of instances to sort (a device word: unused
+// capacity is neither padded nor sorted) and, in capacity mode, the status words.
 constexpr int DUP_LANES = 16;
 constexpr int DUP_PER_BLOCK = 256 / DUP_LANES;
 
 __global__ void __launch_bounds__(256)
-duplicate_kernel(int N, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ order,
+duplicate_kernel(int N, int ngroups, int grid_x, float* __restrict__ rec2d, const uint32_t* __restrict__ order,
                  const uint32_t* __restrict__ point_offsets,
                  const uint32_t* __restrict__ flags, const float* __restrict__ cull_thr,
                  uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ gid_unsorted,
-                 uint32_t capacity, uint32_t pad_to, int32_t* __restrict__ ranges, uint32_t nranges, int packed,
-                 int32_t* __restrict__ status) {
+                 uint32_t capacity, int32_t* __restrict__ ranges, uint32_t nranges, int packed,
+                 int32_t* __restrict__ status, uint32_t* __restrict__ sort_count, TilePasses tp,
+                 uint32_t* __restrict__ partials, uint32_t* __restrict__ zero_words, uint32_t n_zero_words) {
+  __shared__ uint32_t s_dh[3][256];
   const uint32_t gtid = blockIdx.x * 256u + threadIdx.x;
-  if (status != nullptr && gtid == 0) {
-    // capacity mode: publish the instance count and the overflow flag without a host round trip
+  const uint32_t total = gridDim.x * 256u;
+  for (int k = threadIdx.x; k < 3 * 256; k += 256) (&s_dh[0][0])[k] = 0u;
+  if (gtid == 0) {
+    // instances that fit: all of them, or (capacity mode, overflow) those of the Gaussians in front of the first one
+    // whose slots would cross the capacity -- the offsets are non-decreasing, so a binary search finds it
     const uint32_t R = point_offsets[N - 1];
-    status[0] = (int32_t)R;
-    status[1] = R > capacity ? 1 : 0;
+    uint32_t used = R;
+    if (R > capacity) {
+      int lo = 0, hi = N;                         // first rank whose inclusive offset exceeds the capacity
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (point_offsets[mid] > capacity) hi = mid; else lo = mid + 1;
+      }
+      used = lo > 0 ? point_offsets[lo - 1] : 0u;
+    }
+    *sort_count = used;
+    if (status != nullptr) {
+      // [0] instances needed by this call, [1] STICKY overflow flag (the host clears it), [2] largest need seen since
+      // the host last cleared it, [3] instances actually binned by this call
+      status[0] = (int32_t)R;
+      status[1] = status[1] | (R > capacity ? 1 : 0);
+      status[2] = max(status[2], (int32_t)R);
+      status[3] = (int32_t)used;
+    }
   }
-  // housekeeping that used to be two memsets: unused instance slots get all-ones keys (they sort last and own no
-  // tile range), the tile ranges start out empty
-  {
-    const uint32_t total = gridDim.x * 256u;
-    const uint32_t used = min(point_offsets[N - 1], capacity);
-    for (uint32_t k = used + gtid; k < pad_to; k += total) keys[k] = 0xFFFFFFFFu;
-    for (uint32_t k = gtid; k < nranges; k += total) ranges[k] = 0;
-  }
-  const int i = blockIdx.x * DUP_PER_BLOCK + (threadIdx.x / DUP_LANES);      // rank in depth order
+  // housekeeping that used to be memset nodes: tile ranges start out empty, the sort's tickets / look-back words zero
+  for (uint32_t k = gtid; k < nranges; k += total) ranges[k] = 0;
+  for (uint32_t k = gtid; k < n_zero_words; k += total) zero_words[k] = 0u;
+  __syncthreads();
+
   const int q = threadIdx.x % DUP_LANES;
   const int grp_shift = ((threadIdx.x & 63) / DUP_LANES) * DUP_LANES;        // position of the group's bits in a ballot
-  uint32_t tt = 0, off = 0, g = 0;
-  bool work = i < N;
-  if (work) {
-    tt = point_offsets[i] - (i > 0 ? point_offsets[i - 1] : 0u);            // kept tiles of this Gaussian
-    // capacity mode: instances beyond the buffer are dropped (flagged)
-    work = tt != 0 && point_offsets[i] <= capacity;
-  }
-  int rminx = 0, rminy = 0, rw = 1, ntiles = 0;
-  float px = 0.f, py = 0.f, A = 0.f, B = 0.f, C = 0.f, thr = -1.f;
-  if (work) {
-    g = order[i];
-    off = point_offsets[i] - tt;
-    float* rec = rec2d + (size_t)g * REC_FLOATS;
-    const uint32_t rect = __float_as_uint(rec[R_RECT]);
-    if (q == 0) rec[R_OFFSET] = __uint_as_float(off);
-    rminx = (int)(rect & 1023u); rminy = (int)((rect >> 10) & 1023u); rw = (int)(rect >> 20);
-    ntiles = rw * (int)(flags[g] >> 16);
-    px = rec[R_X]; py = rec[R_Y]; A = rec[R_CA]; B = rec[R_CB]; C = rec[R_CC]; thr = cull_thr[g];
-  }
-  // (all 16 lanes of a group share `ntiles`; groups of one wave may differ: a finished group's ballot bits are 0)
-  for (int t0 = 0; t0 < ntiles; t0 += DUP_LANES) {
-    const int t = t0 + q;
-    const int y = rminy + t / rw, x = rminx + t % rw;
-    const bool kept = t < ntiles && tile_kept(px, py, A, B, C, thr, x, y);
-    const uint32_t bits = (uint32_t)(__builtin_amdgcn_ballot_w64(kept) >> grp_shift) & ((1u << DUP_LANES) - 1u);
-    if (kept) {
-      const uint32_t o = off + (uint32_t)__builtin_popcount(bits & ((1u << q) - 1u));
-      const uint32_t tile = (uint32_t)(y * grid_x + x);
-      if (packed) {
-        keys[o] = (tile << PACK_SHIFT) | o;              // key-only sort: the slot rides in the low bits
-      } else {
-        keys[o] = tile;
-        vals[o] = o;
-      }
-      gid_unsorted[o] = g;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int i = grp * DUP_PER_BLOCK + (threadIdx.x / DUP_LANES);          // rank in depth order
+    uint32_t tt = 0, off = 0, g = 0;
+    bool work = i < N, fits = false;
+    if (work) {
+      const uint32_t po = point_offsets[i];
+      tt = po - (i > 0 ? point_offsets[i - 1] : 0u);                         // kept tiles of this Gaussian
+      off = po - tt;
+      fits = po <= capacity;                  // capacity mode: instances beyond the buffer are dropped (flagged)
+      work = tt != 0;
     }
-    off += (uint32_t)__builtin_popcount(bits);
+    int rminx = 0, rminy = 0, rw = 1, ntiles = 0;
+    float px = 0.f, py = 0.f, A = 0.f, B = 0.f, C = 0.f, thr = -1.f;
+    if (work) {
+      g = order[i];
+      float* rec = rec2d + (size_t)g * REC_FLOATS;
+      // (also for a dropped Gaussian: the backward recognises it by offset + count > capacity)
+      if (q == 0) rec[R_OFFSET] = __uint_as_float(off);
+      if (fits) {
+        const uint32_t rect = __float_as_uint(rec[R_RECT]);
+        rminx = (int)(rect & 1023u); rminy = (int)((rect >> 10) & 1023u); rw = (int)(rect >> 20);
+        ntiles = rw * (int)(flags[g] >> 16);
+        px = rec[R_X]; py = rec[R_Y]; A = rec[R_CA]; B = rec[R_CB]; C = rec[R_CC]; thr = cull_thr[g];
+      }
+    }
+    // (all 16 lanes of a group share `ntiles`; groups of one wave may differ: a finished group's ballot bits are 0)
+    for (int t0 = 0; t0 < ntiles; t0 += DUP_LANES) {
+      const int t = t0 + q;
+      const int y = rminy + t / rw, x = rminx + t % rw;
+      const bool kept = t < ntiles && tile_kept(px, py, A, B, C, thr, x, y);
+      const uint32_t bits = (uint32_t)(__builtin_amdgcn_ballot_w64(kept) >> grp_shift) & ((1u << DUP_LANES) - 1u);
+      if (kept) {
+        const uint32_t o = off + (uint32_t)__builtin_popcount(bits & ((1u << q) - 1u));
+        const uint32_t tile = (uint32_t)(y * grid_x + x);
+        if (packed) {
+          keys[o] = (tile << PACK_SHIFT) | o;              // key-only sort: the slot rides in the low bits
+        } else {
+          keys[o] = tile;
+          vals[o] = o;
+        }
+        gid_unsorted[o] = g;
+        for (int p = 0; p < tp.npass; ++p)
+          atomicAdd(&s_dh[p][(tile >> (p * tp.bits_per)) & ((1u << tp.nbits[p]) - 1u)], 1u);
+      }
+      off += (uint32_t)__builtin_popcount(bits);
+    }
   }
+  __syncthreads();
+  uint32_t* out = partials + (size_t)blockIdx.x * tp.npass * 256;
+  for (int k = threadIdx.x; k < tp.npass * 256; k += 256) out[k] = (&s_dh[0][0])[k];
 }
 
 // debug / parity: the 64-bit (tile<<32 | depth bits) key of every sorted instance
@@ -349,13 +421,14 @@ export_keys_kernel(int64_t R, const uint32_t* __restrict__ tile_keys, const uint
 }
 
 __global__ void __launch_bounds__(256)
-ranges_kernel(int64_t R, const uint32_t* __restrict__ keys, uint32_t* __restrict__ slots_sorted,
+ranges_kernel(const uint32_t* __restrict__ count_ptr, const uint32_t* __restrict__ keys,
+              uint32_t* __restrict__ slots_sorted,
               const uint32_t* __restrict__ gid_unsorted, uint32_t* __restrict__ point_list,
               int32_t* __restrict__ ranges, uint32_t ntiles, int packed) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t R = (int64_t)*count_ptr;         // instances actually binned (device word written by duplicate_kernel)
   if (i >= R) return;
-  // tile ids >= ntiles are the all-ones padding keys of capacity mode: they sort last and own no range
-  auto tile_of = [&](uint32_t k) { return packed ? (k == 0xFFFFFFFFu ? 0xFFFFFFFFu : k >> PACK_SHIFT) : k; };
+  auto tile_of = [&](uint32_t k) { return packed ? k >> PACK_SHIFT : k; };
   const uint32_t key = keys[i];
   const uint32_t tile = tile_of(key);
   if (tile < ntiles) {
@@ -394,27 +467,43 @@ Camera make_camera(const instag_raster_args* a) {
 }
 
 int launch_preprocess(const Camera& c, const instag_raster_args* a, float* rec2d, float* cov3d,
-                      uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, uint32_t* depth_key,
-                      uint32_t* order_in, int32_t* radii, hipStream_t s) {
+                      uint32_t* tiles_touched, uint32_t* flags, float* cull_thr, int32_t* radii,
+                      uint32_t* zero_words, uint32_t n_zero_words, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   PreIn in{a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales, a->rotations,
            a->cov3Ds_precomp, a->extra_attrs, a->shs_rest};
   ProfScope p(K_PREPROCESS, s);
-  preprocess_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, in, rec2d, cov3d, tiles_touched, flags, cull_thr, depth_key,
-                                                     order_in, radii);
+  preprocess_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, in, rec2d, cov3d, tiles_touched, flags, cull_thr, radii,
+                                                     zero_words, n_zero_words);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
+uint32_t depth_key_blocks(int32_t N) { return (uint32_t)div_up(std::max(N, 1), DK_THREADS * DK_IPT); }
+
+int launch_depth_keys(const Camera& c, const float* means3D, uint32_t* depth_key, uint32_t* partials,
+                      uint32_t* zero_words, uint32_t n_zero_words, hipStream_t s) {
+  if (c.N == 0) return INSTAG_OK;
+  depth_key_kernel<<<depth_key_blocks(c.N), DK_THREADS, 0, s>>>(c.N, c.view, means3D, depth_key, partials, zero_words,
+                                                             n_zero_words);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+uint32_t duplicate_blocks(int32_t N) { return (uint32_t)std::min(div_up(std::max(N, 1), DUP_PER_BLOCK), 1024); }
+
 int launch_duplicate(const Camera& c, float* rec2d, const uint32_t* order,
                      const uint32_t* point_offsets, const uint32_t* flags, const float* cull_thr, uint32_t* keys,
-                     uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, bool pad, int32_t* ranges,
-                     bool packed, int32_t* status, hipStream_t s) {
+                     uint32_t* vals, uint32_t* gid_unsorted, uint32_t capacity, int32_t* ranges,
+                     bool packed, int32_t* status, uint32_t* sort_count, const TilePasses& tp, uint32_t* partials,
+                     uint32_t* zero_words, uint32_t n_zero_words, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_DUPLICATE, s);
-  duplicate_kernel<<<div_up(c.N, DUP_PER_BLOCK), 256, 0, s>>>(c.N, c.grid_x, rec2d, order, point_offsets, flags,
-                                                     cull_thr, keys, vals, gid_unsorted, capacity, pad ? capacity : 0u,
-                                                     ranges, (uint32_t)(2 * c.grid_x * c.grid_y), packed ? 1 : 0, status);
+  const int ngroups = div_up(c.N, DUP_PER_BLOCK);
+  duplicate_kernel<<<duplicate_blocks(c.N), 256, 0, s>>>(c.N, ngroups, c.grid_x, rec2d, order, point_offsets, flags,
+                                                         cull_thr, keys, vals, gid_unsorted, capacity, ranges,
+                                                         (uint32_t)(2 * c.grid_x * c.grid_y), packed ? 1 : 0, status,
+                                                         sort_count, tp, partials, zero_words, n_zero_words);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -428,11 +517,12 @@ int launch_export_keys(int64_t R, const uint32_t* tile_keys, const uint32_t* poi
   return INSTAG_OK;
 }
 
-int launch_ranges(int64_t R, const uint32_t* keys_sorted, uint32_t* slots_sorted, const uint32_t* gid_unsorted,
-                  uint32_t* point_list, int32_t* ranges, uint32_t ntiles, bool packed, hipStream_t s) {
+int launch_ranges(int64_t R, const uint32_t* count_ptr, const uint32_t* keys_sorted, uint32_t* slots_sorted,
+                  const uint32_t* gid_unsorted, uint32_t* point_list, int32_t* ranges, uint32_t ntiles, bool packed,
+                  hipStream_t s) {
   if (R == 0) return INSTAG_OK;
   ProfScope p(K_RANGES, s);
-  ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(R, keys_sorted, slots_sorted, gid_unsorted,
+  ranges_kernel<<<(unsigned)div_up<int64_t>(R, 256), 256, 0, s>>>(count_ptr, keys_sorted, slots_sorted, gid_unsorted,
                                                                   point_list, ranges, ntiles, packed ? 1 : 0);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;

@@ -61,12 +61,13 @@ class CapacityPlan:
     """Sync-free (hipGraph-capturable) mode of the rasterizer.
 
     The k-th rasterizer call of a step uses the fixed instance capacity ``capacities[k]`` instead of
-    reading the instance count back to the host, and reports (needed R, overflow flag) into the
-    static device tensor ``status[k]``.  Call ``begin_step()`` before every step (eager or capture)."""
+    reading the instance count back to the host, and reports into the static device tensor ``status[k]``
+    (int32[4]: instances needed by the last call, STICKY overflow flag, largest need since the last clear(),
+    instances binned by the last call).  Call ``begin_step()`` before every step (eager or capture)."""
 
     def __init__(self, capacities, device):
         self.capacities = [int(c) for c in capacities]
-        self.status = [torch.zeros(2, dtype=torch.int32, device=device) for _ in self.capacities]
+        self.status = [torch.zeros(4, dtype=torch.int32, device=device) for _ in self.capacities]
         self.index = 0
 
     def begin_step(self):
@@ -80,12 +81,22 @@ class CapacityPlan:
         return self.capacities[k], self.status[k]
 
     def overflowed(self):
-        """Host check (synchronises): list of (slot, needed R) whose capacity was exceeded."""
+        """Host check (synchronises): list of (slot, largest R needed) of every slot whose capacity was exceeded by ANY
+        call since the last clear() -- the flag is sticky on the device, so a check after many replays misses nothing."""
         st = torch.stack(self.status).cpu()
-        return [(k, int(st[k, 0])) for k in range(len(self.capacities)) if int(st[k, 1]) != 0]
+        return [(k, int(st[k, 2])) for k in range(len(self.capacities)) if int(st[k, 1]) != 0]
 
     def needed(self):
+        """Instances the most recent call of every slot needed."""
         return [int(v) for v in torch.stack(self.status).cpu()[:, 0]]
+
+    def peak(self):
+        """Largest need of every slot since the last clear()."""
+        return [int(v) for v in torch.stack(self.status).cpu()[:, 2]]
+
+    def clear(self):
+        for s in self.status:
+            s.zero_()
 
 
 _CAPACITY_PLAN = None

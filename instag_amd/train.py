@@ -409,6 +409,16 @@ class FaceTrainer:
         if self._graph is not None:
             self._graph.replay(frame)
             loss, Ll1 = self._graph.loss, self._graph.l1
+            if self._graph.overflow_due():
+                # some replayed step needed more instances than the captured capacity (its image was truncated to the
+                # nearest Gaussians, gradients of the dropped ones zero): capture again, sized from the peak need
+                peak = max(self._graph.plan.peak())
+                phases = list(self._graph_cache) or [self._graph_phase]
+                self._drop_graph()
+                for ph in phases:
+                    self.enable_graph(frame, phase=ph, min_capacity=int(1.4 * peak) + 4096)
+                self._graph = self._graph_cache.get(phase)
+                self._graph_phase = phase if self._graph is not None else None
         else:
             from . import diff_gauss
             if diff_gauss._CAPACITY_PLAN is not None:
@@ -419,9 +429,35 @@ class FaceTrainer:
         self.last = dict(loss=loss.detach(), l1=Ll1.detach(), num_points=self.g.num_points, phase=phase)
         return self.last
 
+    # ---- state snapshot (benchmark windows start from the same state; in place, so captured graphs stay valid) ----
+    def _state_tensors(self):
+        ts = [p.data for p in self._all_params()]
+        for opt_ in (self.motion_optimizer, self.g.optimizer):
+            for grp in opt_.param_groups:
+                for p in grp["params"]:
+                    st = opt_.state.get(p) if hasattr(opt_.state, "get") else None
+                    if st:
+                        ts += [st[k] for k in ("exp_avg", "exp_avg_sq", "step") if torch.is_tensor(st.get(k))]
+        ts += [self.g.xyz_gradient_accum, self.g.denom, self.g.max_radii2D]
+        return ts
+
+    @torch.no_grad()
+    def snapshot(self):
+        return dict(iteration=self.iteration, tensors=[t.detach().clone() for t in self._state_tensors()])
+
+    @torch.no_grad()
+    def restore(self, snap):
+        """Copy a snapshot() back IN PLACE (same parameter set required: no densification in between)."""
+        live = self._state_tensors()
+        assert len(live) == len(snap["tensors"]), "the parameter / optimizer-state set changed since the snapshot"
+        for dst, src in zip(live, snap["tensors"]):
+            dst.copy_(src)
+        self.iteration = snap["iteration"]
+
     # ---- graph mode --------------------------------------------------------------------------------------------
     def enable_graph(self, example_frame: Frame, headroom: float = 1.4, warmup_steps: int = 3,
-                     split_for_allreduce: Optional[bool] = None, phase: Optional[FacePhase] = None):
+                     split_for_allreduce: Optional[bool] = None, phase: Optional[FacePhase] = None,
+                     min_capacity: int = 0):
         """Capture the whole step into a hipGraph.  Runs `warmup_steps` eager steps plus two capacity-mode steps
         first (they advance the iteration counter like any other step) to measure the instance counts and warm
         every library.  The graph holds the launches of one phase (FacePhase): `phase`, or the phase of the iteration
@@ -433,7 +469,8 @@ class FaceTrainer:
         self._graph = None
         if phase is None:
             phase = self.phase_of(self.iteration + max(1, warmup_steps) + 3)   # the iteration right after capture
-        self._graph = GraphedStep(self, example_frame, headroom, warmup_steps, split_for_allreduce, phase)
+        self._graph = GraphedStep(self, example_frame, headroom, warmup_steps, split_for_allreduce, phase,
+                                  min_capacity=min_capacity)
         self._graph_phase = phase
         self._graph_cache[phase] = self._graph
         return self._graph
@@ -457,8 +494,10 @@ class _no_gc:
 
 
 class GraphedStep:
+    CHECK_EVERY = 64         # replays between two looks at the (sticky, device-side) overflow flags
+
     def __init__(self, trainer: FaceTrainer, example: Frame, headroom: float, warmup_steps: int,
-                 split_for_allreduce: Optional[bool] = None, phase: FacePhase = C3_PHASE):
+                 split_for_allreduce: Optional[bool] = None, phase: FacePhase = C3_PHASE, min_capacity: int = 0):
         from . import diff_gauss
         self.phase = phase
         t = self.trainer = trainer
@@ -479,8 +518,9 @@ class GraphedStep:
             t._zero_grad()
             del pkg        # a live autograd graph keeps grad accumulators bound to this (non-capture) stream
             needed = max(needed, diff_gauss.LAST_STATS["num_rendered"])
-        cap = int(needed * headroom) + 4096
+        cap = max(int(needed * headroom) + 4096, int(min_capacity))
         self.plan = diff_gauss.CapacityPlan([cap, cap], dev)
+        self._replays = 0
         diff_gauss.set_capacity_plan(self.plan)
         # 2. one eager step in capacity mode on a side stream (allocator / library warm-up for capture)
         s = torch.cuda.Stream(device=dev)
@@ -532,6 +572,7 @@ class GraphedStep:
         self.capacity = cap
 
     def replay(self, frame: Frame):
+        self._replays += 1
         self.static.copy_from(frame)
         self.graph_a.replay()
         if self.graph_b is not None:
@@ -540,8 +581,16 @@ class GraphedStep:
             self.graph_b.replay()
 
     def check_overflow(self):
-        """Host-side (synchronising) check that no replayed step exceeded the instance capacity."""
+        """Host-side (synchronising) check that no replayed step exceeded the instance capacity (the device flag is
+        sticky: every step since the capture / the last clear counts)."""
         return self.plan.overflowed()
+
+    def overflow_due(self):
+        """True every CHECK_EVERY replays if a replayed step overflowed (one synchronising read per CHECK_EVERY steps)."""
+        if self._replays < self.CHECK_EVERY:
+            return False
+        self._replays = 0
+        return bool(self.plan.overflowed())
 
 
 def build_trainer(n_gaussians, device, sh_degree=1, seed=0, densify=False, encoder_cls=None, raw=None):

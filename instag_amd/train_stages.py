@@ -147,13 +147,25 @@ class GraphedStage:
         self.out = tuple(out[:-1])
         del out
 
+    CHECK_EVERY = 64         # replays between two looks at the (sticky, device-side) overflow flags
+
     def replay(self, frame: Frame):
         self.static.copy_from(frame)
         self.graph.replay()
+        self._replays = getattr(self, "_replays", 0) + 1
         return self.out
 
     def check_overflow(self):
         return self.plan.overflowed()
+
+    def overflow_due(self):
+        """True every CHECK_EVERY replays if some rasterizer call of a replayed step needed more instances than its
+        capacity (the flag is sticky on the device, one synchronising read per CHECK_EVERY steps): the caller drops the
+        graph -- steps run eagerly, or are captured again with larger capacities."""
+        if getattr(self, "_replays", 0) < self.CHECK_EVERY:
+            return False
+        self._replays = 0
+        return bool(self.plan.overflowed())
 
 
 def _drop_graph(trainer):
@@ -315,6 +327,8 @@ class MouthTrainer:
         if self._graph is not None:
             self._k_dev.fill_(k)
             loss, Ll1 = self._graph.replay(frame)[:2]
+            if self._graph.overflow_due():
+                _drop_graph(self)               # the scene outgrew the captured capacities: eager launches from here on
         else:
             from . import diff_gauss
             if diff_gauss._CAPACITY_PLAN is not None:
@@ -400,6 +414,8 @@ class FuseTrainer:
             _drop_graph(self)
         if self._graph is not None:
             loss, Ll1, image = self._graph.replay(frame)[:3]
+            if self._graph.overflow_due():
+                _drop_graph(self)
         elif it < self.opt.iterations:
             from . import diff_gauss
             if diff_gauss._CAPACITY_PLAN is not None:
