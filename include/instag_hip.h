@@ -174,7 +174,12 @@ int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size
 /* backward.  dL_dout_* may be NULL (treated as zero).  Gradient outputs may be NULL when not
  * needed; non-NULL ones are fully written (not accumulated).  dL_dmeans2D is [N,3]
  * (x,y in NDC units = pixel gradient * 0.5*(W,H); z = 0), the quantity
- * scene/gaussian_model.py:684 consumes. */
+ * scene/gaussian_model.py:684 consumes.
+ * aux_colors [N,3] + dL_dout_aux [3,H,W] (both or neither): the auxiliary image of the forward call is differentiated
+ * too -- dL_daux_colors [N,3] is written and the aux image's share of the screen-space mean gradient is ADDED into
+ * dL_dmeans2D (only there: the reference renders the attention map from detached geometry, gaussian_renderer/
+ * __init__.py:256-268).  With an rgb-only main pass (no depth / normal / extra gradient) this costs no extra launch:
+ * the blend kernel carries both images through one alpha / T recurrence. */
 int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes,
                            const void* binning, size_t binning_bytes, const void* image,
                            size_t image_bytes, int64_t R, const int32_t* radii,
@@ -185,6 +190,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                            float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
                            float* dL_dshs_rest /* [N,M-1,3], with split SH storage: then dL_dshs is [N,1,3] */,
+                           const float* aux_colors, const float* dL_dout_aux, float* dL_daux_colors,
                            instag_stream_t stream);
 
 /* backward of the auxiliary colour set over the forward's state: dL_dout_aux [3,H,W] -> dL_daux_colors [N,3] and
@@ -329,11 +335,14 @@ int instag_knn3_mean_dist2(const float* points, float* out, int32_t N, instag_st
  *   24-25 exp_encode_net.net.{0,1}.weight                  [16,5], [5,16] (may be NULL when e is NULL)
  * forward keeps every activation in `saved` (instag_frame_code_saved_floats floats); backward OVERWRITES
  * every grads[i] (same shapes as params[i]); no gradient flows to a or e.  Deterministic (no atomics).
+ * arrivals (device uint32, ZERO before the first call, owned by ONE network: calls that may overlap on different
+ * streams need words of their own): the forward runs as one workgroup per audio window, the last one to arrive runs
+ * the attention stage and leaves the word zero again.  NULL selects the single-workgroup form.
  * ------------------------------------------------------------------------------------------ */
 int64_t instag_frame_code_saved_floats(int32_t dim_in, int32_t mid, int32_t dim_aud);
 int instag_frame_code_forward(const float* a, const float* e, const float* const* params, float* enc_a,
                               float* enc_e, float* saved, int32_t dim_in, int32_t mid, int32_t dim_aud,
-                              instag_stream_t stream);
+                              uint32_t* arrivals, instag_stream_t stream);
 int instag_frame_code_backward(const float* a, const float* e, const float* const* params, const float* saved,
                                const float* d_enc_a, const float* d_enc_e, float* const* grads, int32_t dim_in,
                                int32_t mid, int32_t dim_aud, instag_stream_t stream);

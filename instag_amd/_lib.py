@@ -99,7 +99,7 @@ _PROTOS = {
     "instag_knn3_mean_dist2": (C.c_int, [vp, vp, i32, vp]),
     "instag_densify_stats": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
     "instag_frame_code_saved_floats": (C.c_int64, [i32, i32, i32]),
-    "instag_frame_code_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "instag_frame_code_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "instag_frame_code_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "instag_l1_ssim_num_partials": (C.c_int, [i32, i32, i32]),
     "instag_l1_ssim_forward": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),

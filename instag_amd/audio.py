@@ -26,7 +26,7 @@ def _ptr_array(tensors):
 
 class _FrameCodes(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, e, dims, *params):
+    def forward(ctx, a, e, dims, arrivals, *params):
         L = _lib.lib()
         dim_in, mid, dim_aud = dims
         a = a.contiguous().float()
@@ -42,7 +42,8 @@ class _FrameCodes(torch.autograd.Function):
             enc_e = torch.empty(6, dtype=torch.float32, device=dev)
         saved = torch.empty(n_saved, dtype=torch.float32, device=dev)
         check(L.instag_frame_code_forward(ptr(a), ptr(e), _ptr_array(params), ptr(enc_a), ptr(enc_e), ptr(saved),
-                                          dim_in, mid, dim_aud, _lib.current_stream()), "frame_code_forward")
+                                          dim_in, mid, dim_aud, ptr(arrivals), _lib.current_stream()),
+              "frame_code_forward")
         ctx.dims = dims
         ctx.has_e = e is not None
         ctx.save_for_backward(a, saved, *( [e] if e is not None else [] ), *[p for p in params if p is not None])
@@ -68,7 +69,7 @@ class _FrameCodes(torch.autograd.Function):
         check(L.instag_frame_code_backward(ptr(a), ptr(e), _ptr_array(params), ptr(saved), ptr(d_enc_a), ptr(d_enc_e),
                                            _ptr_array(grads), dim_in, mid, dim_aud, _lib.current_stream()),
               "frame_code_backward")
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 def _module_params(field):
@@ -122,5 +123,11 @@ def frame_codes(field, a, e):
     """-> (enc_a [1, dim_aud], enc_e [6] or None) for a motion network `field` (UMF or PMF)."""
     params = _module_params(field)
     dims = (int(a.shape[1]), int(field.audio_net.encoder_conv[0].out_channels), int(field.audio_att_net.dim_aud))
-    enc_a, enc_e = _FrameCodes.apply(a, None if e is None else e.reshape(-1), dims, *params)
+    # arrival counter of the forward's eight workgroups: one word per network (the universal and the personalised
+    # field's branches run on different streams at the same time), zero between launches
+    arrivals = getattr(field, "_frame_code_arrivals", None)
+    if arrivals is None or arrivals.device != a.device:
+        arrivals = torch.zeros(1, dtype=torch.int32, device=a.device)
+        field._frame_code_arrivals = arrivals
+    enc_a, enc_e = _FrameCodes.apply(a, None if e is None else e.reshape(-1), dims, arrivals, *params)
     return enc_a, (enc_e if e is not None else None)

@@ -271,6 +271,185 @@ frame_code_forward_kernel(FrameDims d, ParamPtrs P, const float* __restrict__ a,
   for (int i = threadIdx.x; i < L.end - L.a1; i += FT) saved[i] = s[L.a1 + i];
 }
 
+__device__ __forceinline__ int co_of(int o, int lout) { return o / lout; }
+
+// ---- forward over NB workgroups --------------------------------------------------------------------------------
+// AudioNet's eight windows are independent (scene/motion_net.py:67-99): workgroup b runs window b through the four
+// convolutions and two linear layers with EVERY weight already in LDS (all staging loads are issued at kernel start:
+// one memory round trip instead of one per layer), the last workgroup to finish runs AudioAttNet over the eight feature
+// vectors (+ the expression MLP).  The single-workgroup form took 97 us, ~5 us per layer, almost all of it waiting
+// for the layer's weights and for barriers.
+constexpr int FW = 256;           // threads per workgroup of the forward pass
+
+// one output per group of `tpo` lanes (a power of two <= 64), each lane sums a slice of the input channels
+template <int K, int STRIDE>
+__device__ __forceinline__ void conv_forward_split(const float* x, const float* w, const float* bias, float* y, int cin,
+                                                   int cout, int lin, int lout, bool act) {
+  constexpr int PAD = K == 3 ? 1 : 0;
+  const int total = cout * lout;
+  int tpo = 1;
+  while (tpo * 2 * total <= FW && tpo * 2 <= cin && tpo < 64) tpo *= 2;
+  for (int base = 0; base < total; base += FW / tpo) {
+    const int o = base + (int)threadIdx.x / tpo, part = (int)threadIdx.x % tpo;
+    float acc = 0.f;
+    if (o < total) {
+      const int l = o % lout, co = o / lout;
+      const float* wr = w + co * cin * K;
+      const int p0 = STRIDE * l - PAD;
+#pragma unroll 4
+      for (int ci = part; ci < cin; ci += tpo) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int p = p0 + k;
+          const float xv = (p >= 0 && p < lin) ? x[ci * lin + p] : 0.f;
+          acc += wr[ci * K + k] * xv;
+        }
+      }
+    }
+    for (int m = tpo >> 1; m > 0; m >>= 1) acc += __shfl_xor(acc, m);
+    if (o < total && part == 0) {
+      acc += bias ? bias[co_of(o, lout)] : 0.f;
+      y[o] = act ? leaky(acc) : acc;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(FW)
+frame_code_forward_split_kernel(FrameDims d, ParamPtrs P, const float* __restrict__ a, const float* __restrict__ e,
+                                float* __restrict__ enc_a, float* __restrict__ enc_e, float* __restrict__ saved,
+                                uint32_t* __restrict__ arrivals) {
+  extern __shared__ __align__(16) float s[];      // (no static LDS: the dynamic block may be the whole 160 KB)
+  const int D = d.D, M = d.M, A = d.A, b = blockIdx.x, tid = threadIdx.x;
+  const FrameLayout L = frame_layout(D, M, A);
+  // LDS: [weights of the six AudioNet layers][attention + expression weights][this window's activations][attention acts]
+  const int w1 = 0, b1 = w1 + M * D * 3, w2 = b1 + ((M + 3) & ~3), b2 = w2 + M * M * 3, w3 = b2 + ((M + 3) & ~3),
+            b3 = w3 + 64 * M * 3, w4 = b3 + 64, b4 = w4 + 64 * 64 * 3, w5 = b4 + 64, b5 = w5 + 4096, w6 = b5 + 64,
+            b6 = w6 + A * 64, watt = b6 + ((A + 3) & ~3), acts = watt + att_floats(A);
+  float* x0 = s + acts;                     // [D][16]
+  float* a1 = x0 + D * WIN;                 // [M][8]
+  float* a2 = a1 + M * 8;                   // [M][4]
+  float* a3 = a2 + M * 4;                   // [64][2]
+  float* a4 = a3 + 128;                     // [64]
+  float* f1 = a4 + 64;                      // [64]
+  float* f2 = f1 + 64;                      // [A]
+  float* att = f2 + ((A + 3) & ~3);         // last workgroup: f2 of all windows [8][A], then xt .. eh in FrameLayout order
+  volatile uint32_t* s_ticket = reinterpret_cast<volatile uint32_t*>(att + NB * A + (L.end - L.xt));
+  // every load of the kernel's weights is issued here
+  for (int i = tid; i < D * WIN; i += FW) x0[i] = a[b * D * WIN + i];
+  auto stage = [&](int off, const float* src, int n) {
+    if (src == nullptr) return;
+    if ((n & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(off * 4)) & 15) == 0) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      float4* d4 = reinterpret_cast<float4*>(s + off);
+#pragma unroll 4
+      for (int i = tid; i < n / 4; i += FW) d4[i] = s4[i];
+    } else {
+#pragma unroll 4
+      for (int i = tid; i < n; i += FW) s[off + i] = src[i];
+    }
+  };
+  stage(w1, P.p[0], M * D * 3); stage(b1, P.p[1], M);
+  stage(w2, P.p[2], M * M * 3); stage(b2, P.p[3], M);
+  stage(w3, P.p[4], 64 * M * 3); stage(b3, P.p[5], 64);
+  stage(w4, P.p[6], 64 * 64 * 3); stage(b4, P.p[7], 64);
+  stage(w5, P.p[8], 4096); stage(b5, P.p[9], 64);
+  stage(w6, P.p[10], A * 64); stage(b6, P.p[11], A);
+  const AttW aw = att_layout(A);
+  {
+    const int cin[6] = {A, 16, 8, 4, 2, 8}, cout[6] = {16, 8, 4, 2, 1, 8}, K[6] = {3, 3, 3, 3, 3, 1};
+    for (int i = 0; i < 6; ++i) {
+      stage(watt + aw.w[i], P.p[12 + 2 * i], cout[i] * cin[i] * K[i]);
+      stage(watt + aw.b[i], P.p[13 + 2 * i], cout[i]);
+    }
+    if (d.has_exp) { stage(watt + aw.e1, P.p[24], 80); stage(watt + aw.e2, P.p[25], 80); }
+  }
+  __syncthreads();
+  conv_forward_split<3, 2>(x0, s + w1, s + b1, a1, D, M, 16, 8, true);    __syncthreads();
+  conv_forward_split<3, 2>(a1, s + w2, s + b2, a2, M, M, 8, 4, true);     __syncthreads();
+  conv_forward_split<3, 2>(a2, s + w3, s + b3, a3, M, 64, 4, 2, true);    __syncthreads();
+  conv_forward_split<3, 2>(a3, s + w4, s + b4, a4, 64, 64, 2, 1, true);   __syncthreads();
+  conv_forward_split<1, 1>(a4, s + w5, s + b5, f1, 64, 64, 1, 1, true);   __syncthreads();
+  conv_forward_split<1, 1>(f1, s + w6, s + b6, f2, 64, A, 1, 1, false);   __syncthreads();
+  // this window's slices of the saved activations (batch-major arrays of FrameLayout, offsets relative to a1)
+  {
+    float* sv = saved - L.a1;
+    for (int i = tid; i < M * 8; i += FW) sv[L.a1 + b * M * 8 + i] = a1[i];
+    for (int i = tid; i < M * 4; i += FW) sv[L.a2 + b * M * 4 + i] = a2[i];
+    for (int i = tid; i < 128; i += FW) sv[L.a3 + b * 128 + i] = a3[i];
+    for (int i = tid; i < 64; i += FW) { sv[L.a4 + b * 64 + i] = a4[i]; sv[L.f1 + b * 64 + i] = f1[i]; }
+    for (int i = tid; i < A; i += FW) sv[L.f2 + b * A + i] = f2[i];
+  }
+  // hand-off to the last workgroup: stores drained by every wave, workgroup barrier, agent-scope release, then the
+  // arrival counter; the workgroup that draws the last ticket acquires and reads all eight feature vectors
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *s_ticket = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (*s_ticket != NB - 1) return;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *arrivals = 0u;                          // ready for the next launch (stream-ordered behind this one)
+  }
+  __syncthreads();
+  // ---- AudioAttNet over the eight windows + the expression MLP (activations in FrameLayout order from xt on) ----
+  float* F2 = att;                           // [8][A]
+  float* aa = F2 + NB * A - L.xt;            // aa[L.<act>] for act in xt .. eh
+  const float* svr = saved - L.a1;
+  for (int i = tid; i < NB * A; i += FW) F2[i] = svr[L.f2 + i];
+  __syncthreads();
+  for (int i = tid; i < A * NB; i += FW) {            // xt[j][t] = feat[t][j]
+    const int t = i % NB, j = i / NB;
+    aa[L.xt + i] = F2[t * A + j];
+  }
+  if (d.has_exp && tid >= FW - 16) {                   // expression hidden layer on an idle part of the block
+    const int h = tid - (FW - 16);
+    float acc = 0.f;
+    for (int i = 0; i < 5; ++i) acc += s[watt + aw.e1 + h * 5 + i] * e[i];
+    aa[L.eh + h] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  const float* wa = s + watt;
+  conv_forward_split<3, 1>(aa + L.xt, wa + aw.w[0], wa + aw.b[0], aa + L.c1, A, 16, NB, NB, true);  __syncthreads();
+  conv_forward_split<3, 1>(aa + L.c1, wa + aw.w[1], wa + aw.b[1], aa + L.c2, 16, 8, NB, NB, true);  __syncthreads();
+  conv_forward_split<3, 1>(aa + L.c2, wa + aw.w[2], wa + aw.b[2], aa + L.c3, 8, 4, NB, NB, true);   __syncthreads();
+  conv_forward_split<3, 1>(aa + L.c3, wa + aw.w[3], wa + aw.b[3], aa + L.c4, 4, 2, NB, NB, true);   __syncthreads();
+  conv_forward_split<3, 1>(aa + L.c4, wa + aw.w[4], wa + aw.b[4], aa + L.c5, 2, 1, NB, NB, true);   __syncthreads();
+  conv_forward_split<1, 1>(aa + L.c5, wa + aw.w[5], wa + aw.b[5], aa + L.z, NB, NB, 1, 1, false);   __syncthreads();
+  if (tid < NB) {
+    float m = aa[L.z];
+    for (int t = 1; t < NB; ++t) m = fmaxf(m, aa[L.z + t]);
+    float sum = 0.f;
+    for (int t = 0; t < NB; ++t) sum += expf(aa[L.z + t] - m);
+    aa[L.y + tid] = expf(aa[L.z + tid] - m) / sum;
+  }
+  __syncthreads();
+  for (int j = tid; j < A; j += FW) {
+    float acc = 0.f;
+    for (int t = 0; t < NB; ++t) acc += aa[L.y + t] * F2[t * A + j];
+    enc_a[j] = acc;
+  }
+  if (d.has_exp && tid >= FW - 6) {
+    const int q = tid - (FW - 6);
+    float acc;
+    if (q < 5) {
+      acc = 0.f;
+      for (int h = 0; h < 16; ++h) acc += s[watt + aw.e2 + q * 16 + h] * aa[L.eh + h];
+    } else {
+      acc = e[5];
+    }
+    enc_e[q] = acc;
+  }
+  {
+    float* sv = saved - L.a1;
+    for (int i = tid; i < L.end - L.xt; i += FW) sv[L.xt + i] = aa[L.xt + i];
+  }
+}
+
 __global__ void __launch_bounds__(FT)
 frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __restrict__ a,
                            const float* __restrict__ e, const float* __restrict__ saved,
@@ -353,8 +532,19 @@ inline int set_lds_limit() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_code_backward_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_code_forward_split_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   g_attr_set = true;
   return INSTAG_OK;
+}
+
+// LDS floats of the split forward kernel: all weights + one window's activations + the attention stage
+inline size_t split_forward_floats(int D, int M, int A) {
+  const FrameLayout L = frame_layout(D, M, A);
+  size_t w = (size_t)M * D * 3 + ((M + 3) & ~3) + (size_t)M * M * 3 + ((M + 3) & ~3) + (size_t)64 * M * 3 + 64 +
+             64 * 64 * 3 + 64 + 4096 + 64 + (size_t)A * 64 + ((A + 3) & ~3) + att_floats(A);
+  size_t acts = (size_t)D * WIN + M * 8 + M * 4 + 128 + 64 + 64 + ((A + 3) & ~3) + NB * A + (L.end - L.xt);
+  return w + acts + 8;
 }
 
 inline bool dims_ok(int D, int M, int A) {
@@ -378,7 +568,7 @@ int64_t instag_frame_code_saved_floats(int32_t dim_in, int32_t mid, int32_t dim_
 
 int instag_frame_code_forward(const float* a, const float* e, const float* const* params, float* enc_a,
                               float* enc_e, float* saved, int32_t dim_in, int32_t mid, int32_t dim_aud,
-                              instag_stream_t stream) {
+                              uint32_t* arrivals, instag_stream_t stream) {
   INSTAG_REQUIRE(a && params && enc_a && saved, "frame_code_forward: NULL tensor");
   INSTAG_REQUIRE(dims_ok(dim_in, mid, dim_aud), "frame_code: activations do not fit the 160 KB LDS");
   INSTAG_REQUIRE((e == nullptr) == (enc_e == nullptr), "frame_code_forward: e and enc_e go together");
@@ -391,6 +581,14 @@ int instag_frame_code_forward(const float* a, const float* e, const float* const
   if (int rc = set_lds_limit()) return rc;
   const FrameLayout L = frame_layout(dim_in, mid, dim_aud);
   const FrameDims d{dim_in, mid, dim_aud, has_exp};
+  const size_t split_bytes = split_forward_floats(dim_in, mid, dim_aud) * sizeof(float);
+  if (arrivals != nullptr && split_bytes <= 160u * 1024u) {
+    // one workgroup per audio window, the last one to arrive runs the attention stage (see the kernel)
+    frame_code_forward_split_kernel<<<NB, FW, split_bytes, (hipStream_t)stream>>>(d, P, a, e, enc_a, enc_e, saved,
+                                                                                   arrivals);
+    INSTAG_CHECK_LAUNCH();
+    return INSTAG_OK;
+  }
   frame_code_forward_kernel<<<1, FT, (size_t)(L.end + 4 + weight_stage_floats(dim_in, mid, dim_aud)) * sizeof(float),
                               (hipStream_t)stream>>>(d, P, a, e, enc_a, enc_e,
                                                                                         saved);

@@ -354,10 +354,13 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                            void* workspace, size_t workspace_bytes, float* dL_dmeans3D, float* dL_dmeans2D,
                            float* dL_dshs, float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
-                           float* dL_dshs_rest, instag_stream_t stream_) {
+                           float* dL_dshs_rest, const float* aux_colors, const float* dL_dout_aux,
+                           float* dL_daux_colors, instag_stream_t stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (int e = validate(a)) return e;
   INSTAG_REQUIRE(radii != nullptr || a->N == 0, "radii is NULL");
+  INSTAG_REQUIRE((aux_colors == nullptr) == (dL_dout_aux == nullptr), "aux_colors and dL_dout_aux go together");
+  INSTAG_REQUIRE(dL_daux_colors == nullptr || aux_colors != nullptr, "dL_daux_colors needs aux_colors");
   const GeomLayout GL = geom_layout(a->N);
   const ImageLayout IL = image_layout(a->image_height, a->image_width);
   const BinningLayout BL = binning_layout(R);
@@ -370,18 +373,37 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
   const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)image;
   const Camera c = make_camera(a);
   float* inst_grad = (float*)workspace;
+  const float* g_extra = a->E > 0 ? dL_dout_extra : nullptr;
+  const bool full = dL_dout_depth || dL_dout_normal || g_extra;
+  // the auxiliary image rides along the main pass when that is an rgb-only pass (its gradients use the row slots of
+  // the depth / normal / extra channels); otherwise it gets its own blend launch over the same state, below
+  const bool fused_aux = aux_colors != nullptr && !full;
   if (R > 0) {
     if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
                                       (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d), (const uint32_t*)(ib + IL.n_contrib),
                                       (const float*)(ib + IL.final_T), dL_dout_color, dL_dout_depth,
-                                      dL_dout_normal, dL_dout_alpha, a->E > 0 ? dL_dout_extra : nullptr,
-                                      inst_grad, nullptr, s)) return e;
+                                      dL_dout_normal, dL_dout_alpha, g_extra, inst_grad, nullptr,
+                                      fused_aux ? aux_colors : nullptr, fused_aux ? dL_dout_aux : nullptr, s)) return e;
   }
-  return launch_preprocess_backward(c, a, (const float*)(gb + GL.rec2d), (const float*)(gb + GL.cov3d),
-                                    (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
-                                    radii, inst_grad, (uint32_t)R, dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors_precomp,
-                                    dL_dopacities, dL_dscales, dL_drotations, dL_dcov3Ds_precomp,
-                                    a->E > 0 ? dL_dextra_attrs : nullptr, dL_dshs_rest, s);
+  if (int e = launch_preprocess_backward(c, a, (const float*)(gb + GL.rec2d), (const float*)(gb + GL.cov3d),
+                                         (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
+                                         radii, inst_grad, (uint32_t)R, dL_dmeans3D, dL_dmeans2D, dL_dshs,
+                                         dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3Ds_precomp,
+                                         a->E > 0 ? dL_dextra_attrs : nullptr, dL_dshs_rest,
+                                         fused_aux ? dL_daux_colors : nullptr, s)) return e;
+  if (aux_colors != nullptr && !fused_aux) {
+    // all-channel main pass: the aux image's backward reuses the workspace once the main rows have been reduced
+    if (R > 0) {
+      if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
+                                        (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),
+                                        (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
+                                        nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr, s))
+        return e;
+    }
+    return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,
+                                      inst_grad, (uint32_t)R, dL_daux_colors, dL_dmeans2D, /*accumulate=*/true, s);
+  }
+  return INSTAG_OK;
 }
 
 int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes, const void* binning,
@@ -409,10 +431,11 @@ int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, si
     if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
                                       (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),
                                       (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
-                                      nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, s)) return e;
+                                      nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr, s))
+      return e;
   }
   return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,
-                                    inst_grad, (uint32_t)R, dL_daux_colors, dL_dmeans2D, s);
+                                    inst_grad, (uint32_t)R, dL_daux_colors, dL_dmeans2D, /*accumulate=*/false, s);
 }
 
 int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,

@@ -24,6 +24,10 @@ struct BwdIO {
   float *dmeans3D, *dmeans2D, *dshs, *dcolors, *dopac, *dscales, *drots, *dcov3D, *dextra;
   const float* shs_rest;     // split SH storage: shs = [N,1,3], shs_rest = [N,M-1,3]; gradients likewise
   float* dshs_rest;
+  // rows of the fused auxiliary pass (rgb-only main pass): slots 9..11 = dL/d(aux colour), 12..13 = the aux image's
+  // share of dL/d(screen-space mean), which reaches means2D only (the reference renders the aux image from detached
+  // geometry, gaussian_renderer/__init__.py:256-268)
+  float* daux;
 };
 
 // gradient slot of SH coefficient m of Gaussian g (concatenated or split storage)
@@ -64,9 +68,12 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
   const float dL_dx = gs[0], dL_dy = gs[1], gA = gs[2], gB = gs[3], gC = gs[4];
   const float dL_dop = gs[5];
   const float dcol[3] = {gs[6], gs[7], gs[8]};
-  const float dL_ddepth = gs[9];
-  const float dn[3] = {gs[10], gs[11], gs[12]};
-  const float dL_dex = gs[13];
+  const bool aux_rows = io.daux != nullptr;
+  const float dL_ddepth = aux_rows ? 0.f : gs[9];
+  const float dn[3] = {aux_rows ? 0.f : gs[10], aux_rows ? 0.f : gs[11], aux_rows ? 0.f : gs[12]};
+  const float dL_dex = aux_rows ? 0.f : gs[13];
+  if (aux_rows) { io.daux[3 * g + 0] = gs[9]; io.daux[3 * g + 1] = gs[10]; io.daux[3 * g + 2] = gs[11]; }
+  const float aux_dx = aux_rows ? gs[12] : 0.f, aux_dy = aux_rows ? gs[13] : 0.f;
 
   float dmean[3] = {0.f, 0.f, 0.f};
   float dscale[3] = {0.f, 0.f, 0.f};
@@ -92,7 +99,9 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
     dmean[1] = (P[4] * m_w - P[7] * mul1) * dndcx + (P[5] * m_w - P[7] * mul2) * dndcy + V[6] * dL_ddepth;
     dmean[2] = (P[8] * m_w - P[11] * mul1) * dndcx + (P[9] * m_w - P[11] * mul2) * dndcy + V[10] * dL_ddepth;
     if (io.dmeans2D) {
-      io.dmeans2D[3 * g + 0] = dndcx; io.dmeans2D[3 * g + 1] = dndcy; io.dmeans2D[3 * g + 2] = 0.f;
+      io.dmeans2D[3 * g + 0] = dndcx + 0.5f * (float)c.W * aux_dx;
+      io.dmeans2D[3 * g + 1] = dndcy + 0.5f * (float)c.H * aux_dy;
+      io.dmeans2D[3 * g + 2] = 0.f;
     }
 
     // ---- conic -> 2D covariance ---------------------------------------------------------------
@@ -306,7 +315,7 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
 __global__ void __launch_bounds__(256)
 aux_backward_reduce_kernel(Camera c, const float* __restrict__ rec2d, const uint32_t* __restrict__ tiles_touched,
                            const int32_t* __restrict__ radii, const float* __restrict__ inst_grad, uint32_t capacity,
-                           float* __restrict__ dL_daux, float* __restrict__ dL_dmeans2D) {
+                           float* __restrict__ dL_daux, float* __restrict__ dL_dmeans2D, int accumulate) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= c.N) return;
   float gx = 0.f, gy = 0.f, dc[3] = {0.f, 0.f, 0.f};
@@ -325,9 +334,12 @@ aux_backward_reduce_kernel(Camera c, const float* __restrict__ rec2d, const uint
   }
   if (dL_daux) { dL_daux[3 * g] = dc[0]; dL_daux[3 * g + 1] = dc[1]; dL_daux[3 * g + 2] = dc[2]; }
   if (dL_dmeans2D) {
-    dL_dmeans2D[3 * g] = 0.5f * (float)c.W * gx;
-    dL_dmeans2D[3 * g + 1] = 0.5f * (float)c.H * gy;
-    dL_dmeans2D[3 * g + 2] = 0.f;
+    const float ax = 0.5f * (float)c.W * gx, ay = 0.5f * (float)c.H * gy;
+    if (accumulate) {
+      dL_dmeans2D[3 * g] += ax; dL_dmeans2D[3 * g + 1] += ay;
+    } else {
+      dL_dmeans2D[3 * g] = ax; dL_dmeans2D[3 * g + 1] = ay; dL_dmeans2D[3 * g + 2] = 0.f;
+    }
   }
 }
 
@@ -338,11 +350,12 @@ int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, con
                                const int32_t* radii, const float* inst_grad, uint32_t capacity,
                                float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                                float* dL_dopacities, float* dL_dscales, float* dL_drotations,
-                               float* dL_dcov3D, float* dL_dextra, float* dL_dshs_rest, hipStream_t s) {
+                               float* dL_dcov3D, float* dL_dextra, float* dL_dshs_rest, float* dL_daux_colors,
+                               hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   BwdIO io{a->means3D, a->shs, a->scales, a->rotations, a->cov3Ds_precomp,
            dL_dmeans3D, dL_dmeans2D, dL_dshs, dL_dcolors, dL_dopacities, dL_dscales, dL_drotations,
-           dL_dcov3D, dL_dextra, a->shs_rest, dL_dshs_rest};
+           dL_dcov3D, dL_dextra, a->shs_rest, dL_dshs_rest, dL_daux_colors};
   ProfScope p(K_PREPROCESS_BWD, s);
   preprocess_backward_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, io, rec2d, cov3d, tiles_touched, flags,
                                                                radii, inst_grad, capacity);
@@ -352,11 +365,11 @@ int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, con
 
 int launch_aux_backward_reduce(const Camera& c, const float* rec2d, const uint32_t* tiles_touched, const int32_t* radii,
                                const float* inst_grad, uint32_t capacity, float* dL_daux_colors, float* dL_dmeans2D,
-                               hipStream_t s) {
+                               bool accumulate_means2D, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_PREPROCESS_BWD, s);
   aux_backward_reduce_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, rec2d, tiles_touched, radii, inst_grad, capacity,
-                                                               dL_daux_colors, dL_dmeans2D);
+                                                               dL_daux_colors, dL_dmeans2D, accumulate_means2D ? 1 : 0);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -151,20 +151,31 @@ constexpr int BB = 16;          // Gaussians per backward batch (one MFMA row bl
 constexpr int SB = 32;          // records staged per round (two batches)
 constexpr int WROW = 68;        // floats per (pixel-quarter, Gaussian) row of the w / t matrices (64 + 4 pad)
 
-template <bool FULL>            // FULL: depth / normal / extra channels carry gradient too; else rgb only
-__global__ void __launch_bounds__(BLOCK)
+// FULL: depth / normal / extra channels carry gradient too; else rgb only.
+// AUX (rgb only): the auxiliary colour set's image is differentiated in the SAME pass -- alpha, T and w are shared, the
+// aux image adds its own dL/dalpha recurrence (Q_x) and one more small GEMM; its gradients (aux colours, and the
+// screen-space mean's share, which the reference's second rasterizer call sends to means2D only) leave in the row's
+// depth / normal / extra slots, which an rgb-only pass does not use.  One launch instead of two that recompute the
+// same alpha / T recurrence side by side.
+template <bool FULL, bool AUX>
+__global__ void __launch_bounds__(BLOCK, AUX ? 2 : 4)       // (waves per SIMD the LDS footprint allows: 128 / 256 registers)
 blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const uint32_t* __restrict__ slot_list, const float* __restrict__ rec2d, const uint32_t* __restrict__ n_contrib,
                       const float* __restrict__ final_T, const float* __restrict__ dL_dcolor,
                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dnormal,
                       const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
-                      float* __restrict__ inst_grad, const float* __restrict__ color_override /*[N,3] or null*/) {
-  // 40 KB in all (four workgroups per CU).  Records are staged 32 at a time -- two batches -- so that their two
-  // dependent global loads are issued a full two batches (~3 us) before they are needed
+                      float* __restrict__ inst_grad, const float* __restrict__ color_override /*[N,3] or null*/,
+                      const float* __restrict__ aux_colors /*[N,3], AUX*/, const float* __restrict__ dL_daux /*[3,H,W], AUX*/) {
+  static_assert(!(FULL && AUX), "the fused auxiliary pass uses the row slots of the depth / normal / extra gradients");
+  constexpr int NMAT = AUX ? 3 : 2;                     // w x dL/dpixel, t x moments, (t_aux x moments)
+  // Records are staged 32 at a time -- two batches -- so that their two dependent global loads are issued a full two
+  // batches (~3 us) before they are needed
   __shared__ float4 s_rec[SB][4];
+  __shared__ float4 s_axc[AUX ? SB : 1];               // auxiliary colours of the staged records
   __shared__ __align__(16) float s_W[4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
   __shared__ __align__(16) float s_T[4 * BB * WROW];
-  __shared__ float s_res[BB][2][2][16];               // [gaussian][matrix][pixel half][feature]
+  __shared__ __align__(16) float s_X[AUX ? 4 * BB * WROW : 4];
+  __shared__ float s_res[BB][NMAT][4][8];              // [gaussian][matrix][wave = 16 steps of every quarter][feature < 8]
   int* s_max = reinterpret_cast<int*>(&s_res[0][0][0][0]);   // (used once, before the first batch)
   const int tile = blockIdx.x;
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
@@ -189,10 +200,13 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   dpix[5] = (FULL && inside && dL_dnormal) ? dL_dnormal[P + pix] : 0.f;
   dpix[6] = (FULL && inside && dL_dnormal) ? dL_dnormal[2 * P + pix] : 0.f;
   dpix[7] = (FULL && inside && dL_dextra) ? dL_dextra[pix] : 0.f;
+  float dpx[3] = {0.f, 0.f, 0.f};                      // dL/d(aux image) at this pixel
+  if (AUX && inside) { dpx[0] = dL_daux[pix]; dpx[1] = dL_daux[P + pix]; dpx[2] = dL_daux[2 * P + pix]; }
   const float dalpha_img = (inside && dL_dalpha_img) ? dL_dalpha_img[pix] : 0.f;
   bool live = dalpha_img != 0.f;
 #pragma unroll
   for (int k = 0; k < NCH; ++k) live = live || dpix[k] != 0.f;
+  if (AUX) live = live || dpx[0] != 0.f || dpx[1] != 0.f || dpx[2] != 0.f;
   // only the first max(last_contributor) Gaussians of the list reached any pixel of this tile; a pixel whose
   // incoming gradient is exactly zero contributes nothing (a masked loss leaves most tiles of an image untouched)
   int m = live ? last_contributor : 0;
@@ -210,31 +224,33 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   }
   if (n <= 0) return;
 
-  // d(T_final)/d(alpha_i) = -T_final/(1-alpha_i); T_final enters image (+bg) and alpha image (-1)
+  // d(T_final)/d(alpha_i) = -T_final/(1-alpha_i); T_final enters image (+bg) and alpha image (-1); the aux image has
+  // the same background term and no alpha image
   const float tail = (c.bg[0] * dpix[0] + c.bg[1] * dpix[1] + c.bg[2] * dpix[2]) - dalpha_img;
+  const float tail_x = c.bg[0] * dpx[0] + c.bg[1] * dpx[1] + c.bg[2] * dpx[2];
 
-  // ---- B-operand fragments of phase B (fixed per tile).  MFMA step s of pixel quarter kk = lane>>4 covers
-  // pixel p = 64 kk + s; feature f = lane & 15.  Waves 0/2 multiply the w matrix with dL/dpixel[f] (f < 8),
-  // waves 1/3 the t matrix with the moments (1, lx, ly, lx^2, lx ly, ly^2) of the pixel's in-tile coordinates.
-  const int mat = wave & 1, khalf = wave >> 1;         // wave = (matrix, half of every quarter's 64 pixels)
-  float bfrag[32];
+  // ---- B-operand fragments of phase B (fixed per tile).  MFMA step s of pixel quarter kk = lane>>4 covers pixel
+  // p = 64 kk + s; feature f = lane & 15.  Wave q runs steps 16q .. 16q+15 of EVERY matrix product: the w matrix times
+  // dL/dpixel[f] (main channels, then the three aux channels), the t (and t_aux) matrix times the moments
+  // (1, lx, ly, lx^2, lx ly, ly^2) of the pixel's in-tile coordinates.
+  float bfragW[16], bfragM[16];
   {
-    float* s_F = s_W;                       // staging: dL/dpixel of all 256 pixels, [pixel][8]
+    float* s_F = s_W;                       // staging: dL/dpixel of all 256 pixels, [pixel][12]
+    constexpr int NF = 12;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) s_F[tid * NCH + k] = dpix[k];
+    for (int k = 0; k < NCH; ++k) s_F[tid * NF + k] = dpix[k];
+    if (AUX) {                              // (rgb-only pass: the aux channels sit behind the three main ones)
+      s_F[tid * NF + 3] = dpx[0]; s_F[tid * NF + 4] = dpx[1]; s_F[tid * NF + 5] = dpx[2];
+    }
     __syncthreads();
     const int kk = lane >> 4, f = lane & 15;
+    constexpr int NFW = AUX ? 6 : NCH;
 #pragma unroll
-    for (int s_ = 0; s_ < 32; ++s_) {
-      const int p = 64 * kk + 32 * khalf + s_;
-      float v;
-      if (mat == 0) {
-        v = f < NCH ? s_F[p * NCH + f] : 0.f;
-      } else {
-        const float lx = (float)(p & 15), ly = (float)(p >> 4);
-        v = f == 0 ? 1.f : f == 1 ? lx : f == 2 ? ly : f == 3 ? lx * lx : f == 4 ? lx * ly : f == 5 ? ly * ly : 0.f;
-      }
-      bfrag[s_] = v;
+    for (int s_ = 0; s_ < 16; ++s_) {
+      const int p = 64 * kk + 16 * wave + s_;
+      bfragW[s_] = f < NFW ? s_F[p * NF + f] : 0.f;
+      const float lx = (float)(p & 15), ly = (float)(p >> 4);
+      bfragM[s_] = f == 0 ? 1.f : f == 1 ? lx : f == 2 ? ly : f == 3 ? lx * lx : f == 4 ? lx * ly : f == 5 ? ly * ly : 0.f;
     }
   }
 
@@ -242,13 +258,14 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   // of the current Gaussian) and Q = sum over the Gaussians behind of w_i * <c_i, dL/dpixel>.  With
   // cd_j = <c_j, dL/dpixel>:   dL/dalpha_j = T_j cd_j - (Q_j + T_final*tail) / (1 - alpha_j)
   // (the "colour accumulated behind" of the published kernel is Q / T_{j+1} contracted with dL/dpixel).
-  float Q = 0.f;
-  const float tf_tail = T_final * tail;
+  // The aux image runs the same recurrence with its own colours and upstream gradient: (Q_x, tail_x).
+  float Q = 0.f, Qx = 0.f;
+  const float tf_tail = T_final * tail, tf_tail_x = T_final * tail_x;
 
   const float tile_x0 = (float)(tx * TILE_X), tile_y0 = (float)(ty * TILE_Y);
   const int rounds = (n + SB - 1) / SB;
   // the records of round i+1 are fetched (two dependent global loads) while round i is being processed
-  float4 nrec0 = make_float4(0.f, 0.f, 0.f, 0.f), nrec1 = nrec0, nrec2 = nrec0, nrec3 = nrec0;
+  float4 nrec0 = make_float4(0.f, 0.f, 0.f, 0.f), nrec1 = nrec0, nrec2 = nrec0, nrec3 = nrec0, naxc = nrec0;
   auto fetch = [&](int pos) {
     const uint32_t gid = point_list[start + pos];
     const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
@@ -258,6 +275,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       nrec1.z = color_override[3 * (size_t)gid]; nrec1.w = color_override[3 * (size_t)gid + 1];
       nrec2.x = color_override[3 * (size_t)gid + 2];
     }
+    if (AUX) naxc = make_float4(aux_colors[3 * (size_t)gid], aux_colors[3 * (size_t)gid + 1], aux_colors[3 * (size_t)gid + 2], 0.f);
   };
   if (tid < min(SB, n)) fetch((n - 1) - tid);
   for (int si = 0; si < rounds; ++si) {
@@ -266,6 +284,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     const int scnt = min(SB, n - si * SB);
     if (tid < scnt) {
       s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
+      if (AUX) s_axc[tid] = naxc;
     }
     __syncthreads();
     if (tid < min(SB, sbase - SB + 1)) fetch(sbase - SB - tid);
@@ -298,23 +317,48 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       Q = Q + w * cd;
       s_W[(wave * BB + j) * WROW + lane] = w;
       s_T[(wave * BB + j) * WROW + lane] = valid ? G * dL_dalpha : 0.f;
+      if (AUX) {
+        const float4 ax = s_axc[off + j];
+        const float cdx = ax.x * dpx[0] + ax.y * dpx[1] + ax.z * dpx[2];
+        const float dLx = T * cdx - inv1ma * (Qx + tf_tail_x);
+        Qx = Qx + w * cdx;
+        s_X[(wave * BB + j) * WROW + lane] = valid ? G * dLx : 0.f;
+      }
     }
     __syncthreads();
-    // ---- phase B: [16 Gaussians x 256 pixels] x [256 pixels x 16 features] on the matrix cores ------------
+    // ---- phase B: [16 Gaussians x 256 pixels] x [256 pixels x 16 features] on the matrix cores, per matrix ------------
     {
-      const float* M = (mat == 0 ? s_W : s_T) + ((lane >> 4) * BB + (lane & 15)) * WROW + 32 * khalf;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const int rowo = ((lane >> 4) * BB + (lane & 15)) * WROW + 16 * wave;
+      f32x4 accW = {0.f, 0.f, 0.f, 0.f}, accT = accW, accX = accW;
 #pragma unroll
-      for (int s4 = 0; s4 < 8; ++s4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(M + 4 * s4);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bfrag[4 * s4 + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bfrag[4 * s4 + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bfrag[4 * s4 + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bfrag[4 * s4 + 3], acc, 0, 0, 0);
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(s_W + rowo + 4 * s4);
+        const float4 t4 = *reinterpret_cast<const float4*>(s_T + rowo + 4 * s4);
+        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, bfragW[4 * s4 + 0], accW, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, bfragM[4 * s4 + 0], accT, 0, 0, 0);
+        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, bfragW[4 * s4 + 1], accW, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, bfragM[4 * s4 + 1], accT, 0, 0, 0);
+        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, bfragW[4 * s4 + 2], accW, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, bfragM[4 * s4 + 2], accT, 0, 0, 0);
+        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, bfragW[4 * s4 + 3], accW, 0, 0, 0);
+        accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, bfragM[4 * s4 + 3], accT, 0, 0, 0);
+        if (AUX) {
+          const float4 x4 = *reinterpret_cast<const float4*>(s_X + rowo + 4 * s4);
+          accX = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.x, bfragM[4 * s4 + 0], accX, 0, 0, 0);
+          accX = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.y, bfragM[4 * s4 + 1], accX, 0, 0, 0);
+          accX = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.z, bfragM[4 * s4 + 2], accX, 0, 0, 0);
+          accX = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.w, bfragM[4 * s4 + 3], accX, 0, 0, 0);
+        }
       }
       // D[g = 4*(lane>>4) + r][f = lane&15]
+      if ((lane & 15) < 8) {              // (no product uses more than eight feature columns)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s_res[4 * (lane >> 4) + r][mat][khalf][lane & 15] = acc[r];
+        for (int r = 0; r < 4; ++r) {
+          s_res[4 * (lane >> 4) + r][0][wave][lane & 15] = accW[r];
+          s_res[4 * (lane >> 4) + r][1][wave][lane & 15] = accT[r];
+          if (AUX) s_res[4 * (lane >> 4) + r][2][wave][lane & 15] = accX[r];
+        }
+      }
     }
     __syncthreads();
     // ---- one 64-byte gradient row per (tile, Gaussian) instance -------------------------------------------------
@@ -322,9 +366,11 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       const float4 ra = rec[tid][0], rb = rec[tid][1];
       float Dw[NCH], Dt[6];
 #pragma unroll
-      for (int k = 0; k < NCH; ++k) Dw[k] = s_res[tid][0][0][k] + s_res[tid][0][1][k];
+      for (int k = 0; k < NCH; ++k)
+        Dw[k] = (s_res[tid][0][0][k] + s_res[tid][0][1][k]) + (s_res[tid][0][2][k] + s_res[tid][0][3][k]);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Dt[k] = s_res[tid][1][0][k] + s_res[tid][1][1][k];
+      for (int k = 0; k < 6; ++k)
+        Dt[k] = (s_res[tid][1][0][k] + s_res[tid][1][1][k]) + (s_res[tid][1][2][k] + s_res[tid][1][3][k]);
       const float X = ra.x - tile_x0, Y = ra.y - tile_y0;
       const float A = ra.z, B = ra.w, Cc = rb.x, op = rb.y;
       const float S0 = Dt[0], Sx = Dt[1], Sy = Dt[2], Sxx = Dt[3], Sxy = Dt[4], Syy = Dt[5];
@@ -335,8 +381,20 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       float4 r4[4];
       r4[0] = make_float4(-op * (A * tdx + B * tdy), -op * (Cc * tdy + B * tdx), -0.5f * op * tdxx, -op * tdxy);
       r4[1] = make_float4(-0.5f * op * tdyy, S0, Dw[0], Dw[1]);
-      r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);
-      r4[3] = make_float4(Dw[6], Dw[7], 0.f, 0.f);
+      if (AUX) {
+        // slots 9..11: dL/d(aux colour); 12, 13: the aux image's share of dL/d(screen-space mean)
+        float Dx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          Dx[k] = (s_res[tid][NMAT - 1][0][k] + s_res[tid][NMAT - 1][1][k]) +
+                  (s_res[tid][NMAT - 1][2][k] + s_res[tid][NMAT - 1][3][k]);
+        const float xdx = X * Dx[0] - Dx[1], xdy = Y * Dx[0] - Dx[2];
+        r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);
+        r4[3] = make_float4(-op * (A * xdx + B * xdy), -op * (Cc * xdy + B * xdx), 0.f, 0.f);
+      } else {
+        r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);
+        r4[3] = make_float4(Dw[6], Dw[7], 0.f, 0.f);
+      }
       const uint32_t slot = __float_as_uint(rec[tid][3].z);
       float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)slot * REC_FLOATS);
       dst[0] = r4[0]; dst[1] = r4[1]; dst[2] = r4[2]; dst[3] = r4[3];
@@ -368,18 +426,27 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
                           const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
-                          const float* color_override, hipStream_t s) {
+                          const float* color_override, const float* aux_colors, const float* dL_daux, hipStream_t s) {
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
+  const bool full = dL_ddepth || dL_dnormal || dL_dextra;
+  if (aux_colors != nullptr && (full || dL_daux == nullptr)) {
+    set_error("blend backward: the fused auxiliary pass needs an rgb-only main pass and dL_daux");
+    return INSTAG_E_ARG;
+  }
   ProfScope p(K_BLEND_BWD, s);
-  if (dL_ddepth || dL_dnormal || dL_dextra)
-    blend_backward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T, dL_dcolor,
-                                                        dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad,
-                                                        color_override);
+  if (aux_colors != nullptr)
+    blend_backward_kernel<false, true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,
+                                                               dL_dcolor, nullptr, nullptr, dL_dalpha, nullptr, inst_grad,
+                                                               color_override, aux_colors, dL_daux);
+  else if (full)
+    blend_backward_kernel<true, false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,
+                                                               dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra,
+                                                               inst_grad, color_override, nullptr, nullptr);
   else
-    blend_backward_kernel<false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T, dL_dcolor,
-                                                         dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra, inst_grad,
-                                                         color_override);
+    blend_backward_kernel<false, false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,
+                                                                dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra,
+                                                                inst_grad, color_override, nullptr, nullptr);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

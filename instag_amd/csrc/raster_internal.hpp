@@ -73,7 +73,7 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
                           const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
-                          const float* color_override, hipStream_t s);
+                          const float* color_override, const float* aux_colors, const float* dL_daux, hipStream_t s);
 
 // raster_backward.hip
 int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, const float* rec2d,
@@ -82,9 +82,10 @@ int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, con
                                float* dL_dmeans3D,
                                float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                                float* dL_dopacities, float* dL_dscales, float* dL_drotations,
-                               float* dL_dcov3D, float* dL_dextra, float* dL_dshs_rest, hipStream_t s);
+                               float* dL_dcov3D, float* dL_dextra, float* dL_dshs_rest, float* dL_daux_colors,
+                               hipStream_t s);
 int launch_aux_backward_reduce(const Camera& c, const float* rec2d, const uint32_t* tiles_touched, const int32_t* radii,
                                const float* inst_grad, uint32_t capacity, float* dL_daux_colors, float* dL_dmeans2D,
-                               hipStream_t s);
+                               bool accumulate_means2D, hipStream_t s);
 
 }  // namespace instag

@@ -67,8 +67,11 @@ class CapacityPlan:
 
     def __init__(self, capacities, device):
         self.capacities = [int(c) for c in capacities]
-        self.status = [torch.zeros(4, dtype=torch.int32, device=device) for _ in self.capacities]
+        self._all = torch.zeros(len(self.capacities), 4, dtype=torch.int32, device=device)
+        self.status = [self._all[k] for k in range(len(self.capacities))]       # views: one copy reads every slot
         self.index = 0
+        self._host = None
+        self._event = None
 
     def begin_step(self):
         self.index = 0
@@ -83,20 +86,36 @@ class CapacityPlan:
     def overflowed(self):
         """Host check (synchronises): list of (slot, largest R needed) of every slot whose capacity was exceeded by ANY
         call since the last clear() -- the flag is sticky on the device, so a check after many replays misses nothing."""
-        st = torch.stack(self.status).cpu()
+        st = self._all.cpu()
         return [(k, int(st[k, 2])) for k in range(len(self.capacities)) if int(st[k, 1]) != 0]
+
+    def poll_overflow(self):
+        """Asynchronous form for a replay loop: never waits for the device.  Returns the overflow list read by the
+        PREVIOUS call's copy if that copy has landed (else None) and starts a new copy into pinned memory."""
+        result = None
+        if self._event is not None and self._event.query():
+            st = self._host
+            result = [(k, int(st[k, 2])) for k in range(len(self.capacities)) if int(st[k, 1]) != 0]
+            self._event = None
+        if self._event is None:
+            if self._host is None:
+                self._host = torch.zeros(len(self.capacities), 4, dtype=torch.int32).pin_memory()
+            self._host.copy_(self._all, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+        return result
 
     def needed(self):
         """Instances the most recent call of every slot needed."""
-        return [int(v) for v in torch.stack(self.status).cpu()[:, 0]]
+        return [int(v) for v in self._all.cpu()[:, 0]]
 
     def peak(self):
         """Largest need of every slot since the last clear()."""
-        return [int(v) for v in torch.stack(self.status).cpu()[:, 2]]
+        return [int(v) for v in self._all.cpu()[:, 2]]
 
     def clear(self):
-        for s in self.status:
-            s.zero_()
+        self._all.zero_()
+        self._event = None
 
 
 _CAPACITY_PLAN = None
@@ -189,6 +208,7 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
 _AUX_STREAMS = {}
 _AUX_EVENTS = {}
 DEFER_AUX_JOIN = False        # see _RasterizeGaussians.backward; only a caller that joins explicitly may set this
+FUSE_AUX_BACKWARD = None      # None: by image size (see _RasterizeGaussians.backward); True / False: force (tests)
 _PENDING_AUX = []
 
 
@@ -223,8 +243,10 @@ def rasterize_aux_backward(st: "_State", g_aux, want_colors=True, want_means2D=T
     return d_aux, d_m2d
 
 
-def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra, want):
-    """want: dict name -> bool for means3D, means2D, shs, colors, opacities, scales, rotations, cov3D, extra."""
+def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra, want, g_aux=None, want_aux=False):
+    """want: dict name -> bool for means3D, means2D, shs, colors, opacities, scales, rotations, cov3D, extra.
+    g_aux [3,H,W]: upstream gradient of the auxiliary image -- differentiated in the same call (out["aux"] = gradient of
+    the aux colours if want_aux; the aux image's share of the means2D gradient is included in out["means2D"])."""
     L = _lib.lib()
     dev = st.geom.device
     N, M = st.N, st.M
@@ -244,7 +266,10 @@ def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra,
         opacities=buf(want["opacities"], N, 1), scales=buf(want["scales"] and not use_cov, N, 3),
         rotations=buf(want["rotations"] and not use_cov, N, 4), cov3D=buf(want["cov3D"] and use_cov, N, 6),
         extra=buf(want["extra"] and st.E > 0, N, st.E),
+        aux=buf(want_aux and g_aux is not None and st.aux is not None, N, 3),
     )
+    use_aux = g_aux is not None and st.aux is not None
+    g_aux = _f32c(g_aux) if use_aux else None
     ws = torch.empty(L.instag_raster_backward_workspace_bytes(N, st.R), dtype=torch.uint8, device=dev)
     gs = [None if g is None else _f32c(g) for g in (g_color, g_depth, g_normal, g_alpha, g_extra)]
     check(L.instag_raster_backward(C.byref(st.args), ptr(st.geom), st.geom.numel(), ptr(st.binning),
@@ -253,7 +278,8 @@ def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra,
                                    ptr(gs[4]) if st.E > 0 else None, ptr(ws), ws.numel(),
                                    ptr(out["means3D"]), ptr(out["means2D"]), ptr(out["shs"]), ptr(out["colors"]),
                                    ptr(out["opacities"]), ptr(out["scales"]), ptr(out["rotations"]),
-                                   ptr(out["cov3D"]), ptr(out["extra"]), ptr(out["shs_rest"]), stream),
+                                   ptr(out["cov3D"]), ptr(out["extra"]), ptr(out["shs_rest"]),
+                                   ptr(st.aux) if use_aux else None, ptr(g_aux), ptr(out["aux"]), stream),
           "rasterize_gaussians_backward")
     return out
 
@@ -289,19 +315,34 @@ class _RasterizeGaussians(torch.autograd.Function):
                     scales=need[5], rotations=need[6], cov3D=need[7], extra=need[8])
         d_aux = m2d_aux = None
         aux_needed = st.aux is not None and g_aux is not None and (need[10] or need[1])
+        main_grads = any(g is not None for g in (g_color, g_depth, g_normal, g_alpha, g_extra))
         dev = st.geom.device
-        if aux_needed:
+        tiles = ((st.W + 15) // 16) * ((st.H + 15) // 16)
+        full = any(g is not None for g in (g_depth, g_normal)) or (g_extra is not None and st.E > 0)
+        # Two ways to differentiate the aux image (the attention map) next to the main images:
+        #  * fused -- one blend launch carries both images through one alpha / T recurrence (rgb-only main pass; an
+        #    all-channel main pass runs the two launches back to back inside the same C call).  Least total work: right
+        #    when the image has far more tiles than the chip has CUs;
+        #  * side by side -- a second blend launch on a second stream.  At 512x512 only ~400 tiles are populated, one
+        #    workgroup each, so the kernels are bound by the serial walk of a tile's list, not by throughput: two
+        #    launches that each redo the recurrence finish sooner than one that does 1.3x the work per list entry
+        #    (C3: 297 us fused against ~240 us for the pair).
+        fused = aux_needed and main_grads and (FUSE_AUX_BACKWARD if FUSE_AUX_BACKWARD is not None
+                                                 else (full or tiles >= 4096))
+        if aux_needed and not fused:
             ready = _AUX_EVENTS.get((dev.type, dev.index))       # reused: no event is created / destroyed per step
             if ready is None:
                 ready = _AUX_EVENTS[(dev.type, dev.index)] = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(dev))
-        main_grads = any(g is not None for g in (g_color, g_depth, g_normal, g_alpha, g_extra))
         if main_grads:
-            g = rasterize_backward(st, g_color, g_depth, g_normal, g_alpha, g_extra, want)
+            g = rasterize_backward(st, g_color, g_depth, g_normal, g_alpha, g_extra, want,
+                                   g_aux=g_aux if fused else None, want_aux=need[10])
+            if fused:
+                d_aux = g.get("aux")
         else:
             g = dict(means3D=None, means2D=None, shs=None, shs_rest=None, colors=None, opacities=None, scales=None,
                      rotations=None, cov3D=None, extra=None)
-        if aux_needed:
+        if aux_needed and not fused:
             # the aux image only shares the forward state with the main images: its backward runs beside theirs,
             # enqueued AFTER the main one so that in a captured step the main chain keeps its graph branch
             main = torch.cuda.current_stream(dev)

@@ -590,7 +590,7 @@ class GraphedStep:
         if self._replays < self.CHECK_EVERY:
             return False
         self._replays = 0
-        return bool(self.plan.overflowed())
+        return bool(self.plan.poll_overflow())        # asynchronous: the answer of the previous poll, no device wait
 
 
 def build_trainer(n_gaussians, device, sh_degree=1, seed=0, densify=False, encoder_cls=None, raw=None):

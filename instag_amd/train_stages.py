@@ -165,7 +165,7 @@ class GraphedStage:
         if getattr(self, "_replays", 0) < self.CHECK_EVERY:
             return False
         self._replays = 0
-        return bool(self.plan.overflowed())
+        return bool(self.plan.poll_overflow())        # asynchronous: the answer of the previous poll, no device wait
 
 
 def _drop_graph(trainer):

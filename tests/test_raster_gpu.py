@@ -322,10 +322,16 @@ def test_graphed_train_step_matches_eager():
         assert float((params["eager"] - params[mode]).abs().max()) <= 1e-5
 
 
-def test_aux_colors_match_second_pass():
-    """aux_colors rides along the main pass: image and gradients equal a second rasterizer call on detached geometry."""
+@pytest.mark.parametrize("full,fuse", [(False, True), (False, False), (True, None)],
+                         ids=["rgb-main-pass-fused", "rgb-main-pass-side-by-side", "all-channel-main-pass"])
+def test_aux_colors_match_second_pass(full, fuse, monkeypatch):
+    """aux_colors rides along the main pass: image and gradients equal a second rasterizer call on detached geometry
+    (gaussian_renderer/__init__.py:253-268).  With an rgb-only main pass the backward of both images is ONE blend
+    launch; with depth / normal gradients the aux image gets its own launch inside the same C call."""
     import torch
+    from instag_amd import diff_gauss
     from instag_amd.diff_gauss import GaussianRasterizer
+    monkeypatch.setattr(diff_gauss, "FUSE_AUX_BACKWARD", fuse)
     N, size = 3000, 96
     a, sd = make_scene(N, size, sh_degree=1, seed=7)
     a = {k: a[k] for k in ("means3D", "shs", "opacities", "scales", "rotations")}
@@ -349,13 +355,14 @@ def test_aux_colors_match_second_pass():
     out_attn = rast(means3D=r["means3D"].detach(), means2D=r["m2d"], colors_precomp=r["aux"],
                     opacities=r["opacities"].detach(), scales=r["scales"].detach(), rotations=r["rotations"].detach(),
                     extra_attrs=ones)
-    ((out_main[0] * w_img).sum() + out_main[3].sum() + (out_attn[0] * w_aux).sum()).backward()
+    extra_loss = (lambda o: (o[1] * w_img[:1]).sum() + (o[2] * w_aux).sum()) if full else (lambda o: 0.0)
+    ((out_main[0] * w_img).sum() + out_main[3].sum() + (out_attn[0] * w_aux).sum() + extra_loss(out_main)).backward()
     # fused: one call
     f = leaves()
     outs = rast(means3D=f["means3D"], means2D=f["m2d"], shs=f["shs"], opacities=f["opacities"], scales=f["scales"],
                 rotations=f["rotations"], extra_attrs=ones, aux_colors=f["aux"])
     assert len(outs) == 7
-    ((outs[0] * w_img).sum() + outs[3].sum() + (outs[6] * w_aux).sum()).backward()
+    ((outs[0] * w_img).sum() + outs[3].sum() + (outs[6] * w_aux).sum() + extra_loss(outs)).backward()
     assert torch.equal(outs[0], out_main[0])
     assert float((outs[6] - out_attn[0]).abs().max()) <= 1e-6
     for k in r:
