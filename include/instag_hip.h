@@ -179,7 +179,11 @@ int instag_raster_forward_capacity(const instag_raster_args* a, void* geom, size
  * too -- dL_daux_colors [N,3] is written and the aux image's share of the screen-space mean gradient is ADDED into
  * dL_dmeans2D (only there: the reference renders the attention map from detached geometry, gaussian_renderer/
  * __init__.py:256-268).  With an rgb-only main pass (no depth / normal / extra gradient) this costs no extra launch:
- * the blend kernel carries both images through one alpha / T recurrence. */
+ * the blend kernel carries both images through one alpha / T recurrence.
+ * aux_colors_only != 0 (rgb-only main pass): only dL_daux_colors is produced here -- three more feature columns of a
+ * matrix product that has idle ones, i.e. free -- and dL_dmeans2D gets no aux share: the caller runs
+ * instag_raster_aux_backward(dL_daux_colors = NULL) beside this call for that (the two launches overlap; at 512x512
+ * that is faster than one launch that walks every tile's list with 1.3x the work per entry). */
 int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t geom_bytes,
                            const void* binning, size_t binning_bytes, const void* image,
                            size_t image_bytes, int64_t R, const int32_t* radii,
@@ -191,7 +195,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                            float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
                            float* dL_dshs_rest /* [N,M-1,3], with split SH storage: then dL_dshs is [N,1,3] */,
                            const float* aux_colors, const float* dL_dout_aux, float* dL_daux_colors,
-                           instag_stream_t stream);
+                           int32_t aux_colors_only, instag_stream_t stream);
 
 /* backward of the auxiliary colour set over the forward's state: dL_dout_aux [3,H,W] -> dL_daux_colors [N,3] and
  * the aux image's contribution to dL_dmeans2D [N,3] (same convention as above; either may be NULL).  The geometry

@@ -355,7 +355,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                            float* dL_dshs, float* dL_dcolors_precomp, float* dL_dopacities, float* dL_dscales,
                            float* dL_drotations, float* dL_dcov3Ds_precomp, float* dL_dextra_attrs,
                            float* dL_dshs_rest, const float* aux_colors, const float* dL_dout_aux,
-                           float* dL_daux_colors, instag_stream_t stream_) {
+                           float* dL_daux_colors, int32_t aux_colors_only, instag_stream_t stream_) {
   hipStream_t s = (hipStream_t)stream_;
   if (int e = validate(a)) return e;
   INSTAG_REQUIRE(radii != nullptr || a->N == 0, "radii is NULL");
@@ -378,12 +378,14 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
   // the auxiliary image rides along the main pass when that is an rgb-only pass (its gradients use the row slots of
   // the depth / normal / extra channels); otherwise it gets its own blend launch over the same state, below
   const bool fused_aux = aux_colors != nullptr && !full;
+  INSTAG_REQUIRE(!aux_colors_only || fused_aux, "aux_colors_only needs aux_colors and an rgb-only main pass");
   if (R > 0) {
     if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
                                       (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d), (const uint32_t*)(ib + IL.n_contrib),
                                       (const float*)(ib + IL.final_T), dL_dout_color, dL_dout_depth,
                                       dL_dout_normal, dL_dout_alpha, g_extra, inst_grad, nullptr,
-                                      fused_aux ? aux_colors : nullptr, fused_aux ? dL_dout_aux : nullptr, s)) return e;
+                                      fused_aux ? aux_colors : nullptr, fused_aux ? dL_dout_aux : nullptr,
+                                      fused_aux ? (aux_colors_only ? 2 : 1) : 0, s)) return e;
   }
   if (int e = launch_preprocess_backward(c, a, (const float*)(gb + GL.rec2d), (const float*)(gb + GL.cov3d),
                                          (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
@@ -397,7 +399,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
       if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
                                         (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),
                                         (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
-                                        nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr, s))
+                                        nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr, 0, s))
         return e;
     }
     return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,
@@ -431,7 +433,8 @@ int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, si
     if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
                                       (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),
                                       (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
-                                      nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr, s))
+                                      nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr,
+                                      dL_daux_colors == nullptr ? 3 : 0, s))     // no colour gradient wanted: mean-only pass
       return e;
   }
   return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,

@@ -152,13 +152,16 @@ constexpr int SB = 32;          // records staged per round (two batches)
 constexpr int WROW = 68;        // floats per (pixel-quarter, Gaussian) row of the w / t matrices (64 + 4 pad)
 
 // FULL: depth / normal / extra channels carry gradient too; else rgb only.
-// AUX (rgb only): the auxiliary colour set's image is differentiated in the SAME pass -- alpha, T and w are shared, the
-// aux image adds its own dL/dalpha recurrence (Q_x) and one more small GEMM; its gradients (aux colours, and the
-// screen-space mean's share, which the reference's second rasterizer call sends to means2D only) leave in the row's
-// depth / normal / extra slots, which an rgb-only pass does not use.  One launch instead of two that recompute the
-// same alpha / T recurrence side by side.
-template <bool FULL, bool AUX>
-__global__ void __launch_bounds__(BLOCK, AUX ? 2 : 4)       // (waves per SIMD the LDS footprint allows: 128 / 256 registers)
+// AUX (rgb only) -- how much of the auxiliary colour set's image is differentiated in THIS launch:
+//   1: all of it -- alpha, T and w are shared, the aux image adds its own dL/dalpha recurrence (Q_x) and one more small
+//      GEMM; its gradients (aux colours, and the screen-space mean's share, which the reference's second rasterizer
+//      call sends to means2D only) leave in the row's depth / normal / extra slots, which an rgb-only pass does not use;
+//   2: the aux COLOURS' gradient only: it is sum_p w dL/d(aux pixel), i.e. three more feature columns of the w product,
+//      which has ten idle ones -- free.  The screen-space mean's share then comes from an XONLY launch beside this one.
+// XONLY: a pass over `color_override` colours that only produces the screen-space mean's gradient (rows: dx, dy): no w
+//   product at all, half the matrix work of a colour pass.
+template <bool FULL, int AUX, bool XONLY>
+__global__ void __launch_bounds__(BLOCK, AUX == 1 ? 2 : 4)   // (waves per SIMD the LDS footprint allows: 128 / 256 registers)
 blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const uint32_t* __restrict__ slot_list, const float* __restrict__ rec2d, const uint32_t* __restrict__ n_contrib,
                       const float* __restrict__ final_T, const float* __restrict__ dL_dcolor,
@@ -166,15 +169,18 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
                       const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
                       float* __restrict__ inst_grad, const float* __restrict__ color_override /*[N,3] or null*/,
                       const float* __restrict__ aux_colors /*[N,3], AUX*/, const float* __restrict__ dL_daux /*[3,H,W], AUX*/) {
-  static_assert(!(FULL && AUX), "the fused auxiliary pass uses the row slots of the depth / normal / extra gradients");
-  constexpr int NMAT = AUX ? 3 : 2;                     // w x dL/dpixel, t x moments, (t_aux x moments)
+  static_assert(!(FULL && AUX != 0), "the auxiliary gradients use the row slots of the depth / normal / extra gradients");
+  static_assert(!(XONLY && (FULL || AUX != 0)), "XONLY is a pass of its own");
+  constexpr bool AUXW = AUX != 0, AUXX = AUX == 1;
+  constexpr int NMAT = XONLY ? 1 : (AUXX ? 3 : 2);      // w x dL/dpixel, t x moments, (t_aux x moments)
+  constexpr int MW = 0, MT = XONLY ? 0 : 1, MX = 2;
   // Records are staged 32 at a time -- two batches -- so that their two dependent global loads are issued a full two
   // batches (~3 us) before they are needed
   __shared__ float4 s_rec[SB][4];
-  __shared__ float4 s_axc[AUX ? SB : 1];               // auxiliary colours of the staged records
-  __shared__ __align__(16) float s_W[4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
+  __shared__ float4 s_axc[AUXX ? SB : 1];              // auxiliary colours of the staged records
+  __shared__ __align__(16) float s_W[XONLY ? 4 : 4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
   __shared__ __align__(16) float s_T[4 * BB * WROW];
-  __shared__ __align__(16) float s_X[AUX ? 4 * BB * WROW : 4];
+  __shared__ __align__(16) float s_X[AUXX ? 4 * BB * WROW : 4];
   __shared__ float s_res[BB][NMAT][4][8];              // [gaussian][matrix][wave = 16 steps of every quarter][feature < 8]
   int* s_max = reinterpret_cast<int*>(&s_res[0][0][0][0]);   // (used once, before the first batch)
   const int tile = blockIdx.x;
@@ -201,12 +207,12 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   dpix[6] = (FULL && inside && dL_dnormal) ? dL_dnormal[2 * P + pix] : 0.f;
   dpix[7] = (FULL && inside && dL_dextra) ? dL_dextra[pix] : 0.f;
   float dpx[3] = {0.f, 0.f, 0.f};                      // dL/d(aux image) at this pixel
-  if (AUX && inside) { dpx[0] = dL_daux[pix]; dpx[1] = dL_daux[P + pix]; dpx[2] = dL_daux[2 * P + pix]; }
+  if (AUXW && inside) { dpx[0] = dL_daux[pix]; dpx[1] = dL_daux[P + pix]; dpx[2] = dL_daux[2 * P + pix]; }
   const float dalpha_img = (inside && dL_dalpha_img) ? dL_dalpha_img[pix] : 0.f;
   bool live = dalpha_img != 0.f;
 #pragma unroll
   for (int k = 0; k < NCH; ++k) live = live || dpix[k] != 0.f;
-  if (AUX) live = live || dpx[0] != 0.f || dpx[1] != 0.f || dpx[2] != 0.f;
+  if (AUXW) live = live || dpx[0] != 0.f || dpx[1] != 0.f || dpx[2] != 0.f;
   // only the first max(last_contributor) Gaussians of the list reached any pixel of this tile; a pixel whose
   // incoming gradient is exactly zero contributes nothing (a masked loss leaves most tiles of an image untouched)
   int m = live ? last_contributor : 0;
@@ -235,20 +241,20 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   // (1, lx, ly, lx^2, lx ly, ly^2) of the pixel's in-tile coordinates.
   float bfragW[16], bfragM[16];
   {
-    float* s_F = s_W;                       // staging: dL/dpixel of all 256 pixels, [pixel][12]
+    float* s_F = XONLY ? s_T : s_W;         // staging: dL/dpixel of all 256 pixels, [pixel][12]
     constexpr int NF = 12;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) s_F[tid * NF + k] = dpix[k];
-    if (AUX) {                              // (rgb-only pass: the aux channels sit behind the three main ones)
+    if (AUXW) {                             // (rgb-only pass: the aux channels sit behind the three main ones)
       s_F[tid * NF + 3] = dpx[0]; s_F[tid * NF + 4] = dpx[1]; s_F[tid * NF + 5] = dpx[2];
     }
     __syncthreads();
     const int kk = lane >> 4, f = lane & 15;
-    constexpr int NFW = AUX ? 6 : NCH;
+    constexpr int NFW = AUXW ? 6 : NCH;
 #pragma unroll
     for (int s_ = 0; s_ < 16; ++s_) {
       const int p = 64 * kk + 16 * wave + s_;
-      bfragW[s_] = f < NFW ? s_F[p * NF + f] : 0.f;
+      bfragW[s_] = (!XONLY && f < NFW) ? s_F[p * NF + f] : 0.f;
       const float lx = (float)(p & 15), ly = (float)(p >> 4);
       bfragM[s_] = f == 0 ? 1.f : f == 1 ? lx : f == 2 ? ly : f == 3 ? lx * lx : f == 4 ? lx * ly : f == 5 ? ly * ly : 0.f;
     }
@@ -275,7 +281,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       nrec1.z = color_override[3 * (size_t)gid]; nrec1.w = color_override[3 * (size_t)gid + 1];
       nrec2.x = color_override[3 * (size_t)gid + 2];
     }
-    if (AUX) naxc = make_float4(aux_colors[3 * (size_t)gid], aux_colors[3 * (size_t)gid + 1], aux_colors[3 * (size_t)gid + 2], 0.f);
+    if (AUXX) naxc = make_float4(aux_colors[3 * (size_t)gid], aux_colors[3 * (size_t)gid + 1], aux_colors[3 * (size_t)gid + 2], 0.f);
   };
   if (tid < min(SB, n)) fetch((n - 1) - tid);
   for (int si = 0; si < rounds; ++si) {
@@ -284,7 +290,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     const int scnt = min(SB, n - si * SB);
     if (tid < scnt) {
       s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
-      if (AUX) s_axc[tid] = naxc;
+      if (AUXX) s_axc[tid] = naxc;
     }
     __syncthreads();
     if (tid < min(SB, sbase - SB + 1)) fetch(sbase - SB - tid);
@@ -315,9 +321,9 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       const float w = alpha_e * T;
       const float dL_dalpha = T * cd - inv1ma * (Q + tf_tail);
       Q = Q + w * cd;
-      s_W[(wave * BB + j) * WROW + lane] = w;
+      if (!XONLY) s_W[(wave * BB + j) * WROW + lane] = w;
       s_T[(wave * BB + j) * WROW + lane] = valid ? G * dL_dalpha : 0.f;
-      if (AUX) {
+      if (AUXX) {
         const float4 ax = s_axc[off + j];
         const float cdx = ax.x * dpx[0] + ax.y * dpx[1] + ax.z * dpx[2];
         const float dLx = T * cdx - inv1ma * (Qx + tf_tail_x);
@@ -332,17 +338,24 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       f32x4 accW = {0.f, 0.f, 0.f, 0.f}, accT = accW, accX = accW;
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        const float4 w4 = *reinterpret_cast<const float4*>(s_W + rowo + 4 * s4);
         const float4 t4 = *reinterpret_cast<const float4*>(s_T + rowo + 4 * s4);
-        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, bfragW[4 * s4 + 0], accW, 0, 0, 0);
-        accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, bfragM[4 * s4 + 0], accT, 0, 0, 0);
-        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, bfragW[4 * s4 + 1], accW, 0, 0, 0);
-        accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, bfragM[4 * s4 + 1], accT, 0, 0, 0);
-        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, bfragW[4 * s4 + 2], accW, 0, 0, 0);
-        accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, bfragM[4 * s4 + 2], accT, 0, 0, 0);
-        accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, bfragW[4 * s4 + 3], accW, 0, 0, 0);
-        accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, bfragM[4 * s4 + 3], accT, 0, 0, 0);
-        if (AUX) {
+        if (!XONLY) {
+          const float4 w4 = *reinterpret_cast<const float4*>(s_W + rowo + 4 * s4);
+          accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, bfragW[4 * s4 + 0], accW, 0, 0, 0);
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, bfragM[4 * s4 + 0], accT, 0, 0, 0);
+          accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, bfragW[4 * s4 + 1], accW, 0, 0, 0);
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, bfragM[4 * s4 + 1], accT, 0, 0, 0);
+          accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, bfragW[4 * s4 + 2], accW, 0, 0, 0);
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, bfragM[4 * s4 + 2], accT, 0, 0, 0);
+          accW = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, bfragW[4 * s4 + 3], accW, 0, 0, 0);
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, bfragM[4 * s4 + 3], accT, 0, 0, 0);
+        } else {
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.x, bfragM[4 * s4 + 0], accT, 0, 0, 0);
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.y, bfragM[4 * s4 + 1], accT, 0, 0, 0);
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.z, bfragM[4 * s4 + 2], accT, 0, 0, 0);
+          accT = __builtin_amdgcn_mfma_f32_16x16x4f32(t4.w, bfragM[4 * s4 + 3], accT, 0, 0, 0);
+        }
+        if (AUXX) {
           const float4 x4 = *reinterpret_cast<const float4*>(s_X + rowo + 4 * s4);
           accX = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.x, bfragM[4 * s4 + 0], accX, 0, 0, 0);
           accX = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.y, bfragM[4 * s4 + 1], accX, 0, 0, 0);
@@ -354,9 +367,9 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       if ((lane & 15) < 8) {              // (no product uses more than eight feature columns)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s_res[4 * (lane >> 4) + r][0][wave][lane & 15] = accW[r];
-          s_res[4 * (lane >> 4) + r][1][wave][lane & 15] = accT[r];
-          if (AUX) s_res[4 * (lane >> 4) + r][2][wave][lane & 15] = accX[r];
+          if (!XONLY) s_res[4 * (lane >> 4) + r][MW][wave][lane & 15] = accW[r];
+          s_res[4 * (lane >> 4) + r][MT][wave][lane & 15] = accT[r];
+          if (AUXX) s_res[4 * (lane >> 4) + r][MX][wave][lane & 15] = accX[r];
         }
       }
     }
@@ -367,10 +380,10 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       float Dw[NCH], Dt[6];
 #pragma unroll
       for (int k = 0; k < NCH; ++k)
-        Dw[k] = (s_res[tid][0][0][k] + s_res[tid][0][1][k]) + (s_res[tid][0][2][k] + s_res[tid][0][3][k]);
+        Dw[k] = XONLY ? 0.f : (s_res[tid][MW][0][k] + s_res[tid][MW][1][k]) + (s_res[tid][MW][2][k] + s_res[tid][MW][3][k]);
 #pragma unroll
       for (int k = 0; k < 6; ++k)
-        Dt[k] = (s_res[tid][1][0][k] + s_res[tid][1][1][k]) + (s_res[tid][1][2][k] + s_res[tid][1][3][k]);
+        Dt[k] = (s_res[tid][MT][0][k] + s_res[tid][MT][1][k]) + (s_res[tid][MT][2][k] + s_res[tid][MT][3][k]);
       const float X = ra.x - tile_x0, Y = ra.y - tile_y0;
       const float A = ra.z, B = ra.w, Cc = rb.x, op = rb.y;
       const float S0 = Dt[0], Sx = Dt[1], Sy = Dt[2], Sxx = Dt[3], Sxy = Dt[4], Syy = Dt[5];
@@ -379,21 +392,26 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       const float tdxy = X * Y * S0 - X * Sy - Y * Sx + Sxy;
       const float tdyy = Y * Y * S0 - 2.f * Y * Sy + Syy;
       float4 r4[4];
-      r4[0] = make_float4(-op * (A * tdx + B * tdy), -op * (Cc * tdy + B * tdx), -0.5f * op * tdxx, -op * tdxy);
-      r4[1] = make_float4(-0.5f * op * tdyy, S0, Dw[0], Dw[1]);
-      if (AUX) {
-        // slots 9..11: dL/d(aux colour); 12, 13: the aux image's share of dL/d(screen-space mean)
-        float Dx[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          Dx[k] = (s_res[tid][NMAT - 1][0][k] + s_res[tid][NMAT - 1][1][k]) +
-                  (s_res[tid][NMAT - 1][2][k] + s_res[tid][NMAT - 1][3][k]);
-        const float xdx = X * Dx[0] - Dx[1], xdy = Y * Dx[0] - Dx[2];
-        r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);
-        r4[3] = make_float4(-op * (A * xdx + B * xdy), -op * (Cc * xdy + B * xdx), 0.f, 0.f);
+      if (XONLY) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        r4[0] = make_float4(-op * (A * tdx + B * tdy), -op * (Cc * tdy + B * tdx), 0.f, 0.f);
+        r4[1] = z; r4[2] = z; r4[3] = z;
       } else {
-        r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);
+        r4[0] = make_float4(-op * (A * tdx + B * tdy), -op * (Cc * tdy + B * tdx), -0.5f * op * tdxx, -op * tdxy);
+        r4[1] = make_float4(-0.5f * op * tdyy, S0, Dw[0], Dw[1]);
+        r4[2] = make_float4(Dw[2], Dw[3], Dw[4], Dw[5]);       // AUX: slots 9..11 = dL/d(aux colour)
         r4[3] = make_float4(Dw[6], Dw[7], 0.f, 0.f);
+        if (AUXW) r4[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (AUXX) {
+          // slots 12, 13: the aux image's share of dL/d(screen-space mean)
+          float Dx[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            Dx[k] = (s_res[tid][NMAT - 1][0][k] + s_res[tid][NMAT - 1][1][k]) +
+                    (s_res[tid][NMAT - 1][2][k] + s_res[tid][NMAT - 1][3][k]);
+          const float xdx = X * Dx[0] - Dx[1], xdy = Y * Dx[0] - Dx[2];
+          r4[3] = make_float4(-op * (A * xdx + B * xdy), -op * (Cc * xdy + B * xdx), 0.f, 0.f);
+        }
       }
       const uint32_t slot = __float_as_uint(rec[tid][3].z);
       float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)slot * REC_FLOATS);
@@ -426,27 +444,31 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
                           const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
-                          const float* color_override, const float* aux_colors, const float* dL_daux, hipStream_t s) {
+                          const float* color_override, const float* aux_colors, const float* dL_daux, int aux_mode,
+                          hipStream_t s) {
+  // aux_mode: 0 none, 1 whole aux image in this launch, 2 aux colours' gradient only, 3 mean-only pass over
+  // `color_override` (rows carry dx, dy)
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
   const bool full = dL_ddepth || dL_dnormal || dL_dextra;
-  if (aux_colors != nullptr && (full || dL_daux == nullptr)) {
-    set_error("blend backward: the fused auxiliary pass needs an rgb-only main pass and dL_daux");
+  if ((aux_mode == 1 || aux_mode == 2) && (full || aux_colors == nullptr || dL_daux == nullptr)) {
+    set_error("blend backward: the auxiliary gradients need an rgb-only main pass, aux_colors and dL_daux");
+    return INSTAG_E_ARG;
+  }
+  if (aux_mode == 3 && (full || color_override == nullptr)) {
+    set_error("blend backward: the mean-only pass takes its colours from color_override");
     return INSTAG_E_ARG;
   }
   ProfScope p(K_BLEND_BWD, s);
-  if (aux_colors != nullptr)
-    blend_backward_kernel<false, true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,
-                                                               dL_dcolor, nullptr, nullptr, dL_dalpha, nullptr, inst_grad,
-                                                               color_override, aux_colors, dL_daux);
-  else if (full)
-    blend_backward_kernel<true, false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,
-                                                               dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra,
-                                                               inst_grad, color_override, nullptr, nullptr);
-  else
-    blend_backward_kernel<false, false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,
-                                                                dL_dcolor, dL_ddepth, dL_dnormal, dL_dalpha, dL_dextra,
-                                                                inst_grad, color_override, nullptr, nullptr);
+#define INSTAG_BB(F, A, X, d, n, e, ax, dax)                                                                            \
+  blend_backward_kernel<F, A, X><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,   \
+                                                        dL_dcolor, d, n, dL_dalpha, e, inst_grad, color_override, ax, dax)
+  if (aux_mode == 1) INSTAG_BB(false, 1, false, nullptr, nullptr, nullptr, aux_colors, dL_daux);
+  else if (aux_mode == 2) INSTAG_BB(false, 2, false, nullptr, nullptr, nullptr, aux_colors, dL_daux);
+  else if (aux_mode == 3) INSTAG_BB(false, 0, true, nullptr, nullptr, nullptr, nullptr, nullptr);
+  else if (full) INSTAG_BB(true, 0, false, dL_ddepth, dL_dnormal, dL_dextra, nullptr, nullptr);
+  else INSTAG_BB(false, 0, false, nullptr, nullptr, nullptr, nullptr, nullptr);
+#undef INSTAG_BB
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

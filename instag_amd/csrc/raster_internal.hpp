@@ -73,7 +73,8 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
                           const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
-                          const float* color_override, const float* aux_colors, const float* dL_daux, hipStream_t s);
+                          const float* color_override, const float* aux_colors, const float* dL_daux, int aux_mode,
+                          hipStream_t s);
 
 // raster_backward.hip
 int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, const float* rec2d,

@@ -243,7 +243,8 @@ def rasterize_aux_backward(st: "_State", g_aux, want_colors=True, want_means2D=T
     return d_aux, d_m2d
 
 
-def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra, want, g_aux=None, want_aux=False):
+def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra, want, g_aux=None, want_aux=False,
+                       aux_colors_only=False):
     """want: dict name -> bool for means3D, means2D, shs, colors, opacities, scales, rotations, cov3D, extra.
     g_aux [3,H,W]: upstream gradient of the auxiliary image -- differentiated in the same call (out["aux"] = gradient of
     the aux colours if want_aux; the aux image's share of the means2D gradient is included in out["means2D"])."""
@@ -279,7 +280,8 @@ def rasterize_backward(st: _State, g_color, g_depth, g_normal, g_alpha, g_extra,
                                    ptr(out["means3D"]), ptr(out["means2D"]), ptr(out["shs"]), ptr(out["colors"]),
                                    ptr(out["opacities"]), ptr(out["scales"]), ptr(out["rotations"]),
                                    ptr(out["cov3D"]), ptr(out["extra"]), ptr(out["shs_rest"]),
-                                   ptr(st.aux) if use_aux else None, ptr(g_aux), ptr(out["aux"]), stream),
+                                   ptr(st.aux) if use_aux else None, ptr(g_aux), ptr(out["aux"]),
+                                   1 if (use_aux and aux_colors_only) else 0, stream),
           "rasterize_gaussians_backward")
     return out
 
@@ -334,10 +336,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             if ready is None:
                 ready = _AUX_EVENTS[(dev.type, dev.index)] = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(dev))
+        # side by side with an rgb-only main pass: the aux colours' gradient rides in idle columns of the main launch's
+        # matrix product, the side launch only computes the screen-space mean's share (half the matrix work)
+        split = aux_needed and main_grads and not fused and not full and need[10]
         if main_grads:
             g = rasterize_backward(st, g_color, g_depth, g_normal, g_alpha, g_extra, want,
-                                   g_aux=g_aux if fused else None, want_aux=need[10])
-            if fused:
+                                   g_aux=g_aux if (fused or split) else None, want_aux=need[10], aux_colors_only=split)
+            if fused or split:
                 d_aux = g.get("aux")
         else:
             g = dict(means3D=None, means2D=None, shs=None, shs_rest=None, colors=None, opacities=None, scales=None,
@@ -352,7 +357,10 @@ class _RasterizeGaussians(torch.autograd.Function):
                 side = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
             side.wait_event(ready)
             with torch.cuda.stream(side):
-                d_aux, m2d_aux = rasterize_aux_backward(st, g_aux, need[10], need[1])
+                if split:
+                    m2d_aux = rasterize_aux_backward(st, g_aux, False, need[1])[1] if need[1] else None
+                else:
+                    d_aux, m2d_aux = rasterize_aux_backward(st, g_aux, need[10], need[1])
             for t in (g_aux, d_aux, m2d_aux):
                 if t is not None:
                     t.record_stream(side)
