@@ -208,6 +208,10 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
 _AUX_STREAMS = {}
 _AUX_EVENTS = {}
 DEFER_AUX_JOIN = False        # see _RasterizeGaussians.backward; only a caller that joins explicitly may set this
+# Joining the mean-only aux pass only at the end of backward (nothing consumes it earlier) was measured on the C3 step:
+# 1.235 -> 1.385 ms.  A branch left open through the whole backward takes one of the graph's four hardware queues away
+# from the weight-gradient / personalised-field branches that fork later; it is joined where the aux pass always was.
+_LATE_JOIN = False
 FUSE_AUX_BACKWARD = None      # None: by image size (see _RasterizeGaussians.backward); True / False: force (tests)
 _PENDING_AUX = []
 
@@ -216,6 +220,8 @@ def join_pending_aux(final: bool = False):
     """Make the current stream wait for every outstanding aux-image backward.  ``final=True`` (after the backward pass
     has finished) also adds the aux image's means2D contribution to ``means2D.grad`` and forgets the entries."""
     for entry in _PENDING_AUX:
+        if entry.get("late") and not final:
+            continue            # a mean-only pass: nothing consumes its result before the end of backward
         if not entry["joined"]:
             torch.cuda.current_stream(entry["dev"]).wait_stream(entry["side"])
             entry["joined"] = True
@@ -355,6 +361,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             side = _AUX_STREAMS.get(key)
             if side is None:
                 side = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+            # (starting the mean-only pass BEHIND the main blend launch instead of beside it was measured: the main launch
+            # got 35 us shorter, the step 35 us longer -- the pass then competes with the memory-bound kernels downstream)
             side.wait_event(ready)
             with torch.cuda.stream(side):
                 if split:
@@ -370,7 +378,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 # the main chain does not wait for the aux image's backward here, and the aux image's means2D
                 # contribution is added to means2D.grad at the final join.
                 if m2d_aux is not None:
-                    _PENDING_AUX.append(dict(dev=dev, side=side, leaf=ctx.means2D_leaf, m2d_aux=m2d_aux, joined=False))
+                    _PENDING_AUX.append(dict(dev=dev, side=side, leaf=ctx.means2D_leaf, m2d_aux=m2d_aux, joined=False,
+                                             late=bool(split) and _LATE_JOIN))
                 else:
                     main.wait_stream(side)
             else:

@@ -295,9 +295,13 @@ def test_stage_trainers_graph_matches_eager():
         le, ve, _ = run(kind, False)
         lg, vg, tr = run(kind, True)
         assert tr.iteration == 10
+        # The mouth field's 186 KB planes take the generic grid encoder, whose backward flushes its LDS sums with global
+        # float atomics (csrc/grid.hip): the summation order, hence the last bits of the table gradient, differ from
+        # run to run, and ten Adam steps amplify that -- 2.6e-5 on a parameter has been observed between two runs of
+        # the SAME mode.  (The face path, all fixed-order sums, is compared at 1e-5 in test_raster_gpu.py.)
         for a_, b_ in zip(le, lg):
-            assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (kind, le, lg)
-        assert float((ve - vg).abs().max()) <= 1e-5, kind
+            assert abs(a_ - b_) <= 1e-4 * max(1.0, abs(a_)), (kind, le, lg)
+        assert float((ve - vg).abs().max()) <= 2e-4, kind
 
     # density control on: the captured step is abandoned on the iteration that densifies
     pc_face, face_net, pc_mouth, mouth_net = _mouth_setup(dev, n_face=2000, n_mouth=900, seed=8)
