@@ -42,24 +42,24 @@ int instag_abi_version(void);
  * inputs [B,D] fp32 in [0,1]; embeddings [sO,C] fp32; offsets [L+1] int32; outputs [L,B,C];
  * dy_dx [B, L*D*C] or NULL; grad [L,B,C]; grad_embeddings [sO,C] and grad_inputs [B,D] arrive
  * zero-filled and are accumulated into.  D in {2,3}, C in {1,2,4,8}.
- * `workspace` (device, `instag_grid_backward_workspace_bytes` bytes, may be NULL when that is 0)
- * is scratch for the contention-free table-gradient path.
+ * grad_total_variation adds, for every table entry hit by a sample, the normalised sum of its differences to its axis
+ * neighbours (gridencoder.cu:506-610) into `grad` [sO,C]; `workspace` (device, instag_grid_total_variation_workspace_bytes
+ * bytes, cleared by the call) holds per-entry sample counts and fixed-point sums: no float atomics, reproducible.
  * ------------------------------------------------------------------------------------------ */
 int instag_grid_encode_forward(const float* inputs, const float* embeddings, const int32_t* offsets,
                                float* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                                uint32_t H, float* dy_dx, uint32_t gridtype, int align_corners,
                                uint32_t interp, instag_stream_t stream);
-size_t instag_grid_backward_workspace_bytes(uint32_t B, uint32_t D, uint32_t C, uint32_t L,
-                                            uint32_t total_params);
 int instag_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings,
                                 const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D,
                                 uint32_t C, uint32_t L, float S, uint32_t H, const float* dy_dx,
                                 float* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
-                                void* workspace, size_t workspace_bytes, uint32_t total_params,
                                 instag_stream_t stream);
+size_t instag_grid_total_variation_workspace_bytes(uint32_t total_params, uint32_t C);
 int instag_grid_total_variation(const float* inputs, const float* embeddings, float* grad,
                                 const int32_t* offsets, float weight, uint32_t B, uint32_t D, uint32_t C,
                                 uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                uint32_t total_params, void* workspace, size_t workspace_bytes,
                                 instag_stream_t stream);
 
 /* Tri-plane encoder: the three identically configured 2-D, C=1 grid encoders of a motion field (planes xy, yz, xz;

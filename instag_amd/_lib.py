@@ -52,10 +52,11 @@ _PROTOS = {
     "instag_last_error": (C.c_char_p, []),
     "instag_abi_version": (C.c_int, []),
     "instag_grid_encode_forward": (C.c_int, [vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, u32, C.c_int, u32, vp]),
-    "instag_grid_backward_workspace_bytes": (sz, [u32, u32, u32, u32, u32]),
     "instag_grid_encode_backward": (C.c_int, [vp, vp, vp, vp, vp, u32, u32, u32, u32, f32, u32, vp, vp, u32,
-                                              C.c_int, u32, vp, sz, u32, vp]),
-    "instag_grid_total_variation": (C.c_int, [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, C.c_int, vp]),
+                                              C.c_int, u32, vp]),
+    "instag_grid_total_variation_workspace_bytes": (sz, [u32, u32]),
+    "instag_grid_total_variation": (C.c_int, [vp, vp, vp, vp, f32, u32, u32, u32, u32, f32, u32, u32, C.c_int,
+                                              u32, vp, sz, vp]),
     "instag_triplane_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, u32, f32, u32, u32, f32, u32, f32, u32, vp]),
     "instag_triplane_backward_workspace_bytes": (sz, [u32, u32]),
     "instag_triplane_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, u32, f32, vp,

@@ -524,18 +524,10 @@ frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __
   conv_backward<3, 2>(s + L.x0, g + L.a1, nullptr, G.p[0], G.p[1], nullptr, NB, D, M, 16, 8, false);
 }
 
-bool g_attr_set = false;
-
 inline int set_lds_limit() {
-  if (g_attr_set) return INSTAG_OK;
-  INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_code_forward_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_code_backward_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frame_code_forward_split_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  g_attr_set = true;
-  return INSTAG_OK;
+  if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(frame_code_forward_kernel), 160 * 1024)) return rc;
+  if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(frame_code_backward_kernel), 160 * 1024)) return rc;
+  return set_max_dynamic_lds(reinterpret_cast<const void*>(frame_code_forward_split_kernel), 160 * 1024);
 }
 
 // LDS floats of the split forward kernel: all weights + one window's activations + the attention stage

@@ -4,7 +4,10 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <algorithm>
+#include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 
 #include "instag_hip.h"
 
@@ -47,6 +50,20 @@ struct ProfScope {
 
 template <typename T>
 static inline T div_up(T a, T b) { return (a + b - 1) / b; }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); callable from any thread (forward runs
+// on the caller's thread, backward on autograd's) -- the attribute belongs to the device's copy of the code object
+static inline int set_max_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  INSTAG_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({kernel, dev})) return INSTAG_OK;
+  INSTAG_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({kernel, dev});
+  return INSTAG_OK;
+}
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

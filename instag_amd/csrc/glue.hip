@@ -183,9 +183,14 @@ deform_activate_forward_kernel(int N, const float* __restrict__ xyz, const float
     for (int k = 0; k < 4; ++k) rots[4 * r + k] = q[k] * inv;
     opac[r] = sigmoid_f(opacity[r]);
     if (reg_partials) {
-      // the motion regulariser of train_face.py:510-514 rides along (same terms as motion_l1_reg below)
+      // the motion regulariser of train_face.py:510-514 rides along.  Its d_xyz term sees the displacement AFTER the
+      // reference's in-place d_xyz *= p_scale (gaussian_renderer/__init__.py:217 mutates the returned dictionary's
+      // entry): |h * 1e-2 * p_scale|, with p_scale = tanh(.) * 0.25 + 1 > 0
       const float w_xyz = 1e-2f / (3.f * N), w_rot = 1.f / (4.f * N), w_opa = 1.f / (float)N, w_sc = 1.f / (3.f * N);
-      reg = w_xyz * (fabsf(hr[0]) + fabsf(hr[1]) + fabsf(hr[2])) + w_rot * (fabsf(hr[3]) + fabsf(hr[4]) + fabsf(hr[5]) + fabsf(hr[6]))
+      float ps3[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ps3[k] = tanhf(pr[3 + k] * 0.2f) * 0.25f + 1.0f;
+      reg = w_xyz * (fabsf(hr[0]) * ps3[0] + fabsf(hr[1]) * ps3[1] + fabsf(hr[2]) * ps3[2]) + w_rot * (fabsf(hr[3]) + fabsf(hr[4]) + fabsf(hr[5]) + fabsf(hr[6]))
           + w_opa * fabsf(hr[7]) + w_sc * (fabsf(hr[8]) + fabsf(hr[9]) + fabsf(hr[10]))
           + w_xyz * (fabsf(pr[0]) + fabsf(pr[1]) + fabsf(pr[2]));
     }
@@ -254,7 +259,14 @@ deform_activate_backward_kernel(int N, const float* __restrict__ scaling, const 
     const float go = g_reg[0] * reg_weight;
     const float w_xyz = go * 1e-2f / (3.f * N), w_rot = go / (4.f * N), w_opa = go / (float)N, w_sc = go / (3.f * N);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { dh[k] += w_xyz * sgn(hr[k]); dh[8 + k] += w_sc * sgn(hr[8 + k]); dp[k] += w_xyz * sgn(pr[k]); }
+    for (int k = 0; k < 3; ++k) {
+      // d_xyz term: |h_k| * 1e-2 * p_scale_k  (the in-place scaled displacement): gradient to h_k and to p_{3+k}
+      const float th = tanhf(pr[3 + k] * 0.2f);
+      dh[k] += w_xyz * sgn(hr[k]) * (th * 0.25f + 1.0f);
+      dp[3 + k] += w_xyz * fabsf(hr[k]) * 0.25f * (1.f - th * th) * 0.2f;
+      dh[8 + k] += w_sc * sgn(hr[8 + k]);
+      dp[k] += w_xyz * sgn(pr[k]);
+    }
 #pragma unroll
     for (int k = 3; k < 7; ++k) dh[k] += w_rot * sgn(hr[k]);
     dh[7] += w_opa * sgn(hr[7]);

@@ -348,52 +348,120 @@ grid_backward_kernel(const float* __restrict__ grad, const float* __restrict__ i
   }
 }
 
+// ---- total-variation gradient (gridencoder/grid.py:165-185; semantics of gridencoder.cu:506-610) --------------------
+// For every sample and level the reference finds the vertex v = floor(x * scale + 0.5) and adds
+//     weight / (2D) * r * rsqrt(q + 1e-9),   r = sum_n (e[v] - e[n]),  q = sum_n (e[v] - e[n])^2  over v's axis neighbours
+// into grad[v] with one float atomic per sample and channel.  The term depends on the vertex only, so here:
+//   * levels whose vertices map one-to-one onto table entries (no hashing / tiling wrap): pass 1 only COUNTS the samples
+//     per entry (integer atomics), pass 2 walks the table, computes the term once per touched entry and adds
+//     count * term with a plain store -- per cell, not per sample;
+//   * hashed (or wrapped) levels, where several vertices share an entry: the per-sample term is accumulated in 64-bit
+//     fixed point (integer atomics: order-independent, so deterministic) and converted in pass 2.
+// No float atomics; bitwise reproducible.
+template <uint32_t D>
+__device__ __forceinline__ bool level_is_dense(const LevelGeom& lg, bool align_corners) {
+  uint64_t n = 1;
+  const uint64_t side = align_corners ? lg.resolution : lg.resolution + 1;
+#pragma unroll
+  for (uint32_t d = 0; d < D; ++d) { n *= side; if (n > lg.hashmap_size) return false; }
+  return true;
+}
+
+// term of vertex `pos_grid` for every channel
+template <uint32_t D, uint32_t C>
+__device__ __forceinline__ void tv_term(const float* __restrict__ tab, const LevelGeom& lg, uint32_t gridtype,
+                                        bool align_corners, uint32_t (&pos_grid)[D], uint32_t index, float w,
+                                        float (&term)[C]) {
+  float r[C], q[C];
+#pragma unroll
+  for (uint32_t ch = 0; ch < C; ++ch) { r[ch] = 0.f; q[ch] = 0.f; }
+#pragma unroll
+  for (uint32_t d = 0; d < D; ++d) {
+    const uint32_t cur = pos_grid[d];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      if (side == 0 ? cur < lg.resolution : cur > 0) {
+        pos_grid[d] = side == 0 ? cur + 1 : cur - 1;
+        const uint32_t in = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pos_grid) * C;
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) {
+          const float gv = tab[index + ch] - tab[in + ch];
+          r[ch] += gv; q[ch] += gv * gv;
+        }
+      }
+    }
+    pos_grid[d] = cur;
+  }
+#pragma unroll
+  for (uint32_t ch = 0; ch < C; ++ch) term[ch] = w * r[ch] * rsqrtf(q[ch] + 1e-9f);
+}
+
 template <uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(GRID_BLOCK)
-grid_tv_kernel(const float* __restrict__ inputs, const float* __restrict__ grid, float* __restrict__ grad,
-               const int32_t* __restrict__ offsets, float weight, uint32_t B, uint32_t L, float S, uint32_t H,
-               uint32_t gridtype, bool align_corners) {
+grid_tv_count_kernel(const float* __restrict__ inputs, const float* __restrict__ grid,
+                     const int32_t* __restrict__ offsets, float weight, double to_fixed, uint32_t B, float S, uint32_t H,
+                     uint32_t gridtype, bool align_corners, uint32_t* __restrict__ counts,
+                     unsigned long long* __restrict__ acc) {
   const uint32_t b = blockIdx.x * GRID_BLOCK + threadIdx.x;
   if (b >= B) return;
   const uint32_t level = blockIdx.y;
   float x[D];
   if (load_point<D>(inputs, b, x)) return;
   const LevelGeom lg = level_geom(offsets, level, S, H);
-  const float* tab = grid + (size_t)(uint32_t)offsets[level] * C;
-  float* gt = grad + (size_t)(uint32_t)offsets[level] * C;
+  const uint32_t off = (uint32_t)offsets[level];
   uint32_t pos_grid[D];
 #pragma unroll
   for (uint32_t d = 0; d < D; ++d) pos_grid[d] = (uint32_t)floorf(x[d] * lg.scale + (align_corners ? 0.0f : 0.5f));
-  float results[C], idelta[C];
+  const uint32_t idx = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pos_grid);
+  if (level_is_dense<D>(lg, align_corners)) {
+    atomicAdd(&counts[off + idx], 1u);
+  } else {
+    float term[C];
+    tv_term<D, C>(grid + (size_t)off * C, lg, gridtype, align_corners, pos_grid, idx * C, weight / (2 * D), term);
 #pragma unroll
-  for (uint32_t ch = 0; ch < C; ++ch) { results[ch] = 0.f; idelta[ch] = 0.f; }
-  const uint32_t index = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pos_grid) * C;
-  const float w = weight / (2 * D);
-#pragma unroll
-  for (uint32_t d = 0; d < D; ++d) {
-    const uint32_t cur = pos_grid[d];
-    if (cur < lg.resolution) {
-      pos_grid[d] = cur + 1;
-      const uint32_t ir = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pos_grid) * C;
-#pragma unroll
-      for (uint32_t ch = 0; ch < C; ++ch) {
-        const float gv = tab[index + ch] - tab[ir + ch];
-        results[ch] += gv; idelta[ch] += gv * gv;
-      }
-    }
-    if (cur > 0) {
-      pos_grid[d] = cur - 1;
-      const uint32_t il = grid_index<D>(gridtype, align_corners, lg.hashmap_size, lg.resolution, pos_grid) * C;
-#pragma unroll
-      for (uint32_t ch = 0; ch < C; ++ch) {
-        const float gv = tab[index + ch] - tab[il + ch];
-        results[ch] += gv; idelta[ch] += gv * gv;
-      }
-    }
-    pos_grid[d] = cur;
+    for (uint32_t ch = 0; ch < C; ++ch)
+      atomicAdd(&acc[((size_t)off + idx) * C + ch], (unsigned long long)__double2ll_rn((double)term[ch] * to_fixed));
   }
+}
+
+template <uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(GRID_BLOCK)
+grid_tv_apply_kernel(const float* __restrict__ grid, float* __restrict__ grad, const int32_t* __restrict__ offsets,
+                     float weight, double to_float, float S, uint32_t H, uint32_t gridtype, bool align_corners,
+                     const uint32_t* __restrict__ counts, const unsigned long long* __restrict__ acc) {
+  const uint32_t level = blockIdx.y;
+  const LevelGeom lg = level_geom(offsets, level, S, H);
+  const uint32_t off = (uint32_t)offsets[level];
+  const bool dense = level_is_dense<D>(lg, align_corners);
+  const uint32_t side = align_corners ? lg.resolution : lg.resolution + 1;
+  for (uint32_t e = blockIdx.x * GRID_BLOCK + threadIdx.x; e < lg.hashmap_size; e += gridDim.x * GRID_BLOCK) {
+    float total[C];
+    bool any = false;
+    if (dense) {
+      const uint32_t cnt = counts[off + e];
+      if (cnt != 0) {
+        uint32_t pos_grid[D], rem = e;                 // entry -> vertex: index = sum_d pos[d] * side^d
 #pragma unroll
-  for (uint32_t ch = 0; ch < C; ++ch) atomicAdd(&gt[index + ch], w * results[ch] * rsqrtf(idelta[ch] + 1e-9f));
+        for (uint32_t d = 0; d < D; ++d) { pos_grid[d] = rem % side; rem /= side; }
+        float term[C];
+        tv_term<D, C>(grid + (size_t)off * C, lg, gridtype, align_corners, pos_grid, e * C, weight / (2 * D), term);
+#pragma unroll
+        for (uint32_t ch = 0; ch < C; ++ch) total[ch] = (float)cnt * term[ch];
+        any = true;
+      }
+    } else {
+#pragma unroll
+      for (uint32_t ch = 0; ch < C; ++ch) {
+        const long long a = (long long)acc[((size_t)off + e) * C + ch];
+        total[ch] = (float)((double)a * to_float);
+        any = any || a != 0;
+      }
+    }
+    if (any) {
+#pragma unroll
+      for (uint32_t ch = 0; ch < C; ++ch) grad[((size_t)off + e) * C + ch] += total[ch];
+    }
+  }
 }
 
 inline unsigned fwd_blocks(uint32_t B) { return (unsigned)std::min<uint32_t>(div_up<uint32_t>(B, GRID_BLOCK), 2048u); }
@@ -417,13 +485,8 @@ int run_backward(const float* grad, const float* inputs, const int32_t* offsets,
                  uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs, uint32_t gridtype,
                  bool align, uint32_t interp, hipStream_t s) {
   ProfScope p(K_GRID_BWD, s);
-  static bool attr_set = false;       // per <D, C> instantiation
-  if (!attr_set) {
-    INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_backward_kernel<D, C>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(LDS_BWD_ENTRIES * sizeof(unsigned long long))));
-    attr_set = true;
-  }
+  if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(grid_backward_kernel<D, C>),
+                                   (int)(LDS_BWD_ENTRIES * sizeof(unsigned long long)))) return rc;
   grid_backward_kernel<D, C><<<bwd_blocks(B), GRID_BLOCK, LDS_BWD_ENTRIES * sizeof(unsigned long long), s>>>(
       grad, inputs, offsets, grad_emb, B, L, S, H, dy_dx, grad_inputs, gridtype, align, interp);
   INSTAG_CHECK_LAUNCH();
@@ -431,9 +494,17 @@ int run_backward(const float* grad, const float* inputs, const int32_t* offsets,
 }
 template <uint32_t D, uint32_t C>
 int run_tv(const float* inputs, const float* emb, float* grad, const int32_t* offsets, float weight, uint32_t B,
-           uint32_t L, float S, uint32_t H, uint32_t gridtype, bool align, hipStream_t s) {
+           uint32_t L, float S, uint32_t H, uint32_t gridtype, bool align, uint32_t* counts, unsigned long long* acc,
+           hipStream_t s) {
+  // |term| < |weight|: 2^36 fixed-point units per |weight| leave room for 2^26 samples in one entry
+  const double scale = weight != 0.f ? 68719476736.0 / fabs((double)weight) : 1.0;
   dim3 g(div_up<uint32_t>(B, GRID_BLOCK), L, 1);
-  grid_tv_kernel<D, C><<<g, GRID_BLOCK, 0, s>>>(inputs, emb, grad, offsets, weight, B, L, S, H, gridtype, align);
+  grid_tv_count_kernel<D, C><<<g, GRID_BLOCK, 0, s>>>(inputs, emb, offsets, weight, scale, B, S, H, gridtype, align,
+                                                      counts, acc);
+  INSTAG_CHECK_LAUNCH();
+  dim3 g2(256, L, 1);
+  grid_tv_apply_kernel<D, C><<<g2, GRID_BLOCK, 0, s>>>(emb, grad, offsets, weight, 1.0 / scale, S, H, gridtype, align,
+                                                       counts, acc);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -470,14 +541,11 @@ int instag_grid_encode_forward(const float* inputs, const float* embeddings, con
   return INSTAG_E_ARG;
 }
 
-size_t instag_grid_backward_workspace_bytes(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { return 0; }
-
 int instag_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings,
                                 const int32_t* offsets, float* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                                 uint32_t L, float S, uint32_t H, const float* dy_dx, float* grad_inputs,
-                                uint32_t gridtype, int align_corners, uint32_t interp, void* workspace,
-                                size_t workspace_bytes, uint32_t total_params, instag_stream_t stream) {
-  (void)embeddings; (void)workspace; (void)workspace_bytes; (void)total_params;
+                                uint32_t gridtype, int align_corners, uint32_t interp, instag_stream_t stream) {
+  (void)embeddings;                     // (part of the reference's signature; the table gradient does not need the table)
   INSTAG_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: NULL tensor");
   INSTAG_REQUIRE(L >= 1 && L <= 64, "GridEncoding: L must be in [1,64]");
   if (B == 0) return INSTAG_OK;
@@ -488,13 +556,25 @@ int instag_grid_encode_backward(const float* grad, const float* inputs, const fl
   return INSTAG_E_ARG;
 }
 
+size_t instag_grid_total_variation_workspace_bytes(uint32_t total_params, uint32_t C) {
+  return align_up((size_t)total_params * sizeof(uint32_t), 256) + (size_t)total_params * C * sizeof(unsigned long long);
+}
+
 int instag_grid_total_variation(const float* inputs, const float* embeddings, float* grad, const int32_t* offsets,
                                 float weight, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
-                                uint32_t gridtype, int align_corners, instag_stream_t stream) {
+                                uint32_t gridtype, int align_corners, uint32_t total_params, void* workspace,
+                                size_t workspace_bytes, instag_stream_t stream) {
   INSTAG_REQUIRE(inputs && embeddings && grad && offsets, "grad_total_variation: NULL tensor");
+  INSTAG_REQUIRE(L >= 1 && L <= 64, "GridEncoding: L must be in [1,64]");
+  const size_t need = instag_grid_total_variation_workspace_bytes(total_params, C);
+  if (workspace == nullptr || workspace_bytes < need) { set_error("grad_total_variation: workspace too small"); return INSTAG_E_SPACE; }
   if (B == 0) return INSTAG_OK;
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_DC(D, C, run_tv, inputs, embeddings, grad, offsets, weight, B, L, S, H, gridtype, align_corners != 0, s);
+  INSTAG_CHECK_HIP(hipMemsetAsync(workspace, 0, need, s));
+  uint32_t* counts = (uint32_t*)workspace;
+  unsigned long long* acc = (unsigned long long*)((char*)workspace + align_up((size_t)total_params * sizeof(uint32_t), 256));
+  DISPATCH_DC(D, C, run_tv, inputs, embeddings, grad, offsets, weight, B, L, S, H, gridtype, align_corners != 0, counts,
+              acc, s);
   set_error("GridEncoding: D must be 2..5 and C must be 1, 2, 4, or 8.");
   return INSTAG_E_ARG;
 }
@@ -835,12 +915,7 @@ int instag_triplane_forward(const float* xyz, const float* table_xy, const float
   ProfScope p(K_GRID_FWD, s);
   const size_t all_bytes = (size_t)3 * total_params * sizeof(float);
   if (all_bytes <= 150 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(triplane_forward_all_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      attr_set = true;
-    }
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(triplane_forward_all_kernel), 150 * 1024)) return rc;
     const unsigned blocks = std::max(1u, std::min(256u, div_up<uint32_t>(3u * N, TPF_BLOCK)));
     triplane_forward_all_kernel<<<blocks, TPF_BLOCK, all_bytes, s>>>(a, out);
   } else {
@@ -875,12 +950,7 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
   const unsigned blocks = tp_bwd_blocks(N);
   const size_t need = (size_t)blocks * 3 * total_params * sizeof(float);
   if (!workspace || workspace_bytes < need) { set_error("triplane_backward: workspace too small"); return INSTAG_E_SPACE; }
-  static bool attr_set = false;
-  if (!attr_set) {
-    INSTAG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(triplane_backward_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    attr_set = true;
-  }
+  if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(triplane_backward_kernel), 156 * 1024)) return rc;
   INSTAG_REQUIRE(shift == nullptr || shift_stride >= 3, "triplane: shift needs at least 3 columns");
   INSTAG_REQUIRE(dshift == nullptr || (shift != nullptr && dxyz != nullptr), "triplane_backward: dshift needs shift and dxyz");
   TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound, shift, shift_stride, shift_scale};

@@ -66,8 +66,7 @@ class _grid_encode(Function):
         check(_lib.lib().instag_grid_encode_backward(ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets),
                                                      ptr(grad_embeddings), B, D, C, L, S, H, ptr(dy_dx),
                                                      ptr(grad_inputs), gridtype, int(ctx.align_corners),
-                                                     interpolation, None, 0, embeddings.shape[0],
-                                                     _lib.current_stream()), "grid_encode_backward")
+                                                     interpolation, _lib.current_stream()), "grid_encode_backward")
         return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
 
 
@@ -142,10 +141,14 @@ class GridEncoder(nn.Module):
         if self.embeddings.grad is None:
             raise ValueError('grad is None, should be called after loss.backward() and before optimizer.step()!')
         inputs = inputs.contiguous().float()
-        check(_lib.lib().instag_grid_total_variation(ptr(inputs), ptr(self.embeddings), ptr(self.embeddings.grad),
-                                                     ptr(self.offsets), float(weight), B, D, C, L, S, H,
-                                                     self.gridtype_id, int(self.align_corners),
-                                                     _lib.current_stream()), "grad_total_variation")
+        lib = _lib.lib()
+        total = int(self.embeddings.shape[0])
+        ws = torch.empty(lib.instag_grid_total_variation_workspace_bytes(total, C), dtype=torch.uint8,
+                         device=self.embeddings.device)
+        check(lib.instag_grid_total_variation(ptr(inputs), ptr(self.embeddings), ptr(self.embeddings.grad),
+                                              ptr(self.offsets), float(weight), B, D, C, L, S, H,
+                                              self.gridtype_id, int(self.align_corners), total, ptr(ws), ws.numel(),
+                                              _lib.current_stream()), "grad_total_variation")
 
 
 class _tri_plane_encode(Function):

@@ -124,6 +124,15 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
                                  p_motion_preds["_p"], motion_reg_weight)
         means3D, scales, rotations, opacity = outs_d[:4]
         motion_reg = outs_d[4] if motion_reg_weight is not None else None
+        # The reference scales the universal field's displacement IN PLACE (d_xyz *= p_scale, :217): the dictionary it
+        # returns under "motion" -- and motion_net.cache, the same object, which the mouth branch reads at inference
+        # (:362-363) -- holds the scaled value.  The fused operator never materialises it; the entries are rebuilt on
+        # first access (the regulariser inside deform_activate uses the scaled value too).
+        h_, p_ = motion_preds["_h"], p_motion_preds["_p"]
+        motion_preds["d_xyz"] = lambda: (h_[..., :3] * 1e-2) * (torch.tanh(p_[..., 3:] / 5) * 0.25 + 1)
+        if getattr(motion_net, "cache", None) is not None:
+            hd, pd = h_.detach(), p_.detach()
+            motion_net.cache["d_xyz"] = lambda: (hd[..., :3] * 1e-2) * (torch.tanh(pd[..., 3:] / 5) * 0.25 + 1)
     else:
         d_xyz, d_scale, d_rot = motion_preds["d_xyz"], motion_preds["d_scale"], motion_preds["d_rot"]
         if personalized:
@@ -132,6 +141,18 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             d_rot = d_rot + p_motion_preds["d_rot"]
         if align:
             d_xyz = d_xyz * p_motion_preds["p_scale"]
+        # in-place semantics of the reference (d_xyz += ..., d_xyz *= p_scale mutate the entries of the returned
+        # dictionary and of motion_net.cache, gaussian_renderer/__init__.py:207-217): the regularisers of
+        # train_face.py:508-514 and the mouth branch's jaw feature at inference see the combined, scaled values
+        if personalized or align:
+            motion_preds["d_xyz"] = d_xyz
+            if personalized:
+                motion_preds["d_scale"], motion_preds["d_rot"] = d_scale, d_rot
+            cache = getattr(motion_net, "cache", None)
+            if cache is not None:
+                cache["d_xyz"] = d_xyz.detach()
+                if personalized:
+                    cache["d_scale"], cache["d_rot"] = d_scale.detach(), d_rot.detach()
         if detach_motion:
             d_xyz, d_scale, d_rot = d_xyz.detach(), d_scale.detach(), d_rot.detach()
         means3D = pc.get_xyz + d_xyz

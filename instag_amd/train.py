@@ -259,10 +259,9 @@ class FaceTrainer:
             m, pm = pkg["motion"], pkg["p_motion"]
             if pkg.get("motion_reg") is not None:
                 extra, w_extra = pkg["motion_reg"], 1.0        # already weighted, computed by the deform operator
-            elif pkg["render"].is_cuda and m.get("_h") is not None and pm.get("_p") is not None:
-                from .glue import motion_l1_reg
-                extra = motion_l1_reg(m["_h"], pm["_p"])
             else:
+                # (the dictionary entries: render_motion has written the combined, scaled displacements back into
+                # them, as the reference's in-place arithmetic does)
                 extra = (m["d_xyz"].abs().mean() + m["d_rot"].abs().mean() + m["d_opa"].abs().mean()
                          + m["d_scale"].abs().mean() + pm["p_xyz"].abs().mean())
             alpha, attn, lips = pkg["alpha"], pkg["attn"], td["lips_rect"].to(dev)

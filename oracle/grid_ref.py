@@ -9,6 +9,9 @@ Restates /root/reference/gridencoder/src/gridencoder.cu:
                                           out-of-[0,1] input -> zeros, dy_dx[b, l, d, c]
   kernel_grid_backward         :248-340  grad_grid[index] += w * grad  (atomicAdd)
   kernel_input_backward        :343-369  grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]
+  kernel_grad_tv               :506-610  per sample and level: vertex v = floor(x*scale + 0.5); over its 2D axis
+                                          neighbours n (inside [0, resolution]): r = sum (e[v]-e[n]), q = sum (e[v]-e[n])^2;
+                                          grad[v] += weight/(2D) * r * rsqrt(q + 1e-9)
 and the host-side parameterisation of /root/reference/gridencoder/grid.py:
   per_level_scale / offsets    :101-128
   input mapping (x+bound)/(2 bound) :149, outputs [L,B,C] -> [B, L*C] :57
@@ -162,6 +165,39 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, S, H, dy_dx=None,
         dd = dy_dx.reshape(B, L, D, C).astype(np.float64)
         gi = np.einsum("lbc,bldc->bd", grad.astype(np.float64), dd).astype(np.float32)
     return ge.astype(np.float32), gi
+
+
+def grad_total_variation(inputs, embeddings, grad, offsets, weight, S, H, gridtype=0, align_corners=False):
+    """gridencoder.cu:506-610 (grid.py:165-185): adds the total-variation gradient of the table entries hit by
+    `inputs` [B,D] in [0,1] into `grad` [sO,C] (float64 accumulation; returned as a new float32 array)."""
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+    B, D = inputs.shape
+    C = embeddings.shape[1]
+    L = len(offsets) - 1
+    out = grad.astype(np.float64).copy()
+    ok = ~((inputs < 0) | (inputs > 1)).any(axis=1)
+    x = inputs[ok]
+    w = np.float32(np.float32(weight) / np.float32(2 * D))
+    with np.errstate(over="ignore"):
+        for level in range(L):
+            grid = embeddings[offsets[level]:offsets[level + 1]]
+            hashmap_size = int(offsets[level + 1] - offsets[level])
+            _, resolution, pos_grid, _, _ = _level_setup(x, level, S, H, align_corners, 0)
+            index = _grid_index(gridtype, align_corners, hashmap_size, resolution, pos_grid).astype(np.int64)
+            r = np.zeros((x.shape[0], C), dtype=np.float32)
+            q = np.zeros((x.shape[0], C), dtype=np.float32)
+            for d in range(D):
+                cur = pos_grid[:, d]
+                for step, valid in ((1, cur < resolution), (-1, cur > 0)):
+                    pg = pos_grid.copy()
+                    pg[:, d] = (cur.astype(np.int64) + step).astype(np.uint32)
+                    nb = _grid_index(gridtype, align_corners, hashmap_size, resolution, pg).astype(np.int64)
+                    gv = (grid[index] - grid[nb]).astype(np.float32) * valid[:, None]
+                    r = r + gv
+                    q = q + gv * gv
+            term = (w * r * (np.float32(1.0) / np.sqrt(q + np.float32(1e-9)))).astype(np.float64)
+            np.add.at(out, index + int(offsets[level]), term)
+    return out.astype(np.float32)
 
 
 class GridEncoderRef:

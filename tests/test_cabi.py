@@ -57,3 +57,24 @@ def test_drop_in_package_names_import():
     assert shencoder.SHEncoder(3, 4).output_dim == 16
     from simple_knn._C import distCUDA2
     assert callable(distCUDA2)
+
+
+def test_backend_module_names_import():
+    """The module names the reference's own binding files look for first (gridencoder/grid.py:9-10,
+    shencoder/sphere_harmonics.py:9-10) exist and export the pybind entry points of bindings.cpp."""
+    import inspect
+    import _gridencoder
+    import _shencoder
+    sigs = {
+        (_gridencoder, "grid_encode_forward"): ["inputs", "embeddings", "offsets", "outputs", "B", "D", "C", "L", "S", "H",
+                                                "dy_dx", "gridtype", "align_corners", "interp"],
+        (_gridencoder, "grid_encode_backward"): ["grad", "inputs", "embeddings", "offsets", "grad_embeddings", "B", "D",
+                                                 "C", "L", "S", "H", "dy_dx", "grad_inputs", "gridtype", "align_corners",
+                                                 "interp"],
+        (_gridencoder, "grad_total_variation"): ["inputs", "embeddings", "grad", "offsets", "weight", "B", "D", "C", "L",
+                                                 "S", "H", "gridtype", "align_corners"],
+        (_shencoder, "sh_encode_forward"): ["inputs", "outputs", "B", "D", "C", "dy_dx"],
+        (_shencoder, "sh_encode_backward"): ["grad", "inputs", "B", "D", "C", "dy_dx", "grad_inputs"],
+    }
+    for (mod, name), params in sigs.items():
+        assert list(inspect.signature(getattr(mod, name)).parameters) == params, name

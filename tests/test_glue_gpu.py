@@ -344,7 +344,8 @@ def test_deform_activate_with_fused_regulariser():
         scales = torch.nn.functional.softplus(t["scaling"] + t["h"][:, 8:11])
         rots = torch.nn.functional.normalize(t["rotation"] + t["h"][:, 3:7])
         op = torch.sigmoid(t["opacity"])
-        reg = ((t["h"][:, :3] * 1e-2).abs().mean() + t["h"][:, 3:7].abs().mean() + t["h"][:, 7:8].abs().mean()
+        # d_xyz as the reference's dictionary holds it after `d_xyz *= p_scale` (gaussian_renderer/__init__.py:217)
+        reg = (((t["h"][:, :3] * 1e-2) * ps).abs().mean() + t["h"][:, 3:7].abs().mean() + t["h"][:, 7:8].abs().mean()
                + t["h"][:, 8:11].abs().mean() + (t["p"][:, :3] * 1e-2).abs().mean())
         return means, scales, rots, op, w * reg
 

@@ -364,3 +364,123 @@ def test_face_schedule_replays_one_graph_per_phase():
         assert tr._graph is None and not tr._graph_cache
     finally:
         diff_gauss.set_capacity_plan(None)
+
+
+def _plain_render_motion(frame, pc, motion_net, bg, personalized, align):
+    """gaussian_renderer/__init__.py:188-283 written with plain torch ops and the reference's IN-PLACE arithmetic on the
+    motion dictionary (d_xyz += ..., d_xyz *= p_scale), two or three separate rasterizer calls."""
+    import math
+    from instag_amd.diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
+    s = GaussianRasterizationSettings(
+        image_height=frame.image_height, image_width=frame.image_width, tanfovx=math.tan(frame.FoVx * 0.5),
+        tanfovy=math.tan(frame.FoVy * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=frame.world_view_transform,
+        projmatrix=frame.full_proj_transform, sh_degree=pc.active_sh_degree, campos=frame.camera_center,
+        prefiltered=False, debug=False)
+    rast = GaussianRasterizer(s)
+    aud, exp = frame.talking_dict["auds"], frame.talking_dict["au_exp"]
+    xyz = pc.get_xyz
+    p = pc.neural_motion_grid(pc.get_xyz, aud, exp) if (personalized or align) else None
+    if align:
+        xyz = xyz + p["p_xyz"]
+    m = dict(motion_net(xyz, aud, exp).items())            # materialised entries, like the reference's dict
+    d_xyz, d_scale, d_rot = m["d_xyz"], m["d_scale"], m["d_rot"]
+    if personalized:
+        d_xyz += p["d_xyz"]
+        d_scale += p["d_scale"]
+        d_rot += p["d_rot"]
+    if align:
+        d_xyz *= p["p_scale"]
+    means3D = pc.get_xyz + d_xyz
+    opacity = pc.get_opacity
+    scales = pc.scaling_activation(pc._scaling + d_scale)
+    rots = pc.rotation_activation(pc._rotation + d_rot)
+    m2 = torch.zeros_like(pc.get_xyz, requires_grad=True)
+    ones = torch.ones_like(opacity)
+    img, depth, normal, alpha, radii, extra = rast(means3D=means3D, means2D=m2, shs=pc.get_features, opacities=opacity,
+                                                   scales=scales, rotations=rots, extra_attrs=ones)
+
+    def attn_of(preds):
+        col = torch.cat([preds["ambient_aud"], preds["ambient_eye"], torch.zeros_like(preds["ambient_eye"])], dim=-1)
+        return rast(means3D=means3D.detach(), means2D=m2, colors_precomp=col, opacities=opacity.detach(),
+                    scales=scales.detach(), rotations=rots.detach(), extra_attrs=ones)[0]
+    return dict(render=img, depth=depth, normal=normal, alpha=alpha, radii=radii, motion=m, attn=attn_of(m),
+                p_attn=attn_of(p) if personalized else None, viewspace_points=m2, p_motion=p)
+
+
+@pytest.mark.parametrize("personalized,align", [(True, True), (True, False), (False, True), (False, False)],
+                         ids=["personalized+align", "personalized", "align(fused operator)", "plain"])
+def test_render_motion_branches_match_plain_torch(personalized, align):
+    """render_motion in every (personalized, align) combination == the reference's lines transcribed with plain torch
+    ops: images, both attention maps, the motion dictionary AFTER the reference's in-place updates (what the
+    regularisers of train_face.py:508-514 read) and motion_net.cache (what the mouth branch reads at inference,
+    gaussian_renderer/__init__.py:362-363), plus gradients of a loss over image + attention maps + d_xyz."""
+    from instag_amd.renderer import render_motion
+    from instag_amd.train import build_trainer
+    dev = torch.device("cuda")
+    frame = _frames(96, 1, dev, priors=True)[0]
+    tr = build_trainer(2500, dev, seed=4)
+    g = torch.Generator().manual_seed(9)
+    w_img, w_att = torch.randn(3, 96, 96, generator=g).to(dev), torch.randn(3, 96, 96, generator=g).to(dev)
+
+    def loss_of(pkg):
+        ls = (pkg["render"] * w_img).sum() + pkg["alpha"].sum() + (pkg["attn"] * w_att).sum() \
+            + 10.0 * pkg["motion"]["d_xyz"].abs().mean() + pkg["motion"]["d_rot"].abs().mean()
+        if personalized:
+            ls = ls + (pkg["p_attn"] * w_att).sum()
+        return ls
+
+    want = _plain_render_motion(frame, tr.g, tr.motion_net, tr.bg, personalized, align)
+    loss_of(want).backward()
+    ref = _grads(tr)
+    ref_m2d = want["viewspace_points"].grad.clone()
+    tr._zero_grad()
+    got = render_motion(frame, tr.g, tr.motion_net, None, tr.bg, return_attn=True, personalized=personalized,
+                        align=align)
+    cache_dxyz = tr.motion_net.cache["d_xyz"]
+    loss_of(got).backward()
+    mine = _grads(tr)
+    for k in ("render", "alpha", "depth", "normal", "attn") + (("p_attn",) if personalized else ()):
+        assert float((got[k] - want[k]).abs().max()) <= 2e-6, k
+    assert torch.equal(got["radii"], want["radii"])
+    for k in ("d_xyz", "d_rot", "d_scale"):
+        assert float((got["motion"][k] - want["motion"][k]).abs().max()) <= 1e-7, k
+    assert not cache_dxyz.requires_grad
+    assert float((cache_dxyz - want["motion"]["d_xyz"].detach()).abs().max()) <= 1e-7
+    assert set(mine) == set(ref), set(mine) ^ set(ref)
+    for k in ref:
+        scale = float(ref[k].abs().max())
+        assert float((mine[k] - ref[k]).abs().max()) <= 2e-4 * scale + 1e-9, k
+    m2d = got["viewspace_points"].grad
+    assert float((m2d - ref_m2d).abs().max()) <= 2e-4 * float(ref_m2d.abs().max()) + 1e-9
+
+
+def test_static_render_matches_direct_rasterizer_call():
+    """render() (gaussian_renderer/__init__.py:37-133): the dictionary it returns == a direct rasterizer call on the
+    model's activated parameters; override_color switches to colors_precomp."""
+    import math
+    from instag_amd.diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
+    from instag_amd.renderer import render
+    from instag_amd.train import build_trainer
+    dev = torch.device("cuda")
+    frame = _frames(96, 1, dev)[0]
+    tr = build_trainer(2500, dev, seed=6)
+    pc = tr.g
+    s = GaussianRasterizationSettings(
+        image_height=frame.image_height, image_width=frame.image_width, tanfovx=math.tan(frame.FoVx * 0.5),
+        tanfovy=math.tan(frame.FoVy * 0.5), bg=tr.bg, scale_modifier=1.0, viewmatrix=frame.world_view_transform,
+        projmatrix=frame.full_proj_transform, sh_degree=pc.active_sh_degree, campos=frame.camera_center,
+        prefiltered=False, debug=False)
+    for override in (None, torch.rand(pc.get_xyz.shape[0], 3, device=dev)):
+        pkg = render(frame, pc, None, tr.bg, override_color=override)
+        m2 = torch.zeros_like(pc.get_xyz, requires_grad=True)
+        img, depth, normal, alpha, radii, extra = GaussianRasterizer(s)(
+            means3D=pc.get_xyz, means2D=m2, shs=pc.get_features if override is None else None,
+            colors_precomp=override, opacities=pc.get_opacity, scales=pc.get_scaling, rotations=pc.get_rotation,
+            extra_attrs=torch.ones_like(pc.get_opacity))
+        assert torch.equal(pkg["render"], img) and torch.equal(pkg["depth"], depth) and torch.equal(pkg["alpha"], alpha)
+        assert torch.equal(pkg["normal"], normal) and torch.equal(pkg["radii"], radii)
+        assert torch.equal(pkg["visibility_filter"], radii > 0)
+        pkg["render"].sum().backward()
+        img.sum().backward()
+        assert torch.equal(pkg["viewspace_points"].grad, m2.grad)
+        tr._zero_grad()
