@@ -128,6 +128,9 @@ class GaussianModel:
         self.percent_dense = 0.0
         self.spatial_lr_scale = 1.0
         self.neural_motion_grid = neural_motion_grid
+        # GridRenderer: built with the point cloud (scene/gaussian_model.py:317), registered in Adam (:394), stored in
+        # every checkpoint (:130), never evaluated by any InsTaG script
+        self.neural_renderer = None
         self.scaling_activation = torch.nn.functional.softplus
         self.scaling_inverse_activation = inverse_softplus
         self.opacity_activation = torch.sigmoid
@@ -199,7 +202,15 @@ class GaussianModel:
         self._p = {k: nn.Parameter(v.detach().clone().float().to(device).contiguous().requires_grad_(True))
                    for k, v in vals.items()}
         self.max_radii2D = torch.zeros(n, device=device)
+        self._build_neural_renderer()
         return self
+
+    def _build_neural_renderer(self):
+        """scene/gaussian_model.py:317-320: bound = 1.2 x half the largest extent of the cloud, centred on its mean."""
+        from .neural_renderer import GridRenderer
+        xyz = self._p["xyz"].detach()
+        bound = ((xyz.max(0).values - xyz.min(0).values).max()) / 2 * 1.2
+        self.neural_renderer = GridRenderer(bound=bound.cpu(), coord_center=xyz.mean(0).cpu()).to(xyz.device)
 
     def create_from_pcd(self, points, colors, spatial_lr_scale: float, device="cuda"):
         """Initialise from a point cloud like scene/gaussian_model.py:206-335: SH DC = RGB2SH(colour), opacity 0.1,
@@ -283,21 +294,30 @@ class GaussianModel:
         return self.load_raw(raw, device)
 
     def capture(self):
-        """Same 15-tuple as the reference's checkpoint (GridRenderer state = None: dead code there)."""
+        """Same 15-tuple as the reference's checkpoint (scene/gaussian_model.py:115-131), including the GridRenderer's
+        and the personalised field's state_dicts and the optimizer state in torch.optim's format."""
         opt = self.optimizer.state_dict() if hasattr(self.optimizer, "state_dict") else None
         nmg = None if self.neural_motion_grid is None else self.neural_motion_grid.state_dict()
+        nr = None if self.neural_renderer is None else self.neural_renderer.state_dict()
         p = self._p
         return (self.active_sh_degree, p["xyz"], p["f_dc"], p["f_rest"], p["identity"], p["scaling"], p["rotation"],
-                p["opacity"], self.max_radii2D, self.xyz_gradient_accum, self.denom, opt, self.spatial_lr_scale, None, nmg)
+                p["opacity"], self.max_radii2D, self.xyz_gradient_accum, self.denom, opt, self.spatial_lr_scale, nr, nmg)
 
     def restore(self, model_args, training_args=None):
         (self.active_sh_degree, xyz, f_dc, f_rest, identity, scaling, rotation, opacity, max_radii2D,
-         xyz_gradient_accum, denom, opt_dict, self.spatial_lr_scale, _neural_renderer_state, nmg_state) = model_args
+         xyz_gradient_accum, denom, opt_dict, self.spatial_lr_scale, neural_renderer_state, nmg_state) = model_args
         dev = xyz.device
         vals = dict(xyz=xyz, f_dc=f_dc, f_rest=f_rest, identity=identity, opacity=opacity, scaling=scaling,
                     rotation=rotation)
         self._p = {k: nn.Parameter(v.detach().clone().float().contiguous().requires_grad_(True)) for k, v in vals.items()}
         self.max_radii2D = max_radii2D.detach().clone()
+        if neural_renderer_state is not None:
+            from .neural_renderer import GridRenderer
+            self.neural_renderer = GridRenderer()                    # :153-156
+            self.neural_renderer.recover_from_ckpt(neural_renderer_state)
+            self.neural_renderer.to(dev)
+        elif self.neural_renderer is None:
+            self._build_neural_renderer()
         if nmg_state is not None and self.neural_motion_grid is not None:
             self.neural_motion_grid.load_state_dict(nmg_state)
         if training_args is not None:
@@ -319,6 +339,10 @@ class GaussianModel:
                    f_rest=opt.feature_lr / 20.0, identity=1e-2, opacity=opt.opacity_lr, scaling=opt.scaling_lr,
                    rotation=opt.rotation_lr)
         groups = [{"params": [self._p[k]], "lr": lrs[k], "name": k} for k in PARAM_NAMES]
+        if self.neural_renderer is not None:
+            # same groups at the same position as scene/gaussian_model.py:394, so that a reference optimizer
+            # state_dict (groups matched by position) loads; the parameters never receive a gradient
+            groups += self.neural_renderer.get_params(lr=5e-3, lr_net=5e-4)
         if self.neural_motion_grid is not None:
             groups += self.neural_motion_grid.get_params(lr=1e-3, lr_net=1e-4)
         if fused is None:

@@ -78,6 +78,10 @@ class MultiTensorAdam:
             for p in g["params"]:
                 if not p.is_cuda:
                     raise RuntimeError("MultiTensorAdam runs on the GPU only")
+                if p.grad is None and "exp_avg" not in self._state_of(p):
+                    # never had a gradient (e.g. the GridRenderer's tables): no state, no work -- like torch.optim.Adam,
+                    # which creates a parameter's state when its first gradient arrives
+                    continue
                 st = self._ensure_state(p)
                 grad = p.grad
                 if grad is not None and not grad.is_contiguous():

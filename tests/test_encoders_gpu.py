@@ -288,3 +288,36 @@ def test_tri_plane_encode_with_shift():
     assert float(gp_f[:, 3:].abs().max()) == 0.0
     for a, b in zip(ge_f, ge_r):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+def test_grid_renderer_constructs_runs_and_stays_out_of_adam():
+    """GridRenderer (scene/neural_renderer.py:49-222): constructed with every Gaussian model, never evaluated by
+    InsTaG.  forward == its parts composed by hand (3-D hashed encoder checked against the oracle above); its
+    parameters sit in the optimizer's groups but, never receiving a gradient, get no Adam state and no work."""
+    from instag_amd.gaussian_model import GaussianModel, OptimizationParams
+    from instag_amd.neural_renderer import GridRenderer
+    from instag_amd.optim import MultiTensorAdam
+    nr = GridRenderer(bound=0.3, coord_center=[0.01, -0.02, 0.0]).cuda()
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(4000, 3, generator=g) * 0.5 - 0.25).cuda()
+    d = torch.nn.functional.normalize(torch.randn(4000, 3, generator=g), dim=-1).cuda()
+    sigma, color = nr(x, d)
+    assert sigma.shape == (4000,) and color.shape == (4000, 3)
+    assert bool(torch.isfinite(sigma).all()) and float(color.min()) >= -0.001 and float(color.max()) <= 1.001
+    enc = nr.encoder_x(x - nr.coord_center, bound=0.3)
+    h = nr.sigma_net(enc)
+    assert torch.equal(sigma, h[..., 0])
+    want = torch.sigmoid(nr.color_net(torch.cat([nr.encoder_dir(d), h[..., 1:]], dim=-1))) * 1.002 - 0.001
+    assert torch.equal(color, want)
+    (sigma.sum() + color.sum()).backward()
+    assert nr.encoder_x.embeddings.grad is not None and float(nr.encoder_x.embeddings.grad.abs().max()) > 0
+    gm = GaussianModel(1).create_random(500, "cuda", seed=3)
+    gm.training_setup(OptimizationParams)
+    assert isinstance(gm.optimizer, MultiTensorAdam)
+    for p in gm.per_gaussian_parameters():
+        p.grad = torch.randn_like(p) * 1e-3
+    gm.optimizer.step()
+    torch.cuda.synchronize()
+    with_state = [grp["name"] for grp in gm.optimizer.param_groups
+                  if any("exp_avg" in gm.optimizer.state.get(p, {}) for p in grp["params"])]
+    assert with_state == ["xyz", "f_dc", "f_rest", "identity", "opacity", "scaling", "rotation"]

