@@ -20,7 +20,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _keepalive, _lib
 from ._lib import check, ptr
 
 _STATE = {"active": False, "jobs": [], "streams": {}, "forked": set()}
@@ -44,8 +44,8 @@ def flush_async(device):
     with torch.cuda.stream(side):
         _flush(jobs)
     for dz, inp, _ in jobs:
-        dz.record_stream(side)
-        inp.record_stream(side)
+        _keepalive.cross_stream(dz, side)
+        _keepalive.cross_stream(inp, side)
     _STATE["forked"].add(key)
 
 

@@ -18,7 +18,7 @@ from typing import NamedTuple, Optional
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _keepalive, _lib
 from ._lib import RasterArgs, check, ptr
 
 
@@ -371,7 +371,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     d_aux, m2d_aux = rasterize_aux_backward(st, g_aux, need[10], need[1])
             for t in (g_aux, d_aux, m2d_aux):
                 if t is not None:
-                    t.record_stream(side)
+                    _keepalive.cross_stream(t, side)
             if DEFER_AUX_JOIN and (m2d_aux is None or ctx.means2D_leaf is not None):
                 # The caller promised to call join_pending_aux() before it touches the aux gradients (the trainer
                 # does, in the glue operator that consumes them) and join_pending_aux(final=True) after backward:

@@ -342,7 +342,7 @@ class GaussianModel:
         if self.neural_renderer is not None:
             # same groups at the same position as scene/gaussian_model.py:394, so that a reference optimizer
             # state_dict (groups matched by position) loads; the parameters never receive a gradient
-            groups += self.neural_renderer.get_params(lr=5e-3, lr_net=5e-4)
+            groups += [dict(g, lazy=True) for g in self.neural_renderer.get_params(lr=5e-3, lr_net=5e-4)]
         if self.neural_motion_grid is not None:
             groups += self.neural_motion_grid.get_params(lr=1e-3, lr_net=1e-4)
         if fused is None:

@@ -242,9 +242,9 @@ class _TriPlaneField(nn.Module):
             with torch.cuda.stream(side):
                 enc_a, enc_e = self.encode_frame(a, e)
             main_stream.wait_stream(side)
-            enc_a.record_stream(main_stream)
-            if enc_e is not None:
-                enc_e.record_stream(main_stream)
+            from . import _keepalive
+            _keepalive.cross_stream(enc_a, main_stream)
+            _keepalive.cross_stream(enc_e, main_stream)
         else:
             enc_a, enc_e = self.encode_frame(a, e)
         if self.exp_eye and c is None and enc_x.is_cuda:

@@ -78,9 +78,10 @@ class MultiTensorAdam:
             for p in g["params"]:
                 if not p.is_cuda:
                     raise RuntimeError("MultiTensorAdam runs on the GPU only")
-                if p.grad is None and "exp_avg" not in self._state_of(p):
-                    # never had a gradient (e.g. the GridRenderer's tables): no state, no work -- like torch.optim.Adam,
-                    # which creates a parameter's state when its first gradient arrives
+                if g.get("lazy") and p.grad is None and "exp_avg" not in self._state_of(p):
+                    # a group marked "lazy" (the GridRenderer's: its tables never receive a gradient) gets state and work
+                    # when a first gradient arrives, like torch.optim.Adam.  Every other parameter is part of the launch
+                    # from the first step on, gradient or not, so that the layout a captured step bakes in never changes.
                     continue
                 st = self._ensure_state(p)
                 grad = p.grad

@@ -11,6 +11,7 @@ import math
 
 import torch
 
+from . import _keepalive
 from .diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
 from .motion_net import MotionNetwork as _MotionNetwork
 
@@ -202,7 +203,7 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         main_stream.wait_stream(side)
         for t in (rendered_attn, p_rendered_attn):
             if t is not None:
-                t.record_stream(main_stream)
+                _keepalive.cross_stream(t, main_stream)
     elif return_attn:
         if not shared:
             rendered_attn = attn_pass(motion_preds)

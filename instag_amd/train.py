@@ -476,8 +476,11 @@ class FaceTrainer:
 
 
 class _no_gc:
-    """No cyclic garbage collection inside a stream-capture window: a collection there would release device tensors
-    (and events) of earlier steps while the capture is open, which intermittently aborts on ROCm 7.2."""
+    """No cyclic garbage collection inside a stream-capture window.  The crash this once papered over (a segmentation
+    fault in capture_end) is addressed at its cause in instag_amd/_keepalive.py: tensors that cross streams are no
+    longer marked with record_stream inside a capture, the capture's owner keeps them alive until it has ended.  The
+    collector stays off during the window all the same: a collection there frees an earlier step's blocks into the
+    capture's private pool at an arbitrary point of the captured sequence, which makes captures irreproducible."""
 
     def __enter__(self):
         import gc
@@ -567,6 +570,8 @@ class GraphedStep:
                     t._update_stats(self._vs_grad, self._radii)        # local; exchanged when a densification reads them
                     t._step_optimizers()
                     t._zero_grad()
+        from . import _keepalive
+        _keepalive.release()               # the captures have ended: cross-stream tensors held for them may go
         self.loss, self.l1 = loss, l1
         self.capacity = cap
 

@@ -146,6 +146,8 @@ class GraphedStage:
         # releasing it inside the capture window intermittently crashes hipStreamEndCapture), then it is dropped
         self.out = tuple(out[:-1])
         del out
+        from . import _keepalive
+        _keepalive.release()               # the capture has ended: cross-stream tensors held for it may go
 
     CHECK_EVERY = 64         # replays between two looks at the (sticky, device-side) overflow flags
 
