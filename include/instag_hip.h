@@ -114,6 +114,11 @@ typedef struct instag_raster_args {
   int32_t image_height, image_width;
   float tanfovx, tanfovy, scale_modifier;
   int32_t prefiltered, debug;
+  /* execution hint (in the struct's former padding): 1 = keep every launch of this call on `stream`.  By default the
+     depth sort of the Gaussians is forked onto a second stream beside the preprocess kernel; a caller that is itself
+     running on a stream FORKED inside a stream capture must set this -- a fork of a fork inside one capture crashes
+     hipStreamEndCapture on ROCm 7.2 (scripts/probes/infer_capture_probe2.py) */
+  int32_t single_stream;
   /* camera (device): bg[3], viewmatrix[16], projmatrix[16] (row-vector convention, i.e. the
      transposed matrices of scene/cameras.py:61-64), campos[3] */
   const float *bg, *viewmatrix, *projmatrix, *campos;

@@ -40,12 +40,52 @@ class RasterArgs(C.Structure):
         ("N", i32), ("M", i32), ("sh_degree", i32), ("E", i32),
         ("image_height", i32), ("image_width", i32),
         ("tanfovx", f32), ("tanfovy", f32), ("scale_modifier", f32),
-        ("prefiltered", i32), ("debug", i32),
+        ("prefiltered", i32), ("debug", i32), ("single_stream", i32),
         ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp),
         ("means3D", vp), ("shs", vp), ("colors_precomp", vp), ("opacities", vp),
         ("scales", vp), ("rotations", vp), ("cov3Ds_precomp", vp), ("extra_attrs", vp),
         ("shs_rest", vp),
     ]
+
+
+# ---- stream capture bookkeeping -------------------------------------------------------------------------------------
+# A fork of a fork inside ONE stream capture (origin stream -> stream A -> stream B, B joined back into A, A into the
+# origin) crashes hipStreamEndCapture on ROCm 7.2 (segmentation fault inside capture_end; bisected with
+# scripts/probes/infer_capture_probe2.py: any operator that forks internally -- the rasterizer's depth-sort stream, a
+# motion network's per-frame branch -- breaks a capture when it is itself called on a forked stream, the same
+# operators on the origin stream, or without their internal fork, capture fine).  So while a capture is open,
+# operators fork only from the capture's ORIGIN stream, which the owners of our captures announce here.
+_CAPTURE_ORIGIN = None
+
+
+class graph_capture:
+    """``torch.cuda.graph(graph, **kw)`` that also records the capture's origin stream for may_fork()."""
+
+    def __init__(self, graph, **kw):
+        import torch
+        self._ctx = torch.cuda.graph(graph, **kw)
+
+    def __enter__(self):
+        global _CAPTURE_ORIGIN
+        import torch
+        r = self._ctx.__enter__()
+        self._prev = _CAPTURE_ORIGIN
+        _CAPTURE_ORIGIN = torch.cuda.current_stream()
+        return r
+
+    def __exit__(self, *exc):
+        global _CAPTURE_ORIGIN
+        _CAPTURE_ORIGIN = self._prev
+        return self._ctx.__exit__(*exc)
+
+
+def may_fork(device=None) -> bool:
+    """May an operator fork work onto a second stream from the current stream?  Always outside a capture; inside one
+    only from the capture's origin stream (a capture somebody else opened: origin unknown -> no)."""
+    import torch
+    if not torch.cuda.is_current_stream_capturing():
+        return True
+    return _CAPTURE_ORIGIN is not None and torch.cuda.current_stream(device) == _CAPTURE_ORIGIN
 
 
 _PROTOS = {

@@ -125,9 +125,11 @@ def frame_codes(field, a, e):
     dims = (int(a.shape[1]), int(field.audio_net.encoder_conv[0].out_channels), int(field.audio_att_net.dim_aud))
     # arrival counter of the forward's eight workgroups: one word per network (the universal and the personalised
     # field's branches run on different streams at the same time), zero between launches
-    arrivals = getattr(field, "_frame_code_arrivals", None)
-    if arrivals is None or arrivals.device != a.device:
-        arrivals = torch.zeros(1, dtype=torch.int32, device=a.device)
-        field._frame_code_arrivals = arrivals
+    # (and per stream: frames streamed through several lanes at once must not share it either)
+    table = field.__dict__.setdefault("_frame_code_arrivals", {})
+    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream)
+    arrivals = table.get(key)
+    if arrivals is None:
+        arrivals = table[key] = torch.zeros(1, dtype=torch.int32, device=a.device)
     enc_a, enc_e = _FrameCodes.apply(a, None if e is None else e.reshape(-1), dims, arrivals, *params)
     return enc_a, (enc_e if e is not None else None)

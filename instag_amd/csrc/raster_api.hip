@@ -1,4 +1,5 @@
 // C-ABI entry points of the rasterizer (see include/instag_hip.h) + buffer layouts, scan and sort.
+#include <cstdlib>
 #include <cstring>
 
 #include <mutex>
@@ -49,21 +50,27 @@ ProfScope::~ProfScope() {
 namespace {
 struct SideLane {
   int device = -1;
-  hipStream_t stream = nullptr;
+  hipStream_t caller = nullptr, stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
 };
-thread_local SideLane g_side;
+// a few lanes per thread, one per caller stream (frames streamed through several streams at once keep their depth
+// sorts apart); round-robin replacement is never needed in practice: callers use a handful of streams
+constexpr int MAX_LANES = 8;
+thread_local SideLane g_lanes[MAX_LANES];
 
 SideLane* side_lane(hipStream_t caller) {
+  static const bool disabled = getenv("INSTAG_NO_SIDE_LANE") != nullptr;      // diagnostics
+  if (disabled) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  if (g_side.stream != nullptr && g_side.device == dev) return &g_side;
+  SideLane* free_slot = nullptr;
+  for (SideLane& l : g_lanes) {
+    if (l.stream != nullptr && l.device == dev && l.caller == caller) return &l;
+    if (l.stream == nullptr && free_slot == nullptr) free_slot = &l;
+  }
+  if (free_slot == nullptr) return nullptr;        // all lanes taken: the sort stays on the caller's stream
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-  if (g_side.stream != nullptr) {            // the thread moved to another device: rebuild
-    (void)hipEventDestroy(g_side.fork); (void)hipEventDestroy(g_side.join); (void)hipStreamDestroy(g_side.stream);
-    g_side = SideLane();
-  }
   SideLane l;
   if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||
@@ -72,8 +79,9 @@ SideLane* side_lane(hipStream_t caller) {
     return nullptr;
   }
   l.device = dev;
-  g_side = l;
-  return &g_side;
+  l.caller = caller;
+  *free_slot = l;
+  return free_slot;
 }
 }  // namespace
 
@@ -196,7 +204,7 @@ static int per_gaussian_stage(const instag_raster_args* a, const Camera& c, char
                               hipStream_t s) {
   uint32_t* tiles_touched = (uint32_t*)(gb + L.tiles_touched);
   uint32_t* point_offsets = (uint32_t*)(gb + L.point_offsets);
-  SideLane* lane = side_lane(s);
+  SideLane* lane = a->single_stream ? nullptr : side_lane(s);
   if (lane != nullptr) {
     INSTAG_CHECK_HIP(hipEventRecord(lane->fork, s));
     INSTAG_CHECK_HIP(hipStreamWaitEvent(lane->stream, lane->fork, 0));

@@ -148,6 +148,7 @@ def _make_args(s: GaussianRasterizationSettings, means3D, shs, colors, opac, sca
     a.image_height, a.image_width = int(s.image_height), int(s.image_width)
     a.tanfovx, a.tanfovy, a.scale_modifier = float(s.tanfovx), float(s.tanfovy), float(s.scale_modifier)
     a.prefiltered, a.debug = int(bool(s.prefiltered)), int(bool(s.debug))
+    a.single_stream = 0 if _lib.may_fork(means3D.device) else 1        # no fork of a fork inside a capture (_lib.py)
     a.bg, a.viewmatrix, a.projmatrix, a.campos = ptr(bg), ptr(view), ptr(proj), ptr(campos)
     a.means3D, a.shs, a.colors_precomp, a.opacities = ptr(means3D), ptr(shs), ptr(colors), ptr(opac)
     a.scales, a.rotations, a.cov3Ds_precomp, a.extra_attrs = ptr(scales), ptr(rots), ptr(cov3D), ptr(extra)

@@ -199,7 +199,8 @@ class _TriPlaneField(nn.Module):
         same `a` launches it on side stream `stream_index` behind an event recorded HERE, so on the device it
         overlaps everything the caller enqueues in between, while in the autograd graph it is created late
         (right before the glue that consumes it) and its backward is therefore scheduled early."""
-        if not (a.is_cuda and CONCURRENT_AUDIO):
+        from . import _lib
+        if not (a.is_cuda and CONCURRENT_AUDIO and _lib.may_fork(a.device)):
             return
         ev = self.__dict__.get("_audio_event")      # one reusable event per network (no create / destroy per step:
         if ev is None:                              # destroying an event while a stream capture is open aborts)
@@ -211,7 +212,8 @@ class _TriPlaneField(nn.Module):
         """-> (enc_x, ambient_aud [N,1], ambient_eye [N,1] or None, h [N,out_dim], amb3); amb3 = the [N,3] tensor
         (aud, eye, 0) the two ambient columns are views of (fused path) or None.  (Nothing of a step may be kept
         on the module: a live autograd graph across steps breaks stream capture.)"""
-        fork = x.is_cuda and CONCURRENT_AUDIO
+        from . import _lib
+        fork = x.is_cuda and CONCURRENT_AUDIO and _lib.may_fork(x.device)
         pending = self.__dict__.pop("_audio_pending", None)
         if enc_x is None:
             enc_x = self.encode_x(x, bound=self.bound, shift=x_shift)

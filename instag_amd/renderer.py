@@ -178,7 +178,9 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     # The attention map is rendered over the same (detached) geometry as the image: on the device it rides along
     # the main pass as an auxiliary colour set (one preprocess / binning / sort instead of two).
     shared = return_attn and means3D.is_cuda and SHARED_ATTN_PASS
-    fork = return_attn and means3D.is_cuda and CONCURRENT_PASSES and (personalized or not shared)
+    from . import _lib
+    fork = return_attn and means3D.is_cuda and CONCURRENT_PASSES and (personalized or not shared) \
+        and _lib.may_fork(dev)
     if fork:
         # remaining attention pass(es) only share inputs with the main pass: run them on a second stream
         main_stream = torch.cuda.current_stream(dev)

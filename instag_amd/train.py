@@ -29,6 +29,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from . import _lib
 from .gaussian_model import GaussianModel, OptimizationParams
 from .losses import face_loss
 
@@ -546,7 +547,7 @@ class GraphedStep:
         self.graph_b = None
         self.plan.begin_step()
         if not self.split:
-            with _no_gc(), torch.cuda.graph(self.graph_a, **mode):
+            with _no_gc(), _lib.graph_capture(self.graph_a, **mode):
                 pkg, loss, l1 = t._forward_backward(self.static, phase)
                 t._stats_and_optimizers(pkg, False)
                 t._zero_grad()
@@ -554,14 +555,14 @@ class GraphedStep:
             # window intermittently crash hipStreamEndCapture)
             del pkg
         else:
-            with _no_gc(), torch.cuda.graph(self.graph_a, **mode):
+            with _no_gc(), _lib.graph_capture(self.graph_a, **mode):
                 pkg, loss, l1 = t._forward_backward(self.static, phase)
                 self._vs_grad, self._radii = pkg["viewspace_points"].grad, pkg["radii"]
                 self._params = t._all_params()
                 self._bucket = flat_grad_bucket(self._params)
             del pkg
             self.graph_b = torch.cuda.CUDAGraph()
-            with _no_gc(), torch.cuda.graph(self.graph_b, **mode):
+            with _no_gc(), _lib.graph_capture(self.graph_b, **mode):
                 with torch.no_grad():
                     if self.distributed:
                         # mean over ranks of the summed gradients

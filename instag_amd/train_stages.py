@@ -14,6 +14,7 @@ from typing import Optional
 
 import torch
 
+from . import _lib
 from .gaussian_model import GaussianModel, OptimizationParams, sh_to_rgb
 from .losses import l1_and_ssim
 from .train import Frame
@@ -132,7 +133,7 @@ class GraphedStage:
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
         self.plan.begin_step()
-        with _no_gc(), torch.cuda.graph(self.graph):
+        with _no_gc(), _lib.graph_capture(self.graph):
             try:
                 out = body(self.static)
             except BaseException:

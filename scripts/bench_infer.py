@@ -27,3 +27,14 @@ for mode in ("eager", "graph"):
     dt = (time.perf_counter() - t0) / K
     print(f"inference {mode}: {1/dt:8.1f} frames/s  {dt*1e3:.3f} ms/frame  overflow={r.check_overflow()}", flush=True)
 r.close()
+for lanes in (2, 4, 8):
+    r.enable_graph(frames[0], frames_per_replay=lanes)
+    for _ in range(3): r.render_batch(frames[:lanes])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); K = 24
+    for i in range(K): r.render_batch([frames[(i + k) % 8] for k in range(lanes)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (K * lanes)
+    print(f"inference graph, {lanes} frames per replay: {1/dt:8.1f} frames/s  {dt*1e3:.3f} ms/frame  "
+          f"overflow={r.check_overflow()}", flush=True)
+    r.close()

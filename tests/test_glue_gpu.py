@@ -322,6 +322,18 @@ def test_fuse_renderer_graph_matches_eager():
             got = r.render(f)
             assert not r.check_overflow()
             assert torch.equal(got, e)
+        # streaming: three frames per replay, each on a lane of its own inside ONE graph (synthesize_fuse.py:34-92
+        # renders frame after frame; SURVEY 8(f)4 "batch frames per launch"); a group of five = one full + one padded
+        r.close()
+        r.enable_graph(frames[0], frames_per_replay=3)
+        got = r.render_batch(frames)
+        assert got.shape[0] == 3 and not r.check_overflow()
+        for k, e in enumerate(eager):
+            assert torch.equal(got[k], e), k
+        five = r.render_batch([frames[2], frames[0], frames[1], frames[1], frames[0]])
+        for k, j in enumerate((2, 0, 1, 1, 0)):
+            assert torch.equal(five[k], eager[j]), k
+        assert torch.equal(r.render(frames[1]), eager[1])
     finally:
         r.close()
         diff_gauss.set_capacity_plan(None)
