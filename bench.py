@@ -37,9 +37,11 @@ NON_RASTER = ("grid_fwd", "grid_bwd", "mlp_fwd", "mlp_bwd", "mlp_wgrad")
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA (32x32x2 / 16x16x4), 64 FLOP/clk/SIMD
 SIMDS, CLOCK_GHZ = 1024, 2.4
-# VALU instructions one wave issues per (Gaussian, 64-pixel wave) pair in the kernels' inner loops, counted in the ISA
-# (profiles/r02_blend_isa_counts.txt, scripts/isa_loop_count.py); a wave64 VALU instruction holds its SIMD for 2 cycles
-VALU_PER_PAIR = {"blend_fwd": None, "blend_bwd": None}
+# roofline_valu: instructions per (Gaussian, 64-pixel wave) pair of the blend kernels' inner loops, counted in the ISA
+# by scripts/isa_loop_count.py -> profiles/<tag>_blend_isa_counts.json.  MI355X_MICROARCH.md constants table: a wave64
+# VALU instruction occupies its SIMD-32 for 2 cycles (transcendental: 4), v_mfma_f32_16x16x4_f32 for 32; ONE wave
+# alone issues one instruction of any class per ~4 cycles (8 for a transcendental).
+VALU_CYC, TRANS_CYC, MFMA_16x16x4_CYC, LONE_WAVE_CYC = 2, 4, 32, 4
 PROFILE_TAG = "r02"
 
 
@@ -81,6 +83,62 @@ def pmc_traffic(kernel, n_gaussians, size):
         launches = sum(r["launches"] for r in rows)
         return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / max(1, launches)), os.path.basename(path)
     return None, None
+
+
+def traversed_entries(state):
+    """List entries each tile's waves walk in the blend kernels, from the integer state of one forward pass:
+    backward walks exactly min(list length, max n_contrib of the tile) entries; the forward walks at least that many
+    (it stops at the next 256-entry batch boundary after every pixel has finished, or at the end of the list)."""
+    import torch
+    from instag_amd import diff_gauss
+    d = diff_gauss.debug_export(state)
+    nc = d["n_contrib"]
+    H, W = nc.shape
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = torch.zeros(gy * 16, gx * 16, dtype=nc.dtype, device=nc.device)
+    pad[:H, :W] = nc
+    tile_max = pad.view(gy, 16, gx, 16).permute(0, 2, 1, 3).reshape(gy * gx, 256).max(dim=1).values.to(torch.int64)
+    length = (d["ranges"][:, 1] - d["ranges"][:, 0]).to(torch.int64)
+    walked = torch.minimum(length, tile_max)
+    return {"bwd": int(walked.sum()), "fwd_min": int(walked.sum()), "fwd_max": int(length.sum()),
+            "tiles_populated": int((length > 0).sum()), "longest_list": int(length.max()),
+            "longest_walk": int(walked.max())}
+
+
+def roofline_valu(kernel, variants, entries, avg_us, launches_per_step):
+    """VALU / MFMA issue floor of a blend kernel: `entries` list entries x 4 waves per tile = (Gaussian, wave) pairs."""
+    table = None
+    for tag in (PROFILE_TAG, "r01"):
+        try:
+            table = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_blend_isa_counts.json")))
+            src = f"{tag}_blend_isa_counts.json"
+            break
+        except (OSError, ValueError):
+            continue
+    if table is None or not entries:
+        return None
+    rows = [table[v]["per_gaussian"] for v, _ in variants if v in table]
+    if len(rows) != len(variants):
+        return None
+    pairs = 4 * entries
+    valu = sum(r.get("valu", 0.0) for r in rows) / len(rows)
+    trans = sum(r.get("valu_trans", 0.0) for r in rows) / len(rows)
+    every = sum(r["all"] for r in rows) / len(rows)
+    nmat = sum(n for _, n in variants) / len(variants)
+    simd_hz = SIMDS * CLOCK_GHZ * 1e9
+    valu_us = pairs * (valu * VALU_CYC + trans * TRANS_CYC) / simd_hz * 1e6
+    mfma_us = pairs * nmat * MFMA_16x16x4_CYC / simd_hz * 1e6      # phase B: one 16x16x4 per (matrix, Gaussian, wave)
+    lone_us = pairs * ((every - trans) * LONE_WAVE_CYC + trans * 2 * LONE_WAVE_CYC + nmat * MFMA_16x16x4_CYC) / simd_hz * 1e6
+    floor = max(valu_us, mfma_us)
+    return {"kernel": kernel, "variants": [v for v, _ in variants], "isa_counts": src,
+            "pairs_per_launch": pairs, "valu_per_pair": round(valu, 2), "transcendental_per_pair": round(trans, 2),
+            "instructions_per_pair": round(every, 2), "mfma_16x16x4_per_pair": nmat,
+            "valu_floor_us": round(valu_us, 2), "mfma_floor_us": round(mfma_us, 2),
+            "floor_us": round(floor, 2), "achieved_us": round(avg_us, 2), "frac": round(floor / avg_us, 4),
+            "one_wave_per_simd_us": round(lone_us, 2),
+            "note": "floor = max(VALU, MFMA) issue time with every SIMD busy; one_wave_per_simd_us = the same pairs "
+                    "issued by lone waves (any instruction 4 cycles) spread evenly over all 1024 SIMDs -- the step's "
+                    "~410 populated tiles x 4 waves cover at most 1640 wave slots and finish unevenly"}
 
 
 def cpu_baseline(n_gaussians, size, sh_degree, budget_s=30.0):
@@ -300,8 +358,11 @@ def main():
         L.instag_prof_enable(-1)
         L.instag_prof_reset()
         mlp_ops.STATS.update(fwd_flops=0, bwd_flops=0)
+        diff_gauss.KEEP_LAST_STATE = True
         run(args.steps)
         torch.cuda.synchronize()
+        diff_gauss.KEEP_LAST_STATE = False
+        entries = traversed_entries(diff_gauss.LAST_STATS.pop("state")) if rank == 0 else None
         kern = {}
         for name, kid in KERNEL_IDS.items():
             ms, cnt = C.c_double(0), C.c_int64(0)
@@ -311,7 +372,7 @@ def main():
         L.instag_prof_enable(0)
         med = statistics.median(times)
         return dict(times=times, median=med, kern=kern, R=int(diff_gauss.LAST_STATS.get("num_rendered", 0)),
-                    graph=use_graph, why=why, mlp=dict(mlp_ops.STATS))
+                    graph=use_graph, why=why, mlp=dict(mlp_ops.STATS), entries=entries)
 
     log(f"config: {N} Gaussians, {size}x{size}, world {world}")
     main_run = measure(False, max(1, args.windows))
@@ -351,6 +412,19 @@ def main():
                                 "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                                 "flops_per_step": main_run["mlp"][key] // max(1, args.steps),
                                 "launches_per_step": kern[k]["launches"] // max(1, args.steps)}
+        # the blend kernels are instruction-issue bound, not HBM bound: their VALU / MFMA floors
+        valu = {}
+        ent = main_run["entries"]
+        if ent and "blend_bwd" in kern:
+            # this step launches the colour pass (aux colours in its idle GEMM columns) and the mean-only aux pass
+            valu["blend_bwd"] = roofline_valu("blend_bwd", [("blend_backward_kernel<false, 2, false>", 2),
+                                                            ("blend_backward_kernel<false, 0, true>", 1)],
+                                              ent["bwd"], kern["blend_bwd"]["avg_us"], 2)
+        if ent and "blend_fwd" in kern:
+            valu["blend_fwd"] = roofline_valu("blend_fwd", [("blend_forward_kernel<true>", 0)], ent["fwd_min"],
+                                              kern["blend_fwd"]["avg_us"], 1)
+            if valu["blend_fwd"]:
+                valu["blend_fwd"]["pairs_are"] = "a lower bound (entries up to the tile's last contributor)"
         value = world * args.steps / med
         out = {
             "metric": f"train-step frames/sec @{size}x{size}, {N // 1000}k Gaussians", "value": round(value, 3),
@@ -369,6 +443,9 @@ def main():
                                  "same snapshotted state"},
             "windows_ms_per_step": [round(1e3 * t / args.steps, 4) for t in main_run["times"]],
             "roofline": roofline,
+            "roofline_valu": (valu.get(dom) or valu.get("blend_bwd")) and dict(
+                valu.get(dom) or valu["blend_bwd"], other={k: v for k, v in valu.items() if v and k != dom},
+                walked=ent),
             "secondary_rooflines": secondary,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "raster_fwd_bwd_ms_per_frame": round(sum(v["total_ms"] for k, v in kern.items()

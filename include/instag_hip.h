@@ -102,7 +102,7 @@ int instag_sh_encode_backward(const float* grad, const float* inputs, uint32_t B
  *
  * Forward is split in two calls because the number of (tile, Gaussian) instances R is only
  * known after the per-Gaussian stage: stage1 returns R to the HOST (it synchronises the
- * stream once), the caller sizes the binning buffer with instag_raster_binning_bytes(R),
+ * stream once), the caller sizes the binning buffer with instag_raster_binning_bytes(R, H, W),
  * stage2 does duplicate -> sort -> tile ranges -> blend.
  * ------------------------------------------------------------------------------------------ */
 typedef struct instag_raster_args {
@@ -140,7 +140,7 @@ typedef struct instag_raster_args {
 
 size_t instag_raster_geom_bytes(int32_t N);
 size_t instag_raster_image_bytes(int32_t image_height, int32_t image_width);
-size_t instag_raster_binning_bytes(int64_t R);
+size_t instag_raster_binning_bytes(int64_t R, int32_t H, int32_t W);
 /* scratch for backward: per-instance gradient rows */
 size_t instag_raster_backward_workspace_bytes(int32_t N, int64_t R);
 
@@ -161,7 +161,7 @@ int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t
                                  instag_stream_t stream);
 /* Sync-free forward (hipGraph-capturable): stage1 + stage2 in one call with a caller-chosen instance
  * capacity instead of the host round trip.  binning / backward workspace are sized for `capacity`
- * (instag_raster_binning_bytes(capacity), instag_raster_backward_workspace_bytes(N, capacity)) and
+ * (instag_raster_binning_bytes(capacity, H, W), instag_raster_backward_workspace_bytes(N, capacity)) and
  * backward is called with R = capacity.  status (device int32[4], zero-initialised by the caller):
  *   [0] = instances this call needed (R);
  *   [1] = STICKY overflow flag: set to 1 by any call with R > capacity, never cleared by the library -- a caller that

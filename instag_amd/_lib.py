@@ -105,7 +105,7 @@ _PROTOS = {
     "instag_sh_encode_backward": (C.c_int, [vp, vp, u32, u32, u32, vp, vp, vp]),
     "instag_raster_geom_bytes": (sz, [i32]),
     "instag_raster_image_bytes": (sz, [i32, i32]),
-    "instag_raster_binning_bytes": (sz, [i64]),
+    "instag_raster_binning_bytes": (sz, [i64, i32, i32]),
     "instag_raster_backward_workspace_bytes": (sz, [i32, i64]),
     "instag_raster_forward_stage1": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, C.POINTER(i64), vp]),
     "instag_raster_forward_stage2": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, sz, vp, sz, i64,
@@ -164,6 +164,9 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
+ABI_VERSION = 5     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises if the HIP library is unavailable."""
     global _lib
@@ -184,6 +187,9 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        if handle.instag_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {handle.instag_abi_version()}, the bindings expect "
+                               f"{ABI_VERSION}: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         _lib = handle
     return _lib
 

@@ -30,7 +30,8 @@ COMMON = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-fno-gpu-rdc"
 # rectangles, sort keys) are checked bit-for-bit against the CPU oracle.
 SOURCES = {
     "raster_preprocess.hip": ["-ffp-contract=off"],
-    "raster_blend.hip": [],
+    # raster_blend: SLP pairing of scalars ACROSS Gaussians costs a dozen v_mov per group of four in the forward loop
+    "raster_blend.hip": ["-fno-slp-vectorize"],
     "raster_backward.hip": [],
     "raster_api.hip": [],
     "raster_sort.hip": [],

@@ -93,7 +93,9 @@ struct GeomLayout {
 GeomLayout geom_layout(int32_t N);
 
 struct ImageLayout {
-  size_t ranges, n_contrib, final_T, total;
+  size_t ranges, n_contrib, final_T;
+  size_t tile_rounds;                        // u32 per tile: 256-entry rounds of its list the forward blend walked
+  size_t total;
 };
 ImageLayout image_layout(int32_t H, int32_t W);
 
@@ -105,8 +107,14 @@ struct BinningLayout {
   size_t tsort_partials;                    // [1024][3][256]
   size_t sort_count;                        // u32: instances actually binned
   uint32_t tsort_blocks;
+  // Blend segments: round r (256 list entries) of tile t owns slot (start_t >> 8) + t + r -- unique, < seg_slots.
+  // seg_tile[slot] = t + 1 (forward blend; anything else is rejected by its range check), seg_state[slot] = the
+  // per-pixel blend state AFTER that round: [SEG_FLOATS][256 pixels] = T, the 8 channel accumulators, 3 aux ones.
+  size_t seg_tile, seg_state, seg_slots;
   size_t total;
 };
-BinningLayout binning_layout(int64_t R);
+constexpr int SEG_LEN = 256;                 // list entries per blend segment (= the forward blend's batch)
+constexpr int SEG_FLOATS = 12;
+BinningLayout binning_layout(int64_t R, int32_t H, int32_t W);
 
 }  // namespace instag

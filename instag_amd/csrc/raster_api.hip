@@ -120,13 +120,15 @@ ImageLayout image_layout(int32_t H, int32_t W) {
   L.ranges = o; o = align_up(o + tiles * 2 * sizeof(int32_t), 256);
   L.n_contrib = o; o = align_up(o + P * sizeof(uint32_t), 256);
   L.final_T = o; o = align_up(o + P * sizeof(float), 256);
+  L.tile_rounds = o; o = align_up(o + tiles * sizeof(uint32_t), 256);
   L.total = o;
   return L;
 }
 
-BinningLayout binning_layout(int64_t R) {
+BinningLayout binning_layout(int64_t R, int32_t H, int32_t W) {
   BinningLayout L;
   const size_t r = (size_t)(R > 0 ? R : 1);
+  const size_t tiles = (size_t)div_up(W, TILE_X) * div_up(H, TILE_Y);
   size_t o = 0;
   L.keys_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.vals_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
@@ -142,6 +144,9 @@ BinningLayout binning_layout(int64_t R) {
   L.tsort_digit_base = o; o = align_up(o + (size_t)HIST_SLICES * 3 * 256 * sizeof(uint32_t), 256);
   L.tsort_partials = o; o = align_up(o + (size_t)1024 * 3 * 256 * sizeof(uint32_t), 256);
   L.sort_count = o; o = align_up(o + sizeof(uint32_t), 256);
+  L.seg_slots = r / SEG_LEN + tiles + 2;
+  L.seg_tile = o; o = align_up(o + L.seg_slots * sizeof(uint32_t), 256);
+  L.seg_state = o; o = align_up(o + L.seg_slots * SEG_FLOATS * SEG_LEN * sizeof(float), 256);
   L.total = o;
   return L;
 }
@@ -228,11 +233,11 @@ using namespace instag;
 extern "C" {
 
 const char* instag_last_error(void) { return g_err.c_str(); }
-int instag_abi_version(void) { return 4; }
+int instag_abi_version(void) { return 5; }
 
 size_t instag_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t instag_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
-size_t instag_raster_binning_bytes(int64_t R) { return binning_layout(R).total; }
+size_t instag_raster_binning_bytes(int64_t R, int32_t H, int32_t W) { return binning_layout(R, H, W).total; }
 size_t instag_raster_backward_workspace_bytes(int32_t N, int64_t R) {
   (void)N;
   return align_up((size_t)(R > 0 ? R : 1) * REC_FLOATS * sizeof(float), 256);
@@ -269,7 +274,7 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   INSTAG_REQUIRE(R >= 0 && R < (int64_t)1 << 30, "instance count out of range (2^30 - 1 at most)");
   const GeomLayout GL = geom_layout(a->N);
   const ImageLayout IL = image_layout(a->image_height, a->image_width);
-  const BinningLayout BL = binning_layout(R);
+  const BinningLayout BL = binning_layout(R, a->image_height, a->image_width);
   if (geom_bytes < GL.total) { set_error("geom buffer too small"); return INSTAG_E_SPACE; }
   if (image_bytes < IL.total) { set_error("image buffer too small"); return INSTAG_E_SPACE; }
   if (binning_bytes < BL.total) { set_error("binning buffer too small"); return INSTAG_E_SPACE; }
@@ -319,7 +324,8 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   }
   return launch_blend_forward(c, ranges, point_list, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
                               (float*)(ib + IL.final_T), out_color, out_depth, out_normal, out_alpha,
-                              a->E > 0 ? out_extra : nullptr, aux_colors, out_aux, s);
+                              a->E > 0 ? out_extra : nullptr, aux_colors, out_aux, (uint32_t*)(bb + BL.seg_tile),
+                              (float*)(bb + BL.seg_state), (uint32_t*)(ib + IL.tile_rounds), s);
 }
 
 int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
@@ -371,7 +377,7 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
   INSTAG_REQUIRE(dL_daux_colors == nullptr || aux_colors != nullptr, "dL_daux_colors needs aux_colors");
   const GeomLayout GL = geom_layout(a->N);
   const ImageLayout IL = image_layout(a->image_height, a->image_width);
-  const BinningLayout BL = binning_layout(R);
+  const BinningLayout BL = binning_layout(R, a->image_height, a->image_width);
   if (geom_bytes < GL.total || image_bytes < IL.total || binning_bytes < BL.total) {
     set_error("state buffer too small"); return INSTAG_E_SPACE;
   }
@@ -393,7 +399,9 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                                       (const float*)(ib + IL.final_T), dL_dout_color, dL_dout_depth,
                                       dL_dout_normal, dL_dout_alpha, g_extra, inst_grad, nullptr,
                                       fused_aux ? aux_colors : nullptr, fused_aux ? dL_dout_aux : nullptr,
-                                      fused_aux ? (aux_colors_only ? 2 : 1) : 0, s)) return e;
+                                      fused_aux ? (aux_colors_only ? 2 : 1) : 0,
+                                      (const uint32_t*)(bb + BL.seg_tile), (const float*)(bb + BL.seg_state),
+                                      (const uint32_t*)(ib + IL.tile_rounds), (uint32_t)BL.seg_slots, s)) return e;
   }
   if (int e = launch_preprocess_backward(c, a, (const float*)(gb + GL.rec2d), (const float*)(gb + GL.cov3d),
                                          (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
@@ -407,7 +415,9 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
       if (int e = launch_blend_backward(c, (const int32_t*)(ib + IL.ranges), (const uint32_t*)(bb + BL.point_list),
                                         (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),
                                         (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
-                                        nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr, 0, s))
+                                        nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr, 0,
+                                        (const uint32_t*)(bb + BL.seg_tile), (const float*)(bb + BL.seg_state),
+                                      (const uint32_t*)(ib + IL.tile_rounds), (uint32_t)BL.seg_slots, s))
         return e;
     }
     return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,
@@ -427,7 +437,7 @@ int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, si
   INSTAG_REQUIRE(radii != nullptr || a->N == 0, "radii is NULL");
   const GeomLayout GL = geom_layout(a->N);
   const ImageLayout IL = image_layout(a->image_height, a->image_width);
-  const BinningLayout BL = binning_layout(R);
+  const BinningLayout BL = binning_layout(R, a->image_height, a->image_width);
   if (geom_bytes < GL.total || image_bytes < IL.total || binning_bytes < BL.total) {
     set_error("state buffer too small"); return INSTAG_E_SPACE;
   }
@@ -442,7 +452,9 @@ int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, si
                                       (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),
                                       (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
                                       nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr,
-                                      dL_daux_colors == nullptr ? 3 : 0, s))     // no colour gradient wanted: mean-only pass
+                                      dL_daux_colors == nullptr ? 3 : 0,          // no colour gradient wanted: mean-only pass
+                                      (const uint32_t*)(bb + BL.seg_tile), (const float*)(bb + BL.seg_state),
+                                      (const uint32_t*)(ib + IL.tile_rounds), (uint32_t)BL.seg_slots, s))
       return e;
   }
   return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,
@@ -457,7 +469,7 @@ int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* 
   hipStream_t s = (hipStream_t)stream_;
   const GeomLayout GL = geom_layout(N);
   const ImageLayout IL = image_layout(H, W);
-  const BinningLayout BL = binning_layout(R);
+  const BinningLayout BL = binning_layout(R, H, W);
   const char *gb = (const char*)geom, *bb = (const char*)binning, *ib = (const char*)image;
   const size_t tiles = (size_t)div_up(W, TILE_X) * div_up(H, TILE_Y), P = (size_t)H * W;
   auto cp = [&](void* dst, const void* src, size_t n) -> hipError_t {

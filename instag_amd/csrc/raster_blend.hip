@@ -26,6 +26,22 @@ constexpr float T_MIN = 0.0001f;
 
 // AUX: a second colour set [N,3] is blended over the same instances with the same alpha / T (the reference renders
 // it as a separate rasterizer call on detached geometry: gaussian_renderer/__init__.py:243-258, the attention map)
+//
+// A tile's duration is its longest wave's instruction count: at C3's ~1.6 workgroups per CU a wave has its SIMD almost
+// to itself and issues one instruction (vector, scalar or LDS alike) every ~4.5 cycles, so the inner loop is written
+// for FEW INSTRUCTIONS per (Gaussian, pixel):
+//  * the conic is rescaled when a record is staged (-0.5 log2e A, -0.5 log2e C, -log2e B), so the exponent comes out in
+//    the log2 domain: two packed multiplies, one multiply, one add, one fma, then v_exp_f32 directly;
+//  * a pixel that is finished moves to (1e18, 1e18): every later exponent is hugely negative, alpha = 0 < 1/255, the
+//    Gaussian does not count -- no `done` predicate in the loop;
+//  * a Gaussian that does not count has alpha' = 0, so test_T = T exactly and the weight is 0 without any select, and
+//    since T >= T_MIN holds while a pixel is unfinished, "some pixel stops within these four Gaussians" is one compare
+//    of the fourth running product plus ONE wave-uniform branch per four Gaussians; the rare path (each lane takes it
+//    once per tile) redoes the four steps with the per-lane stop logic.
+// The running products are the same sequence of fp32 operations as one-at-a-time blending: T, n_contrib are unchanged.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float FAR_PIXEL = 1e18f;
+
 template <bool AUX>
 __global__ void __launch_bounds__(BLOCK)
 blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -33,20 +49,27 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
                      float* __restrict__ final_T, float* __restrict__ out_color,
                      float* __restrict__ out_depth, float* __restrict__ out_normal,
                      float* __restrict__ out_alpha, float* __restrict__ out_extra,
-                     const float* __restrict__ aux_colors, float* __restrict__ out_aux) {
+                     const float* __restrict__ aux_colors, float* __restrict__ out_aux,
+                     uint32_t* __restrict__ seg_tile, float* __restrict__ seg_state,
+                     uint32_t* __restrict__ tile_rounds) {
+  // [0] x y A' C'   [1] B' op r g   [2] b depth nx ny   [3] nz extra aux_r aux_g ; s_auxb: aux_b
   __shared__ float4 s_rec[BLOCK][4];
-  __shared__ float s_aux[AUX ? BLOCK : 1][3];
+  __shared__ float s_auxb[AUX ? BLOCK : 1];
   const int tile = blockIdx.x;
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
   const int tid = threadIdx.x;
   const int pxi = tx * TILE_X + (tid & 15), pyi = ty * TILE_Y + (tid >> 4);
   const bool inside = pxi < c.W && pyi < c.H;
-  const float pxf = (float)pxi, pyf = (float)pyi;
   const int start = ranges[2 * tile], end = ranges[2 * tile + 1];
   const int rounds = (end - start + BLOCK - 1) / BLOCK;
   int toDo = end - start;
+  // every 256-entry round of the list is a segment with a slot of its own (common.hpp BinningLayout): the per-pixel
+  // state after each round the tile walks is kept there, so that the backward pass can start anywhere
+  const int slot0 = (start >> 8) + tile;
+  for (int r = tid; r < rounds; r += BLOCK) seg_tile[slot0 + r] = (uint32_t)tile + 1u;
+  int walked = 0;
 
-  bool done = !inside;
+  f32x2 pix = inside ? f32x2{(float)pxi, (float)pyi} : f32x2{FAR_PIXEL, FAR_PIXEL};
   float T = 1.0f;
   uint32_t last_contributor = 0;
   // channel accumulators as float pairs: the eight FMAs per Gaussian become four v_pk_fma_f32 (the record keeps
@@ -57,79 +80,125 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   f32x2 xacc2 = {0.f, 0.f};
   float xacc_b = 0.f;
 
-  // the records of batch i+1 are fetched while batch i is being blended
-  float4 nrec0 = make_float4(0.f, 0.f, 0.f, 0.f), nrec1 = nrec0, nrec2 = nrec0, nrec3 = nrec0;
-  float naux[3] = {0.f, 0.f, 0.f};
-  if (start + tid < end) {
-    const uint32_t gid = point_list[start + tid];
-    const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
-    nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
-    if (AUX) { naux[0] = aux_colors[3 * (size_t)gid]; naux[1] = aux_colors[3 * (size_t)gid + 1]; naux[2] = aux_colors[3 * (size_t)gid + 2]; }
-  }
-  for (int i = 0; i < rounds; ++i, toDo -= BLOCK) {
-    if (__syncthreads_count(done) == BLOCK) break;
-    s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
-    if (AUX) { s_aux[tid][0] = naux[0]; s_aux[tid][1] = naux[1]; s_aux[tid][2] = naux[2]; }
-    __syncthreads();
-    {
-      const int nprog = (i + 1) * BLOCK + tid;
-      if (start + nprog < end) {
-        const uint32_t gid = point_list[start + nprog];
-        const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
-        nrec0 = r[0]; nrec1 = r[1]; nrec2 = r[2]; nrec3 = r[3];
-        if (AUX) { naux[0] = aux_colors[3 * (size_t)gid]; naux[1] = aux_colors[3 * (size_t)gid + 1]; naux[2] = aux_colors[3 * (size_t)gid + 2]; }
-      }
-    }
-    const int cnt = min(BLOCK, toDo);
-    // branch-free body (predicated) so that unrolled iterations overlap: only T / done form a serial chain
-#pragma unroll 4
-    for (int j = 0; j < cnt; ++j) {
-      const float4 a = s_rec[j][0];   // x y conA conB
-      const float4 b = s_rec[j][1];   // conC op r g
-      const float4 cc = s_rec[j][2];  // b depth nx ny
-      const float4 dd = s_rec[j][3];  // nz extra . .
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      const float alpha = fminf(0.99f, b.y * __expf(power));
-      const bool hit = !done && !(power > 0.0f) && !(alpha < ALPHA_MIN);
-      const float test_T = T * (1.0f - alpha);
-      const bool stop = hit && (test_T < T_MIN);
-      done = done || stop;
-      const bool take = hit && !stop;
-      const float w = take ? alpha * T : 0.f;
-      const f32x2 w2 = {w, w};
-      acc2[0] = __builtin_elementwise_fma(f32x2{b.z, b.w}, w2, acc2[0]);
-      acc2[1] = __builtin_elementwise_fma(f32x2{cc.x, cc.y}, w2, acc2[1]);
-      acc2[2] = __builtin_elementwise_fma(f32x2{cc.z, cc.w}, w2, acc2[2]);
-      acc2[3] = __builtin_elementwise_fma(f32x2{dd.x, dd.y}, w2, acc2[3]);
+  // the records of batch i+1 are fetched while batch i is being blended; a slot past the end of the list holds a record
+  // with opacity 0 (never counts), so the loop below runs whole groups of four
+  float4 nrec0, nrec1, nrec2, nrec3;
+  float nauxb = 0.f;
+  auto fetch = [&](int pos) {
+    nrec0 = make_float4(0.f, 0.f, 0.f, 0.f); nrec1 = nrec0; nrec2 = nrec0; nrec3 = nrec0; nauxb = 0.f;
+    if (start + pos < end) {
+      const uint32_t gid = point_list[start + pos];
+      const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
+      const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+      nrec0 = make_float4(r0.x, r0.y, (-0.5f * LOG2E) * r0.z, (-0.5f * LOG2E) * r1.x);
+      nrec1 = make_float4(-LOG2E * r0.w, r1.y, r1.z, r1.w);
+      nrec2 = r2;
+      nrec3 = make_float4(r3.x, r3.y, 0.f, 0.f);
       if (AUX) {
-        xacc2 = __builtin_elementwise_fma(f32x2{s_aux[j][0], s_aux[j][1]}, w2, xacc2);
-        xacc_b += s_aux[j][2] * w;
+        nrec3.z = aux_colors[3 * (size_t)gid]; nrec3.w = aux_colors[3 * (size_t)gid + 1];
+        nauxb = aux_colors[3 * (size_t)gid + 2];
       }
-      T = take ? test_T : T;
-      last_contributor = take ? (uint32_t)(i * BLOCK + j + 1) : last_contributor;
     }
+  };
+  fetch(tid);
+  for (int i = 0; i < rounds; ++i, toDo -= BLOCK) {
+    if (__syncthreads_count(pix.x > 0.5f * FAR_PIXEL) == BLOCK) break;
+    s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
+    if (AUX) s_auxb[tid] = nauxb;
+    __syncthreads();
+    fetch((i + 1) * BLOCK + tid);
+    const int groups = (min(BLOCK, toDo) + 3) >> 2;
+    for (int g = 0; g < groups; ++g) {
+      float al[4], w[4];
+      bool hit[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 a = s_rec[4 * g + k][0];
+        const float4 b = s_rec[4 * g + k][1];
+        const f32x2 d = f32x2{a.x, a.y} - pix;
+        const f32x2 u = (d * f32x2{a.z, a.w}) * d;
+        const float p2 = __builtin_fmaf(b.x, d.x * d.y, u.x + u.y);
+        const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
+        hit[k] = !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
+        al[k] = hit[k] ? alpha : 0.f;
+      }
+      const float t1 = T * (1.0f - al[0]);
+      const float t2 = t1 * (1.0f - al[1]);
+      const float t3 = t2 * (1.0f - al[2]);
+      float t4 = t3 * (1.0f - al[3]);
+      w[0] = al[0] * T; w[1] = al[1] * t1; w[2] = al[2] * t2; w[3] = al[3] * t3;
+      uint32_t code = hit[0] ? 1u : 0u;
+      code = hit[1] ? 2u : code;
+      code = hit[2] ? 3u : code;
+      code = hit[3] ? 4u : code;
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(t4 < T_MIN) != 0, 0)) {
+        // some pixel of this wave finishes within these four: redo them with the per-lane stop rule (a lane that
+        // does not stop gets the same numbers again)
+        bool dead = false;
+        float Tc = T;
+        code = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float a = dead ? 0.f : al[k];
+          const float tt = Tc * (1.0f - a);
+          const bool stop = tt < T_MIN;
+          dead = dead || stop;
+          a = stop ? 0.f : a;
+          code = (a > 0.f) ? (uint32_t)(k + 1) : code;
+          w[k] = a * Tc;
+          Tc = stop ? Tc : tt;
+        }
+        t4 = Tc;
+        if (dead) pix = f32x2{FAR_PIXEL, FAR_PIXEL};
+      }
+      T = t4;
+      last_contributor = code ? (uint32_t)(i * BLOCK + 4 * g) + code : last_contributor;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 b = s_rec[4 * g + k][1];
+        const float4 cc = s_rec[4 * g + k][2];
+        const float4 dd = s_rec[4 * g + k][3];
+        const f32x2 w2 = {w[k], w[k]};
+        acc2[0] = __builtin_elementwise_fma(f32x2{b.z, b.w}, w2, acc2[0]);
+        acc2[1] = __builtin_elementwise_fma(f32x2{cc.x, cc.y}, w2, acc2[1]);
+        acc2[2] = __builtin_elementwise_fma(f32x2{cc.z, cc.w}, w2, acc2[2]);
+        acc2[3] = __builtin_elementwise_fma(f32x2{dd.x, dd.y}, w2, acc2[3]);
+        if (AUX) {
+          xacc2 = __builtin_elementwise_fma(f32x2{dd.z, dd.w}, w2, xacc2);
+          xacc_b = __builtin_fmaf(s_auxb[4 * g + k], w[k], xacc_b);
+        }
+      }
+    }
+    {
+      float* ck = seg_state + (size_t)(slot0 + i) * (SEG_FLOATS * SEG_LEN) + tid;
+      ck[0] = T;
+#pragma unroll
+      for (int k = 0; k < NCH / 2; ++k) { ck[(1 + 2 * k) * SEG_LEN] = acc2[k].x; ck[(2 + 2 * k) * SEG_LEN] = acc2[k].y; }
+      ck[9 * SEG_LEN] = xacc2.x; ck[10 * SEG_LEN] = xacc2.y; ck[11 * SEG_LEN] = xacc_b;
+    }
+    walked = i + 1;
   }
+  if (tid == 0) tile_rounds[tile] = (uint32_t)walked;
   const float acc[NCH] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
   const float xacc[3] = {xacc2.x, xacc2.y, xacc_b};
   if (inside) {
     const size_t P = (size_t)c.H * c.W;
-    const size_t pix = (size_t)pyi * c.W + pxi;
-    final_T[pix] = T;
-    n_contrib[pix] = last_contributor;
-    out_color[pix] = acc[0] + T * c.bg[0];
-    out_color[P + pix] = acc[1] + T * c.bg[1];
-    out_color[2 * P + pix] = acc[2] + T * c.bg[2];
-    out_depth[pix] = acc[3];
-    out_normal[pix] = acc[4];
-    out_normal[P + pix] = acc[5];
-    out_normal[2 * P + pix] = acc[6];
-    out_alpha[pix] = 1.0f - T;
-    if (out_extra) out_extra[pix] = acc[7];
+    const size_t pix_i = (size_t)pyi * c.W + pxi;
+    final_T[pix_i] = T;
+    n_contrib[pix_i] = last_contributor;
+    out_color[pix_i] = acc[0] + T * c.bg[0];
+    out_color[P + pix_i] = acc[1] + T * c.bg[1];
+    out_color[2 * P + pix_i] = acc[2] + T * c.bg[2];
+    out_depth[pix_i] = acc[3];
+    out_normal[pix_i] = acc[4];
+    out_normal[P + pix_i] = acc[5];
+    out_normal[2 * P + pix_i] = acc[6];
+    out_alpha[pix_i] = 1.0f - T;
+    if (out_extra) out_extra[pix_i] = acc[7];
     if (AUX) {
-      out_aux[pix] = xacc[0] + T * c.bg[0];
-      out_aux[P + pix] = xacc[1] + T * c.bg[1];
-      out_aux[2 * P + pix] = xacc[2] + T * c.bg[2];
+      out_aux[pix_i] = xacc[0] + T * c.bg[0];
+      out_aux[P + pix_i] = xacc[1] + T * c.bg[1];
+      out_aux[2 * P + pix_i] = xacc[2] + T * c.bg[2];
     }
   }
 }
@@ -168,7 +237,9 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dnormal,
                       const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
                       float* __restrict__ inst_grad, const float* __restrict__ color_override /*[N,3] or null*/,
-                      const float* __restrict__ aux_colors /*[N,3], AUX*/, const float* __restrict__ dL_daux /*[3,H,W], AUX*/) {
+                      const float* __restrict__ aux_colors /*[N,3], AUX*/, const float* __restrict__ dL_daux /*[3,H,W], AUX*/,
+                      const uint32_t* __restrict__ seg_tile, const float* __restrict__ seg_state,
+                      const uint32_t* __restrict__ tile_rounds) {
   static_assert(!(FULL && AUX != 0), "the auxiliary gradients use the row slots of the depth / normal / extra gradients");
   static_assert(!(XONLY && (FULL || AUX != 0)), "XONLY is a pass of its own");
   constexpr bool AUXW = AUX != 0, AUXX = AUX == 1;
@@ -183,18 +254,30 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   __shared__ __align__(16) float s_X[AUXX ? 4 * BB * WROW : 4];
   __shared__ float s_res[BB][NMAT][4][8];              // [gaussian][matrix][wave = 16 steps of every quarter][feature < 8]
   int* s_max = reinterpret_cast<int*>(&s_res[0][0][0][0]);   // (used once, before the first batch)
-  const int tile = blockIdx.x;
+  // One workgroup per SEGMENT (256 list entries of one tile), not per tile: the forward pass left the per-pixel state
+  // after every segment (seg_state), so a segment's back-to-front walk starts from the state behind it instead of
+  // waiting for the walk over everything behind it.  The kernel's duration used to be the longest tile's chain (C3:
+  // 1279 entries = 80 batches); now no chain is longer than 16 batches and the segments fill the chip evenly.
+  const int slot = blockIdx.x;
+  const uint32_t tcode = seg_tile[slot];
+  if (tcode == 0u || tcode > (uint32_t)(c.grid_x * c.grid_y)) return;        // not a segment of this frame
+  const int tile = (int)tcode - 1;
+  const int list_start = ranges[2 * tile], list_end = ranges[2 * tile + 1];
+  const int slot0 = (list_start >> 8) + tile;
+  const int seg = slot - slot0;
+  if (seg < 0 || seg * SEG_LEN >= list_end - list_start) return;             // (stale word of an earlier frame)
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int pxi = tx * TILE_X + (tid & 15), pyi = ty * TILE_Y + (tid >> 4);
   const bool inside = pxi < c.W && pyi < c.H;
   const float pxf = (float)pxi, pyf = (float)pyi;
-  const int start = ranges[2 * tile], end = ranges[2 * tile + 1];
+  const int start = list_start + seg * SEG_LEN, end = min(list_end, start + SEG_LEN);
   const size_t P = (size_t)c.H * c.W;
   const size_t pix = (size_t)pyi * c.W + pxi;
 
-  const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+  // (positions are relative to the segment from here on: <= 0 means the pixel finished in front of it)
+  const int last_contributor = inside ? (int)n_contrib[pix] - seg * SEG_LEN : 0;
   const float T_final = inside ? final_T[pix] : 0.f;
   float T = T_final;
   float dpix[NCH];
@@ -267,6 +350,21 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   // The aux image runs the same recurrence with its own colours and upstream gradient: (Q_x, tail_x).
   float Q = 0.f, Qx = 0.f;
   const float tf_tail = T_final * tail, tf_tail_x = T_final * tail_x;
+  if (live && last_contributor > n) {
+    // the pixel's walk began behind this segment: T in front of the segment's last entry + 1 is the forward pass's own
+    // value, and Q there is <dL/dpixel, colour accumulated behind> = <dL/dpixel, final accumulators - accumulators
+    // after this segment> (the last segment the tile walked holds the final ones)
+    const float* ck = seg_state + (size_t)slot * (SEG_FLOATS * SEG_LEN) + tid;
+    const float* cf = seg_state + (size_t)(slot0 + (int)tile_rounds[tile] - 1) * (SEG_FLOATS * SEG_LEN) + tid;
+    T = ck[0];
+    const int ch0 = color_override ? 9 : 1;
+#pragma unroll
+    for (int k = 0; k < (FULL ? NCH : 3); ++k) Q += dpix[k] * (cf[(ch0 + k) * SEG_LEN] - ck[(ch0 + k) * SEG_LEN]);
+    if (AUXX) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Qx += dpx[k] * (cf[(9 + k) * SEG_LEN] - ck[(9 + k) * SEG_LEN]);
+    }
+  }
 
   const float tile_x0 = (float)(tx * TILE_X), tile_y0 = (float)(ty * TILE_Y);
   const int rounds = (n + SB - 1) / SB;
@@ -426,16 +524,19 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
 int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
                          const float* rec2d, uint32_t* n_contrib, float* final_T, float* out_color,
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
-                         const float* aux_colors, float* out_aux, hipStream_t s) {
+                         const float* aux_colors, float* out_aux, uint32_t* seg_tile, float* seg_state,
+                         uint32_t* tile_rounds, hipStream_t s) {
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
   ProfScope p(K_BLEND_FWD, s);
   if (aux_colors)
     blend_forward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
-                                                       out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux);
+                                                       out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux,
+                                                       seg_tile, seg_state, tile_rounds);
   else
     blend_forward_kernel<false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
-                                                        out_depth, out_normal, out_alpha, out_extra, nullptr, nullptr);
+                                                        out_depth, out_normal, out_alpha, out_extra, nullptr, nullptr,
+                                                        seg_tile, seg_state, tile_rounds);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -445,7 +546,8 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
                           const float* color_override, const float* aux_colors, const float* dL_daux, int aux_mode,
-                          hipStream_t s) {
+                          const uint32_t* seg_tile, const float* seg_state, const uint32_t* tile_rounds,
+                          uint32_t seg_slots, hipStream_t s) {
   // aux_mode: 0 none, 1 whole aux image in this launch, 2 aux colours' gradient only, 3 mean-only pass over
   // `color_override` (rows carry dx, dy)
   const int tiles = c.grid_x * c.grid_y;
@@ -461,8 +563,9 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
   }
   ProfScope p(K_BLEND_BWD, s);
 #define INSTAG_BB(F, A, X, d, n, e, ax, dax)                                                                            \
-  blend_backward_kernel<F, A, X><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,   \
-                                                        dL_dcolor, d, n, dL_dalpha, e, inst_grad, color_override, ax, dax)
+  blend_backward_kernel<F, A, X><<<seg_slots, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib,        \
+                                                            final_T, dL_dcolor, d, n, dL_dalpha, e, inst_grad,          \
+                                                            color_override, ax, dax, seg_tile, seg_state, tile_rounds)
   if (aux_mode == 1) INSTAG_BB(false, 1, false, nullptr, nullptr, nullptr, aux_colors, dL_daux);
   else if (aux_mode == 2) INSTAG_BB(false, 2, false, nullptr, nullptr, nullptr, aux_colors, dL_daux);
   else if (aux_mode == 3) INSTAG_BB(false, 0, true, nullptr, nullptr, nullptr, nullptr, nullptr);

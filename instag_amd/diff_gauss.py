@@ -53,6 +53,7 @@ def _require_cuda(**tensors):
 
 # statistics of the most recent forward (bench.py reads the instance count R for the roofline accounting)
 LAST_STATS = {"num_rendered": 0, "num_gaussians": 0}
+KEEP_LAST_STATE = False       # measurement only (bench.py's traversed-pair count): LAST_STATS["state"] = last forward's state
 # instance count of every rasterizer call since the caller last cleared the list (sizing of a CapacityPlan)
 RENDERED_LOG = []
 
@@ -176,7 +177,7 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
     aux_img = torch.empty(3, H, W, dtype=torch.float32, device=dev) if aux_colors is not None else None
     if _CAPACITY_PLAN is not None:
         R, status = _CAPACITY_PLAN.next_slot()
-        binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
+        binning = torch.empty(L.instag_raster_binning_bytes(R, H, W), dtype=torch.uint8, device=dev)
         check(L.instag_raster_forward_capacity(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
                                                ptr(image), image.numel(), R, ptr(radii), ptr(status), ptr(color),
                                                ptr(depth), ptr(normal), ptr(alpha),
@@ -190,7 +191,7 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
         LAST_STATS["num_rendered"], LAST_STATS["num_gaussians"] = R, N
         if len(RENDERED_LOG) < 4096:
             RENDERED_LOG.append(R)
-        binning = torch.empty(L.instag_raster_binning_bytes(R), dtype=torch.uint8, device=dev)
+        binning = torch.empty(L.instag_raster_binning_bytes(R, H, W), dtype=torch.uint8, device=dev)
         check(L.instag_raster_forward_stage2(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
                                              ptr(image), image.numel(), R, ptr(color), ptr(depth), ptr(normal),
                                              ptr(alpha), ptr(extra_img) if E > 0 else None, ptr(aux_colors),
@@ -201,6 +202,8 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
     st.R, st.radii, st.N, st.H, st.W, st.E, st.M = R, radii, N, H, W, E, M
     st.aux = aux_colors
     st.split_sh = isinstance(shs, (tuple, list)) and shs[1].shape[1] > 0
+    if KEEP_LAST_STATE:
+        LAST_STATS["state"] = st
     if aux_colors is not None:
         return (color, depth, normal, alpha, radii, extra_img, aux_img), st
     return (color, depth, normal, alpha, radii, extra_img), st
