@@ -94,7 +94,7 @@ GeomLayout geom_layout(int32_t N);
 
 struct ImageLayout {
   size_t ranges, n_contrib, final_T;
-  size_t tile_rounds;                        // u32 per tile: 256-entry rounds of its list the forward blend walked
+  size_t tile_rounds;                        // u32 per tile: segments of its list the forward blend walked
   size_t total;
 };
 ImageLayout image_layout(int32_t H, int32_t W);
@@ -107,14 +107,18 @@ struct BinningLayout {
   size_t tsort_partials;                    // [1024][3][256]
   size_t sort_count;                        // u32: instances actually binned
   uint32_t tsort_blocks;
-  // Blend segments: round r (256 list entries) of tile t owns slot (start_t >> 8) + t + r -- unique, < seg_slots.
-  // seg_tile[slot] = t + 1 (forward blend; anything else is rejected by its range check), seg_state[slot] = the
-  // per-pixel blend state AFTER that round: [SEG_FLOATS][256 pixels] = T, the 8 channel accumulators, 3 aux ones.
-  size_t seg_tile, seg_state, seg_slots;
+  // Blend segments (SEG_LEN list entries of one tile).  Segment k of tile t keeps the per-pixel blend state AFTER it in
+  // seg_state[start_t / SEG_LEN + t + k] (unique, < seg_slots): [SEG_FLOATS][TILE_PIX] = T, the 8 channel
+  // accumulators, the 3 aux ones.  The forward blend appends every segment that holds a contributor to seg_queue
+  // ((tile, k) pairs; seg_count of them) -- the work list of the backward blend.  row_flag[set][slot] != 0 marks the
+  // gradient rows a backward blend wrote (two sets: the main and the auxiliary pass may run side by side); the
+  // reducing kernel clears what it consumes.  seg_count and row_flag follow tsort_zero and are cleared with it.
+  size_t seg_state, seg_slots, seg_queue, seg_count, row_flag, row_flag_stride;
   size_t total;
 };
-constexpr int SEG_LEN = 256;                 // list entries per blend segment (= the forward blend's batch)
+constexpr int SEG_LEN = 128;                 // list entries per blend segment (divides the forward blend's batch of 256)
 constexpr int SEG_FLOATS = 12;
+constexpr int TILE_PIX = TILE_X * TILE_Y;
 BinningLayout binning_layout(int64_t R, int32_t H, int32_t W);
 
 }  // namespace instag

@@ -139,14 +139,20 @@ BinningLayout binning_layout(int64_t R, int32_t H, int32_t W) {
   L.gid_unsorted = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.point_list = o; o = align_up(o + r * sizeof(uint32_t), 256);
   L.tsort_blocks = sort_blocks((uint32_t)r, SORT_IPT_TILE);
-  L.tsort_zero_words = 16 + (size_t)3 * L.tsort_blocks * 256;
-  L.tsort_zero = o; o = align_up(o + L.tsort_zero_words * sizeof(uint32_t), 256);
+  // [tickets + look-back words][seg_count + pad][row flags, two sets]: one region, cleared by the duplicate kernel
+  const size_t sort_words = 16 + (size_t)3 * L.tsort_blocks * 256;
+  L.row_flag_stride = align_up(r, 16);
+  L.tsort_zero_words = sort_words + 4 + 2 * L.row_flag_stride / 4;
+  L.tsort_zero = o;
+  L.seg_count = o + sort_words * sizeof(uint32_t);
+  L.row_flag = L.seg_count + 4 * sizeof(uint32_t);
+  o = align_up(o + L.tsort_zero_words * sizeof(uint32_t), 256);
   L.tsort_digit_base = o; o = align_up(o + (size_t)HIST_SLICES * 3 * 256 * sizeof(uint32_t), 256);
   L.tsort_partials = o; o = align_up(o + (size_t)1024 * 3 * 256 * sizeof(uint32_t), 256);
   L.sort_count = o; o = align_up(o + sizeof(uint32_t), 256);
   L.seg_slots = r / SEG_LEN + tiles + 2;
-  L.seg_tile = o; o = align_up(o + L.seg_slots * sizeof(uint32_t), 256);
-  L.seg_state = o; o = align_up(o + L.seg_slots * SEG_FLOATS * SEG_LEN * sizeof(float), 256);
+  L.seg_queue = o; o = align_up(o + 2 * L.seg_slots * sizeof(uint32_t), 256);
+  L.seg_state = o; o = align_up(o + L.seg_slots * SEG_FLOATS * TILE_PIX * sizeof(float), 256);
   L.total = o;
   return L;
 }
@@ -324,8 +330,9 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   }
   return launch_blend_forward(c, ranges, point_list, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
                               (float*)(ib + IL.final_T), out_color, out_depth, out_normal, out_alpha,
-                              a->E > 0 ? out_extra : nullptr, aux_colors, out_aux, (uint32_t*)(bb + BL.seg_tile),
-                              (float*)(bb + BL.seg_state), (uint32_t*)(ib + IL.tile_rounds), s);
+                              a->E > 0 ? out_extra : nullptr, aux_colors, out_aux, (uint32_t*)(bb + BL.seg_queue),
+                              (uint32_t*)(bb + BL.seg_count), (float*)(bb + BL.seg_state),
+                              (uint32_t*)(ib + IL.tile_rounds), s);
 }
 
 int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,
@@ -400,12 +407,14 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                                       dL_dout_normal, dL_dout_alpha, g_extra, inst_grad, nullptr,
                                       fused_aux ? aux_colors : nullptr, fused_aux ? dL_dout_aux : nullptr,
                                       fused_aux ? (aux_colors_only ? 2 : 1) : 0,
-                                      (const uint32_t*)(bb + BL.seg_tile), (const float*)(bb + BL.seg_state),
-                                      (const uint32_t*)(ib + IL.tile_rounds), (uint32_t)BL.seg_slots, s)) return e;
+                                      (const uint32_t*)(bb + BL.seg_queue), (const uint32_t*)(bb + BL.seg_count),
+                                      (const float*)(bb + BL.seg_state), (const uint32_t*)(ib + IL.tile_rounds),
+                                      (uint32_t)BL.seg_slots, (uint8_t*)const_cast<char*>(bb + BL.row_flag) + 0 * BL.row_flag_stride, s)) return e;
   }
   if (int e = launch_preprocess_backward(c, a, (const float*)(gb + GL.rec2d), (const float*)(gb + GL.cov3d),
                                          (const uint32_t*)(gb + GL.tiles_touched), (const uint32_t*)(gb + GL.flags),
-                                         radii, inst_grad, (uint32_t)R, dL_dmeans3D, dL_dmeans2D, dL_dshs,
+                                         radii, inst_grad, (uint8_t*)const_cast<char*>(bb + BL.row_flag), (uint32_t)R, dL_dmeans3D,
+                                         dL_dmeans2D, dL_dshs,
                                          dL_dcolors_precomp, dL_dopacities, dL_dscales, dL_drotations, dL_dcov3Ds_precomp,
                                          a->E > 0 ? dL_dextra_attrs : nullptr, dL_dshs_rest,
                                          fused_aux ? dL_daux_colors : nullptr, s)) return e;
@@ -416,12 +425,14 @@ int instag_raster_backward(const instag_raster_args* a, const void* geom, size_t
                                         (const uint32_t*)(bb + BL.vals), (const float*)(gb + GL.rec2d),
                                         (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
                                         nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr, 0,
-                                        (const uint32_t*)(bb + BL.seg_tile), (const float*)(bb + BL.seg_state),
-                                      (const uint32_t*)(ib + IL.tile_rounds), (uint32_t)BL.seg_slots, s))
+                                        (const uint32_t*)(bb + BL.seg_queue), (const uint32_t*)(bb + BL.seg_count),
+                                      (const float*)(bb + BL.seg_state), (const uint32_t*)(ib + IL.tile_rounds),
+                                      (uint32_t)BL.seg_slots, (uint8_t*)const_cast<char*>(bb + BL.row_flag) + 0 * BL.row_flag_stride, s))
         return e;
     }
     return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,
-                                      inst_grad, (uint32_t)R, dL_daux_colors, dL_dmeans2D, /*accumulate=*/true, s);
+                                      inst_grad, (uint8_t*)const_cast<char*>(bb + BL.row_flag), (uint32_t)R,
+                                      dL_daux_colors, dL_dmeans2D, /*accumulate=*/true, s);
   }
   return INSTAG_OK;
 }
@@ -453,12 +464,14 @@ int instag_raster_aux_backward(const instag_raster_args* a, const void* geom, si
                                       (const uint32_t*)(ib + IL.n_contrib), (const float*)(ib + IL.final_T), dL_dout_aux,
                                       nullptr, nullptr, nullptr, nullptr, inst_grad, aux_colors, nullptr, nullptr,
                                       dL_daux_colors == nullptr ? 3 : 0,          // no colour gradient wanted: mean-only pass
-                                      (const uint32_t*)(bb + BL.seg_tile), (const float*)(bb + BL.seg_state),
-                                      (const uint32_t*)(ib + IL.tile_rounds), (uint32_t)BL.seg_slots, s))
+                                      (const uint32_t*)(bb + BL.seg_queue), (const uint32_t*)(bb + BL.seg_count),
+                                      (const float*)(bb + BL.seg_state), (const uint32_t*)(ib + IL.tile_rounds),
+                                      (uint32_t)BL.seg_slots, (uint8_t*)const_cast<char*>(bb + BL.row_flag) + 1 * BL.row_flag_stride, s))
       return e;
   }
   return launch_aux_backward_reduce(c, (const float*)(gb + GL.rec2d), (const uint32_t*)(gb + GL.tiles_touched), radii,
-                                    inst_grad, (uint32_t)R, dL_daux_colors, dL_dmeans2D, /*accumulate=*/false, s);
+                                    inst_grad, (uint8_t*)const_cast<char*>(bb + BL.row_flag) + BL.row_flag_stride,
+                                    (uint32_t)R, dL_daux_colors, dL_dmeans2D, /*accumulate=*/false, s);
 }
 
 int instag_raster_debug_export(const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,

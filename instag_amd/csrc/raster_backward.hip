@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256)
 preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
                            const float* __restrict__ cov3d, const uint32_t* __restrict__ tiles_touched,
                            const uint32_t* __restrict__ flags_in, const int32_t* __restrict__ radii,
-                           const float* __restrict__ inst_grad, uint32_t capacity) {
+                           const float* __restrict__ inst_grad, uint8_t* __restrict__ row_flag, uint32_t capacity) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= c.N) return;
   bool visible = radii[g] > 0;
@@ -56,13 +56,24 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
     const uint32_t tt = tiles_touched[g];
     const uint32_t off = __float_as_uint(rec2d[(size_t)g * REC_FLOATS + R_OFFSET]);
     const float4* rows = reinterpret_cast<const float4*>(inst_grad + (size_t)off * REC_FLOATS);
-#pragma unroll 4      // several 64-B rows in flight per thread (the rows of a Gaussian are contiguous)
-    for (uint32_t t = 0; t < tt; ++t) {
-      const float4 q0 = rows[4 * t + 0], q1 = rows[4 * t + 1], q2 = rows[4 * t + 2], q3 = rows[4 * t + 3];
-      gs[0] += q0.x; gs[1] += q0.y; gs[2] += q0.z; gs[3] += q0.w;
-      gs[4] += q1.x; gs[5] += q1.y; gs[6] += q1.z; gs[7] += q1.w;
-      gs[8] += q2.x; gs[9] += q2.y; gs[10] += q2.z; gs[11] += q2.w;
-      gs[12] += q3.x; gs[13] += q3.y;
+    // only the rows the blend pass wrote exist (a tile's list is walked up to its last contributor: C3 walks 13 % of
+    // the entries); their flags are cleared here, so that the set is clean for the next backward pass over this state
+    // flags of four rows first, then the rows that exist: their loads are issued together
+    for (uint32_t t0 = 0; t0 < tt; t0 += 4) {
+      uint8_t f[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) f[k] = (t0 + k < tt) ? row_flag[off + t0 + k] : (uint8_t)0;
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        if (f[k] == 0) continue;
+        const uint32_t t = t0 + k;
+        row_flag[off + t] = 0;
+        const float4 q0 = rows[4 * t + 0], q1 = rows[4 * t + 1], q2 = rows[4 * t + 2], q3 = rows[4 * t + 3];
+        gs[0] += q0.x; gs[1] += q0.y; gs[2] += q0.z; gs[3] += q0.w;
+        gs[4] += q1.x; gs[5] += q1.y; gs[6] += q1.z; gs[7] += q1.w;
+        gs[8] += q2.x; gs[9] += q2.y; gs[10] += q2.z; gs[11] += q2.w;
+        gs[12] += q3.x; gs[13] += q3.y;
+      }
     }
   }
   const float dL_dx = gs[0], dL_dy = gs[1], gA = gs[2], gB = gs[3], gC = gs[4];
@@ -314,7 +325,8 @@ preprocess_backward_kernel(Camera c, BwdIO io, const float* __restrict__ rec2d,
 // gradient.  Sums the Gaussian's instance rows written by blend-backward run with the colour override.
 __global__ void __launch_bounds__(256)
 aux_backward_reduce_kernel(Camera c, const float* __restrict__ rec2d, const uint32_t* __restrict__ tiles_touched,
-                           const int32_t* __restrict__ radii, const float* __restrict__ inst_grad, uint32_t capacity,
+                           const int32_t* __restrict__ radii, const float* __restrict__ inst_grad,
+                           uint8_t* __restrict__ row_flag, uint32_t capacity,
                            float* __restrict__ dL_daux, float* __restrict__ dL_dmeans2D, int accumulate) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   if (g >= c.N) return;
@@ -326,6 +338,8 @@ aux_backward_reduce_kernel(Camera c, const float* __restrict__ rec2d, const uint
       const float4* rows = reinterpret_cast<const float4*>(inst_grad + (size_t)off * REC_FLOATS);
 #pragma unroll 4
       for (uint32_t t = 0; t < tt; ++t) {
+        if (row_flag[off + t] == 0) continue;
+        row_flag[off + t] = 0;
         const float4 q0 = rows[4 * t + 0], q1 = rows[4 * t + 1], q2 = rows[4 * t + 2];
         gx += q0.x; gy += q0.y;
         dc[0] += q1.z; dc[1] += q1.w; dc[2] += q2.x;
@@ -347,7 +361,7 @@ aux_backward_reduce_kernel(Camera c, const float* __restrict__ rec2d, const uint
 
 int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, const float* rec2d,
                                const float* cov3d, const uint32_t* tiles_touched, const uint32_t* flags,
-                               const int32_t* radii, const float* inst_grad, uint32_t capacity,
+                               const int32_t* radii, const float* inst_grad, uint8_t* row_flag, uint32_t capacity,
                                float* dL_dmeans3D, float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                                float* dL_dopacities, float* dL_dscales, float* dL_drotations,
                                float* dL_dcov3D, float* dL_dextra, float* dL_dshs_rest, float* dL_daux_colors,
@@ -358,17 +372,17 @@ int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, con
            dL_dcov3D, dL_dextra, a->shs_rest, dL_dshs_rest, dL_daux_colors};
   ProfScope p(K_PREPROCESS_BWD, s);
   preprocess_backward_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, io, rec2d, cov3d, tiles_touched, flags,
-                                                               radii, inst_grad, capacity);
+                                                               radii, inst_grad, row_flag, capacity);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
 int launch_aux_backward_reduce(const Camera& c, const float* rec2d, const uint32_t* tiles_touched, const int32_t* radii,
-                               const float* inst_grad, uint32_t capacity, float* dL_daux_colors, float* dL_dmeans2D,
-                               bool accumulate_means2D, hipStream_t s) {
+                               const float* inst_grad, uint8_t* row_flag, uint32_t capacity, float* dL_daux_colors,
+                               float* dL_dmeans2D, bool accumulate_means2D, hipStream_t s) {
   if (c.N == 0) return INSTAG_OK;
   ProfScope p(K_PREPROCESS_BWD, s);
-  aux_backward_reduce_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, rec2d, tiles_touched, radii, inst_grad, capacity,
+  aux_backward_reduce_kernel<<<div_up(c.N, 256), 256, 0, s>>>(c, rec2d, tiles_touched, radii, inst_grad, row_flag, capacity,
                                                                dL_daux_colors, dL_dmeans2D, accumulate_means2D ? 1 : 0);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;

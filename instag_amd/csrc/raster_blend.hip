@@ -50,11 +50,15 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
                      float* __restrict__ out_depth, float* __restrict__ out_normal,
                      float* __restrict__ out_alpha, float* __restrict__ out_extra,
                      const float* __restrict__ aux_colors, float* __restrict__ out_aux,
-                     uint32_t* __restrict__ seg_tile, float* __restrict__ seg_state,
-                     uint32_t* __restrict__ tile_rounds) {
-  // [0] x y A' C'   [1] B' op r g   [2] b depth nx ny   [3] nz extra aux_r aux_g ; s_auxb: aux_b
-  __shared__ float4 s_rec[BLOCK][4];
-  __shared__ float s_auxb[AUX ? BLOCK : 1];
+                     uint32_t* __restrict__ seg_queue, uint32_t* __restrict__ seg_count,
+                     float* __restrict__ seg_state, uint32_t* __restrict__ tile_rounds) {
+  // One LDS array per read of the inner loop, each read a whole ds_read_b128 (4 LDS cycles per wave) or ds_read_b64
+  // (2): the LDS array, shared by every wave of the CU, is the forward pass's scarcest resource -- a record read as
+  // 64-bit halves of neighbouring float4 (what the compiler makes of an array of structs) costs twice as much.
+  __shared__ float4 s_geo[BLOCK];                  // x y A' C'
+  __shared__ float2 s_bo[BLOCK];                   // B' opacity
+  __shared__ float4 s_c0[BLOCK], s_c1[BLOCK];      // r g b depth | nx ny nz extra
+  __shared__ float4 s_c2[AUX ? BLOCK : 1];         // aux r g b -
   const int tile = blockIdx.x;
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
   const int tid = threadIdx.x;
@@ -63,10 +67,11 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   const int start = ranges[2 * tile], end = ranges[2 * tile + 1];
   const int rounds = (end - start + BLOCK - 1) / BLOCK;
   int toDo = end - start;
-  // every 256-entry round of the list is a segment with a slot of its own (common.hpp BinningLayout): the per-pixel
-  // state after each round the tile walks is kept there, so that the backward pass can start anywhere
-  const int slot0 = (start >> 8) + tile;
-  for (int r = tid; r < rounds; r += BLOCK) seg_tile[slot0 + r] = (uint32_t)tile + 1u;
+  // every SEG_LEN entries of the list are a segment with a slot of its own (common.hpp BinningLayout): the per-pixel
+  // state after each segment the tile walks is kept there, so that the backward pass can start anywhere
+  static_assert(BLOCK % SEG_LEN == 0 && SEG_LEN % 4 == 0, "a batch is a whole number of segments");
+  constexpr int SUBS = BLOCK / SEG_LEN;
+  const int slot0 = start / SEG_LEN + tile;
   int walked = 0;
 
   f32x2 pix = inside ? f32x2{(float)pxi, (float)pyi} : f32x2{FAR_PIXEL, FAR_PIXEL};
@@ -77,8 +82,7 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   f32x2 acc2[NCH / 2];
 #pragma unroll
   for (int k = 0; k < NCH / 2; ++k) acc2[k] = f32x2{0.f, 0.f};
-  f32x2 xacc2 = {0.f, 0.f};
-  float xacc_b = 0.f;
+  f32x2 xacc2 = {0.f, 0.f}, xacc3 = {0.f, 0.f};
 
   // the records of batch i+1 are fetched while batch i is being blended; a slot past the end of the list holds a record
   // with opacity 0 (never counts), so the loop below runs whole groups of four
@@ -103,84 +107,106 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   fetch(tid);
   for (int i = 0; i < rounds; ++i, toDo -= BLOCK) {
     if (__syncthreads_count(pix.x > 0.5f * FAR_PIXEL) == BLOCK) break;
-    s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
-    if (AUX) s_auxb[tid] = nauxb;
+    s_geo[tid] = nrec0; s_bo[tid] = make_float2(nrec1.x, nrec1.y);
+    s_c0[tid] = make_float4(nrec1.z, nrec1.w, nrec2.x, nrec2.y);
+    s_c1[tid] = make_float4(nrec2.z, nrec2.w, nrec3.x, nrec3.y);
+    if (AUX) s_c2[tid] = make_float4(nrec3.z, nrec3.w, nauxb, 0.f);
     __syncthreads();
     fetch((i + 1) * BLOCK + tid);
     const int groups = (min(BLOCK, toDo) + 3) >> 2;
-    for (int g = 0; g < groups; ++g) {
-      float al[4], w[4];
-      bool hit[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float4 a = s_rec[4 * g + k][0];
-        const float4 b = s_rec[4 * g + k][1];
-        const f32x2 d = f32x2{a.x, a.y} - pix;
-        const f32x2 u = (d * f32x2{a.z, a.w}) * d;
-        const float p2 = __builtin_fmaf(b.x, d.x * d.y, u.x + u.y);
-        const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
-        hit[k] = !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
-        al[k] = hit[k] ? alpha : 0.f;
-      }
-      const float t1 = T * (1.0f - al[0]);
-      const float t2 = t1 * (1.0f - al[1]);
-      const float t3 = t2 * (1.0f - al[2]);
-      float t4 = t3 * (1.0f - al[3]);
-      w[0] = al[0] * T; w[1] = al[1] * t1; w[2] = al[2] * t2; w[3] = al[3] * t3;
-      uint32_t code = hit[0] ? 1u : 0u;
-      code = hit[1] ? 2u : code;
-      code = hit[2] ? 3u : code;
-      code = hit[3] ? 4u : code;
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(t4 < T_MIN) != 0, 0)) {
-        // some pixel of this wave finishes within these four: redo them with the per-lane stop rule (a lane that
-        // does not stop gets the same numbers again)
-        bool dead = false;
-        float Tc = T;
-        code = 0u;
+    for (int h = 0; h < SUBS && h * (SEG_LEN / 4) < groups; ++h) {
+      const int g_end = min(groups, (h + 1) * (SEG_LEN / 4));
+      for (int g = h * (SEG_LEN / 4); g < g_end; ++g) {
+        float al[4], w[4];
+        bool hit[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          float a = dead ? 0.f : al[k];
-          const float tt = Tc * (1.0f - a);
-          const bool stop = tt < T_MIN;
-          dead = dead || stop;
-          a = stop ? 0.f : a;
-          code = (a > 0.f) ? (uint32_t)(k + 1) : code;
-          w[k] = a * Tc;
-          Tc = stop ? Tc : tt;
+          const float4 a = s_geo[4 * g + k];
+          const float2 b = s_bo[4 * g + k];
+          const f32x2 d = f32x2{a.x, a.y} - pix;
+          const f32x2 u = (d * f32x2{a.z, a.w}) * d;
+          const float p2 = __builtin_fmaf(b.x, d.x * d.y, u.x + u.y);
+          const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
+          hit[k] = !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
+          al[k] = hit[k] ? alpha : 0.f;
         }
-        t4 = Tc;
-        if (dead) pix = f32x2{FAR_PIXEL, FAR_PIXEL};
-      }
-      T = t4;
-      last_contributor = code ? (uint32_t)(i * BLOCK + 4 * g) + code : last_contributor;
+        const float t1 = T * (1.0f - al[0]);
+        const float t2 = t1 * (1.0f - al[1]);
+        const float t3 = t2 * (1.0f - al[2]);
+        float t4 = t3 * (1.0f - al[3]);
+        w[0] = al[0] * T; w[1] = al[1] * t1; w[2] = al[2] * t2; w[3] = al[3] * t3;
+        uint32_t code = hit[0] ? 1u : 0u;
+        code = hit[1] ? 2u : code;
+        code = hit[2] ? 3u : code;
+        code = hit[3] ? 4u : code;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(t4 < T_MIN) != 0, 0)) {
+          // some pixel of this wave finishes within these four: redo them with the per-lane stop rule (a lane that
+          // does not stop gets the same numbers again)
+          bool dead = false;
+          float Tc = T;
+          code = 0u;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float4 b = s_rec[4 * g + k][1];
-        const float4 cc = s_rec[4 * g + k][2];
-        const float4 dd = s_rec[4 * g + k][3];
-        const f32x2 w2 = {w[k], w[k]};
-        acc2[0] = __builtin_elementwise_fma(f32x2{b.z, b.w}, w2, acc2[0]);
-        acc2[1] = __builtin_elementwise_fma(f32x2{cc.x, cc.y}, w2, acc2[1]);
-        acc2[2] = __builtin_elementwise_fma(f32x2{cc.z, cc.w}, w2, acc2[2]);
-        acc2[3] = __builtin_elementwise_fma(f32x2{dd.x, dd.y}, w2, acc2[3]);
-        if (AUX) {
-          xacc2 = __builtin_elementwise_fma(f32x2{dd.z, dd.w}, w2, xacc2);
-          xacc_b = __builtin_fmaf(s_auxb[4 * g + k], w[k], xacc_b);
+          for (int k = 0; k < 4; ++k) {
+            float a = dead ? 0.f : al[k];
+            const float tt = Tc * (1.0f - a);
+            const bool stop = tt < T_MIN;
+            dead = dead || stop;
+            a = stop ? 0.f : a;
+            code = (a > 0.f) ? (uint32_t)(k + 1) : code;
+            w[k] = a * Tc;
+            Tc = stop ? Tc : tt;
+          }
+          t4 = Tc;
+          if (dead) pix = f32x2{FAR_PIXEL, FAR_PIXEL};
+        }
+        T = t4;
+        last_contributor = code ? (uint32_t)(i * BLOCK + 4 * g) + code : last_contributor;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 c0 = s_c0[4 * g + k];
+          const float4 c1 = s_c1[4 * g + k];
+          const f32x2 w2 = {w[k], w[k]};
+          acc2[0] = __builtin_elementwise_fma(f32x2{c0.x, c0.y}, w2, acc2[0]);
+          acc2[1] = __builtin_elementwise_fma(f32x2{c0.z, c0.w}, w2, acc2[1]);
+          acc2[2] = __builtin_elementwise_fma(f32x2{c1.x, c1.y}, w2, acc2[2]);
+          acc2[3] = __builtin_elementwise_fma(f32x2{c1.z, c1.w}, w2, acc2[3]);
+          if (AUX) {
+            const float4 c2 = s_c2[4 * g + k];
+            xacc2 = __builtin_elementwise_fma(f32x2{c2.x, c2.y}, w2, xacc2);
+            xacc3 = __builtin_elementwise_fma(f32x2{c2.z, c2.w}, w2, xacc3);   // (.w: a 12-byte read costs two 16-byte ones)
+          }
         }
       }
-    }
-    {
-      float* ck = seg_state + (size_t)(slot0 + i) * (SEG_FLOATS * SEG_LEN) + tid;
+      float* ck = seg_state + (size_t)(slot0 + i * SUBS + h) * (SEG_FLOATS * TILE_PIX) + tid;
       ck[0] = T;
 #pragma unroll
-      for (int k = 0; k < NCH / 2; ++k) { ck[(1 + 2 * k) * SEG_LEN] = acc2[k].x; ck[(2 + 2 * k) * SEG_LEN] = acc2[k].y; }
-      ck[9 * SEG_LEN] = xacc2.x; ck[10 * SEG_LEN] = xacc2.y; ck[11 * SEG_LEN] = xacc_b;
+      for (int k = 0; k < NCH / 2; ++k) { ck[(1 + 2 * k) * TILE_PIX] = acc2[k].x; ck[(2 + 2 * k) * TILE_PIX] = acc2[k].y; }
+      ck[9 * TILE_PIX] = xacc2.x; ck[10 * TILE_PIX] = xacc2.y; ck[11 * TILE_PIX] = xacc3.x;
+      walked = i * SUBS + h + 1;
     }
-    walked = i + 1;
   }
-  if (tid == 0) tile_rounds[tile] = (uint32_t)walked;
+  {
+    // work list of the backward pass: the segments in front of the tile's last contributor
+    __shared__ uint32_t s_last[BLOCK / 64], s_base;
+    uint32_t m = inside ? last_contributor : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((tid & 63) == 0) s_last[tid >> 6] = m;
+    __syncthreads();
+    const uint32_t tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    const uint32_t nseg = (tile_last + SEG_LEN - 1) / SEG_LEN;
+    if (tid == 0) {
+      tile_rounds[tile] = (uint32_t)walked;
+      s_base = nseg ? atomicAdd(seg_count, nseg) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < nseg; k += BLOCK) {
+      seg_queue[2 * (s_base + k)] = (uint32_t)tile;
+      seg_queue[2 * (s_base + k) + 1] = k;
+    }
+  }
   const float acc[NCH] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
-  const float xacc[3] = {xacc2.x, xacc2.y, xacc_b};
+  const float xacc[3] = {xacc2.x, xacc2.y, xacc3.x};
   if (inside) {
     const size_t P = (size_t)c.H * c.W;
     const size_t pix_i = (size_t)pyi * c.W + pxi;
@@ -230,16 +256,16 @@ constexpr int WROW = 68;        // floats per (pixel-quarter, Gaussian) row of t
 // XONLY: a pass over `color_override` colours that only produces the screen-space mean's gradient (rows: dx, dy): no w
 //   product at all, half the matrix work of a colour pass.
 template <bool FULL, int AUX, bool XONLY>
-__global__ void __launch_bounds__(BLOCK, AUX == 1 ? 2 : 4)   // (waves per SIMD the LDS footprint allows: 128 / 256 registers)
-blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+__device__ __forceinline__ void
+blend_backward_segment(const int tile, const int seg, const Camera& c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                       const uint32_t* __restrict__ slot_list, const float* __restrict__ rec2d, const uint32_t* __restrict__ n_contrib,
                       const float* __restrict__ final_T, const float* __restrict__ dL_dcolor,
                       const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dnormal,
                       const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
                       float* __restrict__ inst_grad, const float* __restrict__ color_override /*[N,3] or null*/,
                       const float* __restrict__ aux_colors /*[N,3], AUX*/, const float* __restrict__ dL_daux /*[3,H,W], AUX*/,
-                      const uint32_t* __restrict__ seg_tile, const float* __restrict__ seg_state,
-                      const uint32_t* __restrict__ tile_rounds) {
+                      const float* __restrict__ seg_state, const uint32_t* __restrict__ tile_rounds,
+                      uint8_t* __restrict__ row_flag) {
   static_assert(!(FULL && AUX != 0), "the auxiliary gradients use the row slots of the depth / normal / extra gradients");
   static_assert(!(XONLY && (FULL || AUX != 0)), "XONLY is a pass of its own");
   constexpr bool AUXW = AUX != 0, AUXX = AUX == 1;
@@ -247,25 +273,25 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   constexpr int MW = 0, MT = XONLY ? 0 : 1, MX = 2;
   // Records are staged 32 at a time -- two batches -- so that their two dependent global loads are issued a full two
   // batches (~3 us) before they are needed
-  __shared__ float4 s_rec[SB][4];
+  // staged records, one LDS array per read of phase A (whole ds_read_b128 / ds_read_b64, see blend_forward_kernel)
+  __shared__ float4 s_geo[SB];                  // x y A' C'   (conic in the log2 domain, as in the forward pass)
+  __shared__ float2 s_bo[SB];                   // B' opacity
+  __shared__ float4 s_c0[SB];                   // r g b depth
+  __shared__ float4 s_c1[FULL ? SB : 1];        // nx ny nz extra
+  __shared__ float4 s_con[SB];                  // conic A B C and the instance's gradient row (row assembly only)
   __shared__ float4 s_axc[AUXX ? SB : 1];              // auxiliary colours of the staged records
   __shared__ __align__(16) float s_W[XONLY ? 4 : 4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
   __shared__ __align__(16) float s_T[4 * BB * WROW];
   __shared__ __align__(16) float s_X[AUXX ? 4 * BB * WROW : 4];
   __shared__ float s_res[BB][NMAT][4][8];              // [gaussian][matrix][wave = 16 steps of every quarter][feature < 8]
   int* s_max = reinterpret_cast<int*>(&s_res[0][0][0][0]);   // (used once, before the first batch)
-  // One workgroup per SEGMENT (256 list entries of one tile), not per tile: the forward pass left the per-pixel state
-  // after every segment (seg_state), so a segment's back-to-front walk starts from the state behind it instead of
-  // waiting for the walk over everything behind it.  The kernel's duration used to be the longest tile's chain (C3:
-  // 1279 entries = 80 batches); now no chain is longer than 16 batches and the segments fill the chip evenly.
-  const int slot = blockIdx.x;
-  const uint32_t tcode = seg_tile[slot];
-  if (tcode == 0u || tcode > (uint32_t)(c.grid_x * c.grid_y)) return;        // not a segment of this frame
-  const int tile = (int)tcode - 1;
+  // One SEGMENT (SEG_LEN list entries of one tile) per call, not a whole tile: the forward pass left the per-pixel
+  // state after every segment (seg_state), so a segment's back-to-front walk starts from the state behind it instead
+  // of waiting for the walk over everything behind it.  The kernel's duration used to be the longest tile's chain (C3:
+  // 1279 entries = 80 batches); now no chain is longer than SEG_LEN / 16 batches and the segments fill the chip evenly.
   const int list_start = ranges[2 * tile], list_end = ranges[2 * tile + 1];
-  const int slot0 = (list_start >> 8) + tile;
-  const int seg = slot - slot0;
-  if (seg < 0 || seg * SEG_LEN >= list_end - list_start) return;             // (stale word of an earlier frame)
+  const int slot0 = list_start / SEG_LEN + tile;
+  const int slot = slot0 + seg;
   const int tx = tile % c.grid_x, ty = tile / c.grid_x;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -304,13 +330,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
   if (lane == 0) s_max[wave] = m;
   __syncthreads();
   const int n = min(end - start, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-  // instances behind the last contributor of every pixel get an all-zero gradient row (every row of the tile's
-  // list is written exactly once, so the caller does not have to clear inst_grad)
-  for (int i = max(n, 0) + tid; i < end - start; i += BLOCK) {
-    float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)slot_list[start + i] * REC_FLOATS);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    dst[0] = z; dst[1] = z; dst[2] = z; dst[3] = z;
-  }
+  // entries behind the last contributor of every pixel get no gradient row: row_flag says which rows exist
   if (n <= 0) return;
 
   // d(T_final)/d(alpha_i) = -T_final/(1-alpha_i); T_final enters image (+bg) and alpha image (-1); the aux image has
@@ -354,17 +374,19 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     // the pixel's walk began behind this segment: T in front of the segment's last entry + 1 is the forward pass's own
     // value, and Q there is <dL/dpixel, colour accumulated behind> = <dL/dpixel, final accumulators - accumulators
     // after this segment> (the last segment the tile walked holds the final ones)
-    const float* ck = seg_state + (size_t)slot * (SEG_FLOATS * SEG_LEN) + tid;
-    const float* cf = seg_state + (size_t)(slot0 + (int)tile_rounds[tile] - 1) * (SEG_FLOATS * SEG_LEN) + tid;
+    const float* ck = seg_state + (size_t)slot * (SEG_FLOATS * TILE_PIX) + tid;
+    const float* cf = seg_state + (size_t)(slot0 + (int)tile_rounds[tile] - 1) * (SEG_FLOATS * TILE_PIX) + tid;
     T = ck[0];
     const int ch0 = color_override ? 9 : 1;
 #pragma unroll
-    for (int k = 0; k < (FULL ? NCH : 3); ++k) Q += dpix[k] * (cf[(ch0 + k) * SEG_LEN] - ck[(ch0 + k) * SEG_LEN]);
+    for (int k = 0; k < (FULL ? NCH : 3); ++k) Q += dpix[k] * (cf[(ch0 + k) * TILE_PIX] - ck[(ch0 + k) * TILE_PIX]);
     if (AUXX) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) Qx += dpx[k] * (cf[(9 + k) * SEG_LEN] - ck[(9 + k) * SEG_LEN]);
+      for (int k = 0; k < 3; ++k) Qx += dpx[k] * (cf[(9 + k) * TILE_PIX] - ck[(9 + k) * TILE_PIX]);
     }
   }
+  Q += tf_tail; Qx += tf_tail_x;               // (the recurrences below carry Q + T_final * tail)
+  const f32x2 pix2 = {pxf, pyf};
 
   const float tile_x0 = (float)(tx * TILE_X), tile_y0 = (float)(ty * TILE_Y);
   const int rounds = (n + SB - 1) / SB;
@@ -387,7 +409,11 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     const int sbase = n - 1 - si * SB;        // list index of round element 0 (walks backwards)
     const int scnt = min(SB, n - si * SB);
     if (tid < scnt) {
-      s_rec[tid][0] = nrec0; s_rec[tid][1] = nrec1; s_rec[tid][2] = nrec2; s_rec[tid][3] = nrec3;
+      s_geo[tid] = make_float4(nrec0.x, nrec0.y, (-0.5f * LOG2E) * nrec0.z, (-0.5f * LOG2E) * nrec1.x);
+      s_bo[tid] = make_float2(-LOG2E * nrec0.w, nrec1.y);
+      s_c0[tid] = make_float4(nrec1.z, nrec1.w, nrec2.x, nrec2.y);
+      if (FULL) s_c1[tid] = make_float4(nrec2.z, nrec2.w, nrec3.x, nrec3.y);
+      s_con[tid] = make_float4(nrec0.z, nrec0.w, nrec1.x, nrec3.z);
       if (AUXX) s_axc[tid] = naxc;
     }
     __syncthreads();
@@ -395,37 +421,37 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
    for (int off = 0; off < scnt; off += BB) {
     const int base = sbase - off;             // list index of batch element 0
     const int cnt = min(BB, scnt - off);
-    const float4 (*rec)[4] = s_rec + off;
     // ---- phase A: advance the per-pixel recurrence, emit w and t (branch-free, unrolled) ------------------
 #pragma unroll 4
     for (int j = 0; j < cnt; ++j) {
       const int idx = base - j;
-      const float4 a = rec[j][0];   // x y conA conB
-      const float4 b = rec[j][1];   // conC op r g
-      const float4 cc = rec[j][2];  // b depth nx ny
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      const float G = __expf(power);
-      const float alpha = fminf(0.99f, b.y * G);
-      const bool valid = (idx < last_contributor) && !(power > 0.0f) && !(alpha < ALPHA_MIN);
-      float cd = b.z * dpix[0] + b.w * dpix[1] + cc.x * dpix[2];
+      const float4 a = s_geo[off + j];
+      const float2 bo = s_bo[off + j];
+      const float4 c0 = s_c0[off + j];
+      const f32x2 d = f32x2{a.x, a.y} - pix2;
+      const f32x2 u = (d * f32x2{a.z, a.w}) * d;
+      const float p2 = __builtin_fmaf(bo.x, d.x * d.y, u.x + u.y);
+      const float G = __builtin_amdgcn_exp2f(p2);
+      const float alpha = fminf(0.99f, bo.y * G);
+      const bool valid = (idx < last_contributor) && !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
+      float cd = c0.x * dpix[0] + c0.y * dpix[1] + c0.z * dpix[2];
       if (FULL) {
-        const float4 dd = rec[j][3];  // nz extra . .
-        cd += cc.y * dpix[3] + cc.z * dpix[4] + cc.w * dpix[5] + dd.x * dpix[6] + dd.y * dpix[7];
+        const float4 c1 = s_c1[off + j];
+        cd += c0.w * dpix[3] + c1.x * dpix[4] + c1.y * dpix[5] + c1.z * dpix[6] + c1.w * dpix[7];
       }
       const float alpha_e = valid ? alpha : 0.f;
       const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha_e);    // exactly 1 when not contributing
       T = T * inv1ma;
       const float w = alpha_e * T;
-      const float dL_dalpha = T * cd - inv1ma * (Q + tf_tail);
-      Q = Q + w * cd;
+      const float dL_dalpha = T * cd - inv1ma * Q;
+      Q = __builtin_fmaf(w, cd, Q);
       if (!XONLY) s_W[(wave * BB + j) * WROW + lane] = w;
       s_T[(wave * BB + j) * WROW + lane] = valid ? G * dL_dalpha : 0.f;
       if (AUXX) {
         const float4 ax = s_axc[off + j];
         const float cdx = ax.x * dpx[0] + ax.y * dpx[1] + ax.z * dpx[2];
-        const float dLx = T * cdx - inv1ma * (Qx + tf_tail_x);
-        Qx = Qx + w * cdx;
+        const float dLx = T * cdx - inv1ma * Qx;
+        Qx = __builtin_fmaf(w, cdx, Qx);
         s_X[(wave * BB + j) * WROW + lane] = valid ? G * dLx : 0.f;
       }
     }
@@ -474,7 +500,8 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
     __syncthreads();
     // ---- one 64-byte gradient row per (tile, Gaussian) instance -------------------------------------------------
     if (tid < cnt) {
-      const float4 ra = rec[tid][0], rb = rec[tid][1];
+      const float4 ra = s_geo[off + tid], con = s_con[off + tid];
+      const float2 rbo = s_bo[off + tid];
       float Dw[NCH], Dt[6];
 #pragma unroll
       for (int k = 0; k < NCH; ++k)
@@ -483,7 +510,7 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
       for (int k = 0; k < 6; ++k)
         Dt[k] = (s_res[tid][MT][0][k] + s_res[tid][MT][1][k]) + (s_res[tid][MT][2][k] + s_res[tid][MT][3][k]);
       const float X = ra.x - tile_x0, Y = ra.y - tile_y0;
-      const float A = ra.z, B = ra.w, Cc = rb.x, op = rb.y;
+      const float A = con.x, B = con.y, Cc = con.z, op = rbo.y;
       const float S0 = Dt[0], Sx = Dt[1], Sy = Dt[2], Sxx = Dt[3], Sxy = Dt[4], Syy = Dt[5];
       const float tdx = X * S0 - Sx, tdy = Y * S0 - Sy;
       const float tdxx = X * X * S0 - 2.f * X * Sx + Sxx;
@@ -511,11 +538,35 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
           r4[3] = make_float4(-op * (A * xdx + B * xdy), -op * (Cc * xdy + B * xdx), 0.f, 0.f);
         }
       }
-      const uint32_t slot = __float_as_uint(rec[tid][3].z);
-      float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)slot * REC_FLOATS);
+      const uint32_t row = __float_as_uint(con.w);
+      float4* dst = reinterpret_cast<float4*>(inst_grad + (size_t)row * REC_FLOATS);
       dst[0] = r4[0]; dst[1] = r4[1]; dst[2] = r4[2]; dst[3] = r4[3];
+      row_flag[row] = 1;
     }
    }
+  }
+}
+
+// Persistent over the work list the forward pass built: (tile, segment) pairs, seg_count of them.
+template <bool FULL, int AUX, bool XONLY>
+__global__ void __launch_bounds__(BLOCK, AUX == 1 ? 2 : 4)   // (waves per SIMD the LDS footprint allows: 128 / 256 registers)
+blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                      const uint32_t* __restrict__ slot_list, const float* __restrict__ rec2d, const uint32_t* __restrict__ n_contrib,
+                      const float* __restrict__ final_T, const float* __restrict__ dL_dcolor,
+                      const float* __restrict__ dL_ddepth, const float* __restrict__ dL_dnormal,
+                      const float* __restrict__ dL_dalpha_img, const float* __restrict__ dL_dextra,
+                      float* __restrict__ inst_grad, const float* __restrict__ color_override,
+                      const float* __restrict__ aux_colors, const float* __restrict__ dL_daux,
+                      const uint32_t* __restrict__ seg_queue, const uint32_t* __restrict__ seg_count,
+                      const float* __restrict__ seg_state, const uint32_t* __restrict__ tile_rounds,
+                      uint8_t* __restrict__ row_flag) {
+  const uint32_t count = *seg_count;
+  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    blend_backward_segment<FULL, AUX, XONLY>((int)seg_queue[2 * item], (int)seg_queue[2 * item + 1], c, ranges, point_list,
+                                             slot_list, rec2d, n_contrib, final_T, dL_dcolor, dL_ddepth, dL_dnormal,
+                                             dL_dalpha_img, dL_dextra, inst_grad, color_override, aux_colors, dL_daux,
+                                             seg_state, tile_rounds, row_flag);
+    __syncthreads();                      // the next segment reuses the LDS arrays
   }
 }
 
@@ -524,19 +575,19 @@ blend_backward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32
 int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
                          const float* rec2d, uint32_t* n_contrib, float* final_T, float* out_color,
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
-                         const float* aux_colors, float* out_aux, uint32_t* seg_tile, float* seg_state,
-                         uint32_t* tile_rounds, hipStream_t s) {
+                         const float* aux_colors, float* out_aux, uint32_t* seg_queue, uint32_t* seg_count,
+                         float* seg_state, uint32_t* tile_rounds, hipStream_t s) {
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
   ProfScope p(K_BLEND_FWD, s);
   if (aux_colors)
     blend_forward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
                                                        out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux,
-                                                       seg_tile, seg_state, tile_rounds);
+                                                       seg_queue, seg_count, seg_state, tile_rounds);
   else
     blend_forward_kernel<false><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
                                                         out_depth, out_normal, out_alpha, out_extra, nullptr, nullptr,
-                                                        seg_tile, seg_state, tile_rounds);
+                                                        seg_queue, seg_count, seg_state, tile_rounds);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
@@ -546,8 +597,8 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
                           const float* color_override, const float* aux_colors, const float* dL_daux, int aux_mode,
-                          const uint32_t* seg_tile, const float* seg_state, const uint32_t* tile_rounds,
-                          uint32_t seg_slots, hipStream_t s) {
+                          const uint32_t* seg_queue, const uint32_t* seg_count, const float* seg_state,
+                          const uint32_t* tile_rounds, uint32_t seg_slots, uint8_t* row_flag, hipStream_t s) {
   // aux_mode: 0 none, 1 whole aux image in this launch, 2 aux colours' gradient only, 3 mean-only pass over
   // `color_override` (rows carry dx, dy)
   const int tiles = c.grid_x * c.grid_y;
@@ -561,11 +612,14 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
     set_error("blend backward: the mean-only pass takes its colours from color_override");
     return INSTAG_E_ARG;
   }
+  // at most 16 workgroups per CU: enough to fill every slot the LDS footprint allows four times over; a workgroup
+  // takes further segments of the list in strides of the grid
+  const uint32_t grid = std::min<uint32_t>(seg_slots, 4096u);
   ProfScope p(K_BLEND_BWD, s);
 #define INSTAG_BB(F, A, X, d, n, e, ax, dax)                                                                            \
-  blend_backward_kernel<F, A, X><<<seg_slots, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib,        \
-                                                            final_T, dL_dcolor, d, n, dL_dalpha, e, inst_grad,          \
-                                                            color_override, ax, dax, seg_tile, seg_state, tile_rounds)
+  blend_backward_kernel<F, A, X><<<grid, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,     \
+                                                       dL_dcolor, d, n, dL_dalpha, e, inst_grad, color_override, ax,    \
+                                                       dax, seg_queue, seg_count, seg_state, tile_rounds, row_flag)
   if (aux_mode == 1) INSTAG_BB(false, 1, false, nullptr, nullptr, nullptr, aux_colors, dL_daux);
   else if (aux_mode == 2) INSTAG_BB(false, 2, false, nullptr, nullptr, nullptr, aux_colors, dL_daux);
   else if (aux_mode == 3) INSTAG_BB(false, 0, true, nullptr, nullptr, nullptr, nullptr, nullptr);

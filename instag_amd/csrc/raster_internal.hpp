@@ -68,27 +68,27 @@ inline bool use_packed_keys(int64_t R, int tiles) { return R < ((int64_t)1 << PA
 int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
                          const float* rec2d, uint32_t* n_contrib, float* final_T, float* out_color,
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
-                         const float* aux_colors, float* out_aux, uint32_t* seg_tile, float* seg_state,
-                         uint32_t* tile_rounds, hipStream_t s);
+                         const float* aux_colors, float* out_aux, uint32_t* seg_queue, uint32_t* seg_count,
+                         float* seg_state, uint32_t* tile_rounds, hipStream_t s);
 int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
                           const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,
                           const float* dL_dalpha, const float* dL_dextra, float* inst_grad,
                           const float* color_override, const float* aux_colors, const float* dL_daux, int aux_mode,
-                          const uint32_t* seg_tile, const float* seg_state, const uint32_t* tile_rounds,
-                          uint32_t seg_slots, hipStream_t s);
+                          const uint32_t* seg_queue, const uint32_t* seg_count, const float* seg_state,
+                          const uint32_t* tile_rounds, uint32_t seg_slots, uint8_t* row_flag, hipStream_t s);
 
 // raster_backward.hip
 int launch_preprocess_backward(const Camera& c, const instag_raster_args* a, const float* rec2d,
                                const float* cov3d, const uint32_t* tiles_touched, const uint32_t* flags,
-                               const int32_t* radii, const float* inst_grad, uint32_t capacity,
+                               const int32_t* radii, const float* inst_grad, uint8_t* row_flag, uint32_t capacity,
                                float* dL_dmeans3D,
                                float* dL_dmeans2D, float* dL_dshs, float* dL_dcolors,
                                float* dL_dopacities, float* dL_dscales, float* dL_drotations,
                                float* dL_dcov3D, float* dL_dextra, float* dL_dshs_rest, float* dL_daux_colors,
                                hipStream_t s);
 int launch_aux_backward_reduce(const Camera& c, const float* rec2d, const uint32_t* tiles_touched, const int32_t* radii,
-                               const float* inst_grad, uint32_t capacity, float* dL_daux_colors, float* dL_dmeans2D,
-                               bool accumulate_means2D, hipStream_t s);
+                               const float* inst_grad, uint8_t* row_flag, uint32_t capacity, float* dL_daux_colors,
+                               float* dL_dmeans2D, bool accumulate_means2D, hipStream_t s);
 
 }  // namespace instag

@@ -23,7 +23,7 @@ echo "[profile] trace done"
 # 2. HBM traffic: two TCC passes
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o run --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 \
-      --no-cpu-baseline > "$OUT/pmc_$C.log" 2>&1 || exit 1
+      --no-cpu-baseline --no-stable-targets > "$OUT/pmc_$C.log" 2>&1 || exit 1
 done
 python3 "$ROOT/scripts/pmc_summary.py" "$OUT/pmc_FETCH_SIZE/run_counter_collection.csv" \
     "$OUT/pmc_WRITE_SIZE/run_counter_collection.csv" "$SUM/${TAG}_pmc_hbm_traffic_c3" || exit 1
@@ -32,7 +32,18 @@ echo "[profile] hbm passes done"
 # 3. what the resident waves do: SQ pass (8 slots)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
     SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES -d "$OUT/pmc_sq" -o run --output-format csv -- python3 "$ROOT/bench.py" \
-    --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/pmc_sq.log" 2>&1 || exit 1
+    --steps 5 --warmup 2 --no-cpu-baseline --no-stable-targets > "$OUT/pmc_sq.log" 2>&1 || exit 1
 python3 "$ROOT/scripts/pmc_sq_summary.py" "$OUT/pmc_sq/run_counter_collection.csv" \
     "$SUM/${TAG}_pmc_sq_c3.csv" || exit 1
 echo "[profile] sq pass done"
+
+# 4. LDS / scalar / MFMA instruction mix of the blend kernels (own pass; a counter this build does not know only loses
+#    this summary)
+if rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM \
+    SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES -d "$OUT/pmc_lds" -o run --output-format csv -- python3 "$ROOT/bench.py" \
+    --steps 5 --warmup 2 --no-cpu-baseline --no-stable-targets > "$OUT/pmc_lds.log" 2>&1; then
+  python3 "$ROOT/scripts/pmc_sq_summary.py" "$OUT/pmc_lds/run_counter_collection.csv" "$SUM/${TAG}_pmc_lds_c3.csv"
+  echo "[profile] lds pass done"
+else
+  tail -5 "$OUT/pmc_lds.log"; echo "[profile] lds pass skipped"
+fi
