@@ -68,9 +68,17 @@ SideLane* side_lane(hipStream_t caller) {
     if (l.stream != nullptr && l.device == dev && l.caller == caller) return &l;
     if (l.stream == nullptr && free_slot == nullptr) free_slot = &l;
   }
-  if (free_slot == nullptr) return nullptr;        // all lanes taken: the sort stays on the caller's stream
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(caller, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (hipStreamIsCapturing(caller, &cs) != hipSuccess) return nullptr;
+  if (cs != hipStreamCaptureStatusNone) {
+    // a capturing caller (torch captures on a stream of its own, which never made an eager call) cannot create a lane:
+    // it borrows one that an eager call on this device created.  Only a capture's origin stream gets here
+    // (instag_raster_args.single_stream), and a thread issues one call at a time, so the lane is not in use.
+    for (SideLane& l : g_lanes)
+      if (l.stream != nullptr && l.device == dev) return &l;
+    return nullptr;
+  }
+  if (free_slot == nullptr) return nullptr;        // all lanes taken: the sort stays on the caller's stream
   SideLane l;
   if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
   if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess ||

@@ -83,10 +83,18 @@ class _FusedMLP(torch.autograd.Function):
         if deferred.active() and all(w is None or w.is_leaf for w in ctx.weights):
             for dz, inp, idx, shp in layers:
                 deferred.defer_weight_grad(dz, inp, ctx.weights[idx - 1])
+            if EAGER_FLUSH_ROWS and N >= EAGER_FLUSH_ROWS:
+                # a per-Gaussian MLP: its weight-gradient GEMMs are the big ones (sigma_net: a third of the step's MFMA
+                # work) and their operands exist now -- start them on the side stream beside the rest of the backward
+                # chain instead of in one lump beside the personalised field's backward, which they slow down
+                deferred.flush_async(dev)
             return dx, None, None, None
         dws = compute()
         dw1, dw2, dw3 = dws.get(1), dws.get(2), dws.get(3)
         return dx, dw1, dw2, dw3
+
+
+EAGER_FLUSH_ROWS = 32768      # 0: weight gradients wait for the flush points of renderer.py / gridencoder.py
 
 
 class _SharedInputMLPs(torch.autograd.Function):

@@ -26,6 +26,7 @@ from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import List, Optional
 
+import os
 import torch
 import torch.distributed as dist
 
@@ -545,6 +546,9 @@ class GraphedStep:
         mode = {"capture_error_mode": "thread_local"} if self.distributed else {}
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
+        dot = os.environ.get("INSTAG_GRAPH_DOT")       # diagnostics: the captured step's nodes and edges (DOT)
+        if dot:
+            self.graph_a.enable_debug_mode()
         self.plan.begin_step()
         if not self.split:
             with _no_gc(), _lib.graph_capture(self.graph_a, **mode):
@@ -573,6 +577,8 @@ class GraphedStep:
                     t._zero_grad()
         from . import _keepalive
         _keepalive.release()               # the captures have ended: cross-stream tensors held for them may go
+        if dot:
+            self.graph_a.debug_dump(dot)
         self.loss, self.l1 = loss, l1
         self.capacity = cap
 
