@@ -94,7 +94,11 @@ class _FusedMLP(torch.autograd.Function):
         return dx, dw1, dw2, dw3
 
 
-EAGER_FLUSH_ROWS = 32768      # 0: weight gradients wait for the flush points of renderer.py / gridencoder.py
+# Rows from which an MLP's weight gradients are launched right after its backward (0 = wait for the flush points of
+# renderer.py / gridencoder.py).  Measured on the C3 step (round 2): starting sigma_net's three GEMMs beside the glue
+# backward doubles that kernel (33 -> 75 us, it is on the critical path) and the graph executor then queues the
+# personalised field's backward behind the next flush: 1.072 ms/step with 0, 1.088 with 32768.
+EAGER_FLUSH_ROWS = 0
 
 
 class _SharedInputMLPs(torch.autograd.Function):
