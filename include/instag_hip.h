@@ -70,7 +70,11 @@ int instag_grid_total_variation(const float* inputs, const float* embeddings, fl
  * instag_triplane_backward_workspace_bytes(N, total_params) bytes of scratch.
  * shift (optional, [N, shift_stride >= 3]): the encoders are evaluated at xyz + shift_scale * shift[:, :3] (the universal
  * field sits behind the personalised alignment, gaussian_renderer/__init__.py:196-197); backward then also writes
- * dshift [N, shift_stride] = (shift_scale * d/dpoint, 0, ...) when it is non-NULL (needs dxyz). */
+ * dshift [N, shift_stride] = (shift_scale * d/dpoint, 0, ...) when it is non-NULL (needs dxyz).
+ * dxyz_add [N,3] / dshift_add [N, shift_stride] (optional, distinct from the outputs): gradients that the position's /
+ * the shift's OTHER consumers produced, added into dxyz / dshift by the same kernel -- the host code passes the position
+ * through the encoder (instag_amd/gridencoder.py tri_plane_encode(passthrough=True)), so autograd never launches a
+ * separate add for them. */
 int instag_triplane_forward(const float* xyz, const float* table_xy, const float* table_yz,
                             const float* table_xz, const int32_t* offsets, float* out, const float* shift,
                             uint32_t shift_stride, float shift_scale, uint32_t N, uint32_t L,
@@ -81,7 +85,7 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
                              float* dtable_yz, float* dtable_xz, void* workspace, size_t workspace_bytes,
                              const float* shift, uint32_t shift_stride, float shift_scale, float* dshift,
                              uint32_t N, uint32_t L, float S, uint32_t H, float bound, uint32_t total_params,
-                             instag_stream_t stream);
+                             const float* dxyz_add, const float* dshift_add, instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spherical-harmonics encoder.  Replaces shencoder/src/shencoder.h:8-9:

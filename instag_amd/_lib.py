@@ -100,7 +100,7 @@ _PROTOS = {
     "instag_triplane_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, u32, f32, u32, u32, f32, u32, f32, u32, vp]),
     "instag_triplane_backward_workspace_bytes": (sz, [u32, u32]),
     "instag_triplane_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, u32, f32, vp,
-                                           u32, u32, f32, u32, f32, u32, vp]),
+                                           u32, u32, f32, u32, f32, u32, vp, vp, vp]),
     "instag_sh_encode_forward": (C.c_int, [vp, vp, u32, u32, u32, vp, vp]),
     "instag_sh_encode_backward": (C.c_int, [vp, vp, u32, u32, u32, vp, vp, vp]),
     "instag_raster_geom_bytes": (sz, [i32]),
@@ -164,7 +164,7 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
-ABI_VERSION = 5     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
+ABI_VERSION = 6     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
 
 
 def lib():

@@ -773,7 +773,9 @@ inline unsigned tp_bwd_blocks(uint32_t N) {
 
 __global__ void __launch_bounds__(TP_BWD_BLOCK)
 triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]*/, float* __restrict__ dxyz /*[N,3] or null*/,
-                         float* __restrict__ dshift /*[N, shift_stride] or null*/, float* __restrict__ ws /*[gridDim.x][3T]*/) {
+                         float* __restrict__ dshift /*[N, shift_stride] or null*/, float* __restrict__ ws /*[gridDim.x][3T]*/,
+                         const float* __restrict__ dxyz_add /*[N,3] or null: added to dxyz*/,
+                         const float* __restrict__ dshift_add /*[N, shift_stride] or null: added to dshift*/) {
   extern __shared__ __align__(16) unsigned long long s_mem64[];      // [T] i64 gradient | [T] f32 table of the plane
   __shared__ TpLevel s_lv[TP_MAX_L];
   __shared__ float s_wmax[TP_BWD_BLOCK / 64];
@@ -854,13 +856,19 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
         if (plane == 0) { d[0] = gx; d[1] = gy; d[2] = 0.f; }
         else if (plane == 1) { d[1] += gx; d[2] += gy; }
         else {
-          const float d0 = d[0] + gx, d1 = d[1], d2 = d[2] + gy;
-          d[0] = d0; d[2] = d2;
+          float d0 = d[0] + gx, d1 = d[1], d2 = d[2] + gy;
           if (dshift) {               // d/d shift[:, :3] = shift_scale * d/d point, the other columns get no gradient here
             float* ds = dshift + (size_t)b * a.shift_stride;
-            ds[0] = a.shift_scale * d0; ds[1] = a.shift_scale * d1; ds[2] = a.shift_scale * d2;
-            for (uint32_t k = 3; k < a.shift_stride; ++k) ds[k] = 0.f;
+            const float* da = dshift_add ? dshift_add + (size_t)b * a.shift_stride : nullptr;
+            ds[0] = a.shift_scale * d0 + (da ? da[0] : 0.f);
+            ds[1] = a.shift_scale * d1 + (da ? da[1] : 0.f);
+            ds[2] = a.shift_scale * d2 + (da ? da[2] : 0.f);
+            for (uint32_t k = 3; k < a.shift_stride; ++k) ds[k] = da ? da[k] : 0.f;
           }
+          if (dxyz_add) {             // the gradient of the position's other consumers, summed here (no extra launch)
+            d0 += dxyz_add[(size_t)b * 3]; d1 += dxyz_add[(size_t)b * 3 + 1]; d2 += dxyz_add[(size_t)b * 3 + 2];
+          }
+          d[0] = d0; d[1] = d1; d[2] = d2;
         }
       }
     }
@@ -934,8 +942,11 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
                              float* dtable_yz, float* dtable_xz, void* workspace, size_t workspace_bytes,
                              const float* shift, uint32_t shift_stride, float shift_scale, float* dshift, uint32_t N,
                              uint32_t L, float S, uint32_t H, float bound, uint32_t total_params,
-                             instag_stream_t stream) {
+                             const float* dxyz_add, const float* dshift_add, instag_stream_t stream) {
   using namespace instag;
+  INSTAG_REQUIRE(dxyz_add == nullptr || (dxyz != nullptr && dxyz_add != dxyz), "triplane_backward: dxyz_add needs a distinct dxyz");
+  INSTAG_REQUIRE(dshift_add == nullptr || (dshift != nullptr && dshift_add != dshift),
+                 "triplane_backward: dshift_add needs a distinct dshift");
   INSTAG_REQUIRE(grad && xyz && table_xy && table_yz && table_xz && offsets && dtable_xy && dtable_yz && dtable_xz,
                  "triplane_backward: NULL tensor");
   INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
@@ -956,7 +967,8 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
   TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound, shift, shift_stride, shift_scale};
   ProfScope p(K_GRID_BWD, s);
   triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)12 * total_params, s>>>(a, grad, dxyz, dshift,
-                                                                                    (float*)workspace);
+                                                                                    (float*)workspace, dxyz_add,
+                                                                                    dshift_add);
   INSTAG_CHECK_LAUNCH();
   triplane_reduce_kernel<<<div_up<uint32_t>(3 * total_params, 32), 256, 0, s>>>((const float*)workspace, blocks,
                                                                               total_params, dtable_xy, dtable_yz,

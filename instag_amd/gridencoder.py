@@ -154,10 +154,15 @@ class GridEncoder(nn.Module):
 class _tri_plane_encode(Function):
     """cat(enc_xy(xy), enc_yz(yz), enc_xz(xz)) of three identically configured 2-D, C=1 encoders in one kernel
     (csrc/grid.hip: triplane_*).  Equivalent to scene/motion_net.py:244-258 of the reference.  Optional ``shift``
-    [N, >=3]: the encoders are evaluated at xyz + shift_scale * shift[:, :3]."""
+    [N, >=3]: the encoders are evaluated at xyz + shift_scale * shift[:, :3].
+
+    ``passthrough``: also return ``xyz`` (and ``shift``) themselves.  A caller whose position has further consumers
+    hands THOSE the returned tensors: their gradients then arrive here and are summed into d/dxyz (d/dshift) by the
+    backward kernel, instead of by one autograd add launch per extra consumer behind it (C3: four launches, each with a
+    cross-queue wait, on the tail of the step)."""
 
     @staticmethod
-    def forward(ctx, xyz, emb_xy, emb_yz, emb_xz, offsets, S, H, bound, shift, shift_scale):
+    def forward(ctx, xyz, emb_xy, emb_yz, emb_xz, offsets, S, H, bound, shift, shift_scale, passthrough=False):
         xyz = xyz.contiguous().float()
         tabs = [e.contiguous().float() for e in (emb_xy, emb_yz, emb_xz)]
         _check_inputs(xyz=xyz, offsets=offsets, emb_xy=tabs[0], emb_yz=tabs[1], emb_xz=tabs[2])
@@ -173,10 +178,12 @@ class _tri_plane_encode(Function):
               "triplane_forward")
         ctx.save_for_backward(xyz, tabs[0], tabs[1], tabs[2], offsets, *([shift] if shift is not None else []))
         ctx.meta = (N, L, S, H, float(bound), T, float(shift_scale))
+        if passthrough:
+            return (out, xyz, shift) if shift is not None else (out, xyz)
         return out
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, grad, g_xyz=None, g_shift=None):
         saved = ctx.saved_tensors
         xyz, t0, t1, t2, offsets = saved[:5]
         shift = saved[5] if len(saved) > 5 else None
@@ -186,20 +193,24 @@ class _tri_plane_encode(Function):
         want_shift = shift is not None and ctx.needs_input_grad[8]
         dxyz = torch.empty_like(xyz) if (ctx.needs_input_grad[0] or want_shift) else None
         dshift = torch.empty_like(shift) if want_shift else None
+        g_xyz = g_xyz.contiguous().float() if (g_xyz is not None and dxyz is not None) else None
+        g_shift = g_shift.contiguous().float() if (g_shift is not None and dshift is not None) else None
         dt = torch.empty(3, T, 1, device=xyz.device, dtype=torch.float32)
         ws_bytes = L_.instag_triplane_backward_workspace_bytes(N, T)
         ws = torch.empty(max(1, ws_bytes // 4), device=xyz.device, dtype=torch.float32)
         check(L_.instag_triplane_backward(ptr(grad), ptr(xyz), ptr(t0), ptr(t1), ptr(t2), ptr(offsets),
                                           ptr(dxyz), ptr(dt[0]), ptr(dt[1]), ptr(dt[2]), ptr(ws), ws_bytes,
                                           ptr(shift), 0 if shift is None else shift.shape[1], shift_scale, ptr(dshift),
-                                          N, L, S, H, bound, T, _lib.current_stream()), "triplane_backward")
+                                          N, L, S, H, bound, T, ptr(g_xyz), ptr(g_shift), _lib.current_stream()),
+              "triplane_backward")
         if shift is None:
             # a field's encoder backward is the last kernel of that field: the weight gradients its MLPs queued
             # (instag_amd/deferred.py) start on the side stream beside it instead of after it.  (Not for the field
             # evaluated at a shifted position: another field's backward chain follows it, see render_motion.)
             from . import deferred
             deferred.flush_async(xyz.device)
-        return (dxyz if ctx.needs_input_grad[0] else None), dt[0], dt[1], dt[2], None, None, None, None, dshift, None
+        return ((dxyz if ctx.needs_input_grad[0] else None), dt[0], dt[1], dt[2], None, None, None, None, dshift, None,
+                None)
 
 
 def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
@@ -221,9 +232,39 @@ def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
     return True
 
 
+_PASS = None
+
+
+class passthrough:
+    """``with passthrough(carrier):`` -- a tri-plane encode inside the block also leaves its position (and shift) in
+    ``carrier["xyz"]`` (``carrier["shift"]``) as outputs of the encode (see _tri_plane_encode): the caller hands those to
+    the position's further consumers.  Values are the inputs'; only the route of their gradients changes."""
+
+    def __init__(self, carrier):
+        self.carrier = carrier
+
+    def __enter__(self):
+        global _PASS
+        self.prev, _PASS = _PASS, self.carrier
+        return self.carrier
+
+    def __exit__(self, *exc):
+        global _PASS
+        _PASS = self.prev
+        return False
+
+
 def tri_plane_encode(xyz, enc_xy, enc_yz, enc_xz, bound, shift=None, shift_scale=1.0):
     """xyz [N,3] (+ shift_scale * shift[:, :3]) -> [N, 3*L]; the three encoders must satisfy tri_plane_supported()."""
     e0 = enc_xy
-    return _tri_plane_encode.apply(xyz, enc_xy.embeddings, enc_yz.embeddings, enc_xz.embeddings, e0.offsets,
-                                   float(np.log2(e0.per_level_scale)), int(e0.base_resolution), bound, shift,
-                                   shift_scale)
+    args = (xyz, enc_xy.embeddings, enc_yz.embeddings, enc_xz.embeddings, e0.offsets,
+            float(np.log2(e0.per_level_scale)), int(e0.base_resolution), bound, shift, shift_scale)
+    if _PASS is not None and torch.is_grad_enabled() and xyz.requires_grad \
+            and xyz.is_contiguous() and xyz.dtype == torch.float32 \
+            and (shift is None or (shift.is_contiguous() and shift.dtype == torch.float32)):
+        res = _tri_plane_encode.apply(*args, True)
+        _PASS["xyz"] = res[1]
+        if shift is not None:
+            _PASS["shift"] = res[2]
+        return res[0]
+    return _tri_plane_encode.apply(*args)

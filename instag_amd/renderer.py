@@ -94,9 +94,19 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         if personalized and hasattr(pc.neural_motion_grid, "start_audio"):
             # (with align only, the personalised field's deformation head is never read: motion_net.py)
             pc.neural_motion_grid.start_audio(audio_feat, 2, exp_feat)
+    # The Gaussians' positions feed three operators (personalised field, universal field, deformation): on the device
+    # each encode hands the position on as one of its outputs, so the three gradients are summed inside the encoders'
+    # backward kernels instead of by autograd add launches on the tail of the step (gridencoder.passthrough)
+    from . import gridencoder as _ge
+    carrier = {}
+    xyz_route = pc.get_xyz
     if personalized or align:
-        p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat, exp_feat)
+        with _ge.passthrough(carrier):
+            p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat, exp_feat)
+        xyz_route = carrier.pop("xyz", xyz_route)
+        xyz = xyz_route
     x_shift = None
+    p_route = None
     if align:
         p_raw = p_motion_preds.get("_p")
         if p_raw is not None and xyz.is_cuda and isinstance(motion_net, _MotionNetwork):
@@ -109,10 +119,14 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
                 p_raw.register_hook(lambda g, dev=dev: deferred.flush_async(dev))
         else:
             xyz = xyz + p_motion_preds["p_xyz"]
-    if x_shift is not None:
-        motion_preds = motion_net(xyz, audio_feat, exp_feat, x_shift=x_shift)
-    else:
-        motion_preds = motion_net(xyz, audio_feat, exp_feat)
+    with _ge.passthrough(carrier):
+        if x_shift is not None:
+            motion_preds = motion_net(xyz, audio_feat, exp_feat, x_shift=x_shift)
+        else:
+            motion_preds = motion_net(xyz, audio_feat, exp_feat)
+    if x_shift is not None or not align:
+        xyz_route = carrier.pop("xyz", xyz_route)     # (align without the fused shift encodes xyz + p_xyz, not xyz)
+    p_route = carrier.pop("shift", None)
     motion_reg = None
 
     fused = (align and not personalized and not detach_motion and pc.get_xyz.is_cuda
@@ -121,8 +135,8 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     if fused:
         # deltas + softplus / normalize / sigmoid in one HIP kernel per pass (instag_amd/glue.py)
         from .glue import deform_activate
-        outs_d = deform_activate(pc.get_xyz, pc._scaling, pc._rotation, pc._opacity, motion_preds["_h"],
-                                 p_motion_preds["_p"], motion_reg_weight)
+        outs_d = deform_activate(xyz_route, pc._scaling, pc._rotation, pc._opacity, motion_preds["_h"],
+                                 p_route if p_route is not None else p_motion_preds["_p"], motion_reg_weight)
         means3D, scales, rotations, opacity = outs_d[:4]
         motion_reg = outs_d[4] if motion_reg_weight is not None else None
         # The reference scales the universal field's displacement IN PLACE (d_xyz *= p_scale, :217): the dictionary it
@@ -156,7 +170,7 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
                     cache["d_scale"], cache["d_rot"] = d_scale.detach(), d_rot.detach()
         if detach_motion:
             d_xyz, d_scale, d_rot = d_xyz.detach(), d_scale.detach(), d_rot.detach()
-        means3D = pc.get_xyz + d_xyz
+        means3D = xyz_route + d_xyz
         opacity = pc.get_opacity
         scales = pc.scaling_activation(pc._scaling + d_scale)
         rotations = pc.rotation_activation(pc._rotation + d_rot)
