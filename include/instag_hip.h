@@ -268,6 +268,18 @@ int instag_mlp_backward_add(const float* dy, const float* a1, const float* a2, c
                             const float* w2, const float* w3, float* dz1, float* dz2, float* dx,
                             const float* dx_add, int32_t N, int32_t K0, int32_t H, int32_t O, int32_t NL,
                             instag_stream_t stream);
+/* Two 2-layer MLPs over the SAME input x in one launch: (MLP_a(x), MLP_b(x)) -- the universal field's aud_ch_att_net and
+ * eye_att_net both read the tri-plane features (scene/motion_net.py:281-290).  backward: dx = W_a1^T dz1a + W_b1^T dz1b
+ * (+ dx_add, which may alias dx).  instag_mlp2_supported: 1 when the shape pair has a kernel (36 -> 32 -> 32 with
+ * 36 -> 16 -> 6, in groups of eight features); otherwise launch the heads one by one. */
+int instag_mlp2_supported(int32_t K0, int32_t HA, int32_t OA, int32_t HB, int32_t OB);
+int instag_mlp2_forward(const float* x, const float* wa1, const float* wa2, const float* wb1, const float* wb2,
+                        float* ya, float* yb, float* a1a, float* a1b, int32_t N, int32_t K0, int32_t HA, int32_t OA,
+                        int32_t HB, int32_t OB, instag_stream_t stream);
+int instag_mlp2_backward(const float* dya, const float* dyb, const float* a1a, const float* a1b, const float* wa1,
+                         const float* wa2, const float* wb1, const float* wb2, float* dz1a, float* dz1b, float* dx,
+                         const float* dx_add, int32_t N, int32_t K0, int32_t HA, int32_t OA, int32_t HB, int32_t OB,
+                         instag_stream_t stream);
 size_t instag_linear_weight_grad_workspace_bytes(int32_t N, int32_t O, int32_t K);
 int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void* workspace,
                               size_t workspace_bytes, int32_t N, int32_t O, int32_t K,

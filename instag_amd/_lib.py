@@ -126,6 +126,9 @@ _PROTOS = {
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward_add": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_linear_weight_grad_batched": (C.c_int, [vp, i32, vp, sz, vp]),
+    "instag_mlp2_supported": (C.c_int, [i32] * 5),
+    "instag_mlp2_forward": (C.c_int, [vp] * 9 + [i32] * 6 + [vp]),
+    "instag_mlp2_backward": (C.c_int, [vp] * 12 + [i32] * 6 + [vp]),
     "instag_linear_weight_grad_workspace_bytes": (sz, [i32, i32, i32]),
     "instag_linear_weight_grad": (C.c_int, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "instag_motion_glue_forward": (C.c_int, [vp] * 7 + [i32] * 4 + [vp]),

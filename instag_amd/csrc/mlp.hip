@@ -278,6 +278,135 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
   }
 }
 
+
+// ---- two 2-layer MLPs over the SAME input in one launch ------------------------------------------------------------
+// aud_ch_att_net and eye_att_net of the universal field both read the tri-plane features (scene/motion_net.py:281-290).
+// As two launches each pays its own weight staging, tile-load latency and launch tail (19 + 12 us forward, 28 + 17 us
+// backward at 100k rows, for 0.6 GFLOP); here a wave loads its 32-row tile once and runs both heads on it, and the
+// backward adds the two input gradients (and the gradient of the input's other consumers) in registers.
+struct Mlp2Dims { int N, K0, HA, OA, HB, OB; };
+
+template <int KQ0, int HQA, int HQB>
+size_t mlp2_lds_bytes() {
+  constexpr int KP0 = (KQ0 + 3) / 4 * 32, HPA = (HQA + 3) / 4 * 32, HPB = (HQB + 3) / 4 * 32;
+  return sizeof(float) * (HPA * (KP0 + 1) + 32 * (HPA + 1) + HPB * (KP0 + 1) + 32 * (HPB + 1));
+}
+
+template <int KQ0, int HQA, int OQA, int HQB, int OQB>
+__global__ void __launch_bounds__(MLP_BLOCK)
+mlp2_forward_kernel(Mlp2Dims d, const float* __restrict__ X, const float* __restrict__ WA1,
+                    const float* __restrict__ WA2, const float* __restrict__ WB1, const float* __restrict__ WB2,
+                    float* __restrict__ YA, float* __restrict__ YB, float* __restrict__ A1A, float* __restrict__ A1B) {
+  extern __shared__ __align__(16) float s_w[];
+  constexpr int KB0 = (KQ0 + 3) / 4, HBA = (HQA + 3) / 4, HBB = (HQB + 3) / 4;
+  constexpr int KP0 = KB0 * 32, HPA = HBA * 32, HPB = HBB * 32;
+  float* wa1 = s_w;
+  float* wa2 = wa1 + HPA * (KP0 + 1);
+  float* wb1 = wa2 + 32 * (HPA + 1);
+  float* wb2 = wb1 + HPB * (KP0 + 1);
+  stage_weights<HPA, KB0>(wa1, WA1, d.HA, d.K0);
+  stage_weights<32, HBA>(wa2, WA2, d.OA, d.HA);
+  stage_weights<HPB, KB0>(wb1, WB1, d.HB, d.K0);
+  stage_weights<32, HBB>(wb2, WB2, d.OB, d.HB);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int ntiles = (d.N + 31) / 32;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const size_t row = (size_t)tile * 32 + l31;
+    const bool valid = row < (size_t)d.N;
+    f32x16 in0[KB0];
+#pragma unroll
+    for (int b = 0; b < KB0; ++b) load_block(X, row, valid, d.K0, b, h, in0[b]);
+    {
+      f32x16 h1[HBA], out[1];
+      layer_forward<KQ0, KB0, HBA>(wa1, in0, h1, l31, h);
+      relu_blocks<HBA>(h1);
+#pragma unroll
+      for (int b = 0; b < HBA; ++b) store_block(A1A, row, valid, d.HA, b, h, h1[b]);
+      layer_forward<HQA, HBA, 1>(wa2, h1, out, l31, h);
+      store_block(YA, row, valid, d.OA, 0, h, out[0]);
+    }
+    {
+      f32x16 h1[HBB], out[1];
+      layer_forward<KQ0, KB0, HBB>(wb1, in0, h1, l31, h);
+      relu_blocks<HBB>(h1);
+#pragma unroll
+      for (int b = 0; b < HBB; ++b) store_block(A1B, row, valid, d.HB, b, h, h1[b]);
+      layer_forward<HQB, HBB, 1>(wb2, h1, out, l31, h);
+      store_block(YB, row, valid, d.OB, 0, h, out[0]);
+    }
+  }
+}
+
+template <int KQ0, int HQA, int OQA, int HQB, int OQB>
+__global__ void __launch_bounds__(MLP_BLOCK)
+mlp2_backward_kernel(Mlp2Dims d, const float* __restrict__ dYA, const float* __restrict__ dYB,
+                     const float* __restrict__ A1A, const float* __restrict__ A1B, const float* __restrict__ WA1,
+                     const float* __restrict__ WA2, const float* __restrict__ WB1, const float* __restrict__ WB2,
+                     float* __restrict__ dZ1A, float* __restrict__ dZ1B, float* dX,
+                     const float* dXadd /* [N,K0] added to the input gradient, may alias dX, or null */) {
+  extern __shared__ __align__(16) float s_w[];
+  constexpr int KB0 = (KQ0 + 3) / 4, HBA = (HQA + 3) / 4, HBB = (HQB + 3) / 4;
+  constexpr int KP0 = KB0 * 32, HPA = HBA * 32, HPB = HBB * 32;
+  float* wa1 = s_w;
+  float* wa2 = wa1 + HPA * (KP0 + 1);
+  float* wb1 = wa2 + 32 * (HPA + 1);
+  float* wb2 = wb1 + HPB * (KP0 + 1);
+  if (dX) { stage_weights<HPA, KB0>(wa1, WA1, d.HA, d.K0); stage_weights<HPB, KB0>(wb1, WB1, d.HB, d.K0); }
+  stage_weights<32, HBA>(wa2, WA2, d.OA, d.HA);
+  stage_weights<32, HBB>(wb2, WB2, d.OB, d.HB);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  const int ntiles = (d.N + 31) / 32;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const size_t row = (size_t)tile * 32 + l31;
+    const bool valid = row < (size_t)d.N;
+    f32x16 gx[KB0];
+#pragma unroll
+    for (int b = 0; b < KB0; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) gx[b][i] = 0.f;
+    {
+      f32x16 dy[1], g1[HBA], act[HBA];
+      load_block(dYA, row, valid, d.OA, 0, h, dy[0]);
+      layer_backward<OQA, 1, HBA>(wa2, dy, g1, l31, h);
+#pragma unroll
+      for (int b = 0; b < HBA; ++b) load_block(A1A, row, valid, d.HA, b, h, act[b]);
+      mask_blocks<HBA>(g1, act);
+#pragma unroll
+      for (int b = 0; b < HBA; ++b) store_block(dZ1A, row, valid, d.HA, b, h, g1[b]);
+      if (dX) layer_backward<HQA, HBA, KB0>(wa1, g1, gx, l31, h);
+    }
+    {
+      f32x16 dy[1], g1[HBB], act[HBB], gb[KB0];
+      load_block(dYB, row, valid, d.OB, 0, h, dy[0]);
+      layer_backward<OQB, 1, HBB>(wb2, dy, g1, l31, h);
+#pragma unroll
+      for (int b = 0; b < HBB; ++b) load_block(A1B, row, valid, d.HB, b, h, act[b]);
+      mask_blocks<HBB>(g1, act);
+#pragma unroll
+      for (int b = 0; b < HBB; ++b) store_block(dZ1B, row, valid, d.HB, b, h, g1[b]);
+      if (dX) {
+        layer_backward<HQB, HBB, KB0>(wb1, g1, gb, l31, h);
+#pragma unroll
+        for (int b = 0; b < KB0; ++b) gx[b] += gb[b];
+      }
+    }
+    if (dX) {
+      if (dXadd) {
+#pragma unroll
+        for (int b = 0; b < KB0; ++b) {
+          f32x16 prev;
+          load_block(dXadd, row, valid, d.K0, b, h, prev);
+          gx[b] += prev;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < KB0; ++b) store_block(dX, row, valid, d.K0, b, h, gx[b]);
+    }
+  }
+}
+
 // ---- dW[o][k] = sum_rows dZ[row][o] * In[row][k] ---------------------------------------------------
 template <int OB, int KB>
 __device__ __forceinline__ void weight_grad_body(const float* __restrict__ dZ, const float* __restrict__ In, int N, int O,
@@ -414,9 +543,13 @@ weight_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int cou
 
 inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256)); }
 
-// Two workgroups per CU, each staging the weights once and walking a strided list of 32-row tiles.
+// Up to three workgroups per CU (what the largest network's weights in LDS allow), each staging the weights once and
+// walking a strided list of 32-row tiles.  100k rows are 3125 tiles: with 512 workgroups (2048 waves) half of the waves
+// walk two tiles one after the other, each with its own exposed load latency; with 768 nearly every wave has one tile
+// and a SIMD overlaps the loads of three of them (sigma_net forward 45 -> see DESIGN.md).
 inline int mlp_blocks(int ntiles) {
-  return std::max(1, std::min(512, (ntiles + 3) / 4));
+  static const int cap = getenv("INSTAG_MLP_BLOCKS") ? atoi(getenv("INSTAG_MLP_BLOCKS")) : 768;
+  return std::max(1, std::min(cap, (ntiles + 3) / 4));
 }
 
 template <int KB0, int HB, int NL>
@@ -536,6 +669,46 @@ int instag_mlp_backward(const float* dy, const float* a1, const float* a2, const
                         const float* w3, float* dz1, float* dz2, float* dx, int32_t N, int32_t K0, int32_t H,
                         int32_t O, int32_t NL, instag_stream_t stream) {
   return instag_mlp_backward_add(dy, a1, a2, w1, w2, w3, dz1, dz2, dx, nullptr, N, K0, H, O, NL, stream);
+}
+
+/* Two 2-layer MLPs over the same input in one launch (see mlp2_forward_kernel).  Shapes: the universal field's
+ * attention heads (36 -> 32 -> 32 and 36 -> 16 -> 6 in groups of eight features); instag_mlp2_supported says whether a
+ * shape pair has a kernel -- otherwise the caller launches the heads one by one (instag_mlp_forward / _backward_add). */
+int instag_mlp2_supported(int32_t K0, int32_t HA, int32_t OA, int32_t HB, int32_t OB) {
+  const int kq = (K0 + 7) / 8, ha = (HA + 7) / 8, oa = (OA + 7) / 8, hb = (HB + 7) / 8, ob = (OB + 7) / 8;
+  return kq == 5 && ha == 4 && oa == 4 && hb == 2 && ob == 1;
+}
+
+int instag_mlp2_forward(const float* x, const float* wa1, const float* wa2, const float* wb1, const float* wb2,
+                        float* ya, float* yb, float* a1a, float* a1b, int32_t N, int32_t K0, int32_t HA, int32_t OA,
+                        int32_t HB, int32_t OB, instag_stream_t stream) {
+  INSTAG_REQUIRE(instag_mlp2_supported(K0, HA, OA, HB, OB), "mlp2_forward: unsupported shape pair");
+  INSTAG_REQUIRE(x && wa1 && wa2 && wb1 && wb2 && ya && yb && a1a && a1b, "mlp2_forward: NULL tensor");
+  if (N <= 0) return INSTAG_OK;
+  const Mlp2Dims d{N, K0, HA, OA, HB, OB};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_MLP_FWD, s);
+  mlp2_forward_kernel<5, 4, 4, 2, 1><<<mlp_blocks((N + 31) / 32), MLP_BLOCK, mlp2_lds_bytes<5, 4, 2>(), s>>>(
+      d, x, wa1, wa2, wb1, wb2, ya, yb, a1a, a1b);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_mlp2_backward(const float* dya, const float* dyb, const float* a1a, const float* a1b, const float* wa1,
+                         const float* wa2, const float* wb1, const float* wb2, float* dz1a, float* dz1b, float* dx,
+                         const float* dx_add, int32_t N, int32_t K0, int32_t HA, int32_t OA, int32_t HB, int32_t OB,
+                         instag_stream_t stream) {
+  INSTAG_REQUIRE(instag_mlp2_supported(K0, HA, OA, HB, OB), "mlp2_backward: unsupported shape pair");
+  INSTAG_REQUIRE(dya && dyb && a1a && a1b && wa1 && wa2 && wb1 && wb2 && dz1a && dz1b, "mlp2_backward: NULL tensor");
+  INSTAG_REQUIRE(dx_add == nullptr || dx != nullptr, "mlp2_backward: dx_add needs dx");
+  if (N <= 0) return INSTAG_OK;
+  const Mlp2Dims d{N, K0, HA, OA, HB, OB};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope p(K_MLP_BWD, s);
+  mlp2_backward_kernel<5, 4, 4, 2, 1><<<mlp_blocks((N + 31) / 32), MLP_BLOCK, mlp2_lds_bytes<5, 4, 2>(), s>>>(
+      d, dya, dyb, a1a, a1b, wa1, wa2, wb1, wb2, dz1a, dz1b, dx, dx_add);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
 }
 
 size_t instag_linear_weight_grad_workspace_bytes(int32_t N, int32_t O, int32_t K) {

@@ -73,8 +73,10 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   constexpr int SUBS = BLOCK / SEG_LEN;
   const int slot0 = start / SEG_LEN + tile;
   int walked = 0;
+  bool wave_done = false;
 
   f32x2 pix = inside ? f32x2{(float)pxi, (float)pyi} : f32x2{FAR_PIXEL, FAR_PIXEL};
+  wave_done = __builtin_amdgcn_ballot_w64(inside) == 0;
   float T = 1.0f;
   uint32_t last_contributor = 0;
   // channel accumulators as float pairs: the eight FMAs per Gaussian become four v_pk_fma_f32 (the record keeps
@@ -116,7 +118,7 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
     const int groups = (min(BLOCK, toDo) + 3) >> 2;
     for (int h = 0; h < SUBS && h * (SEG_LEN / 4) < groups; ++h) {
       const int g_end = min(groups, (h + 1) * (SEG_LEN / 4));
-      for (int g = h * (SEG_LEN / 4); g < g_end; ++g) {
+      for (int g = h * (SEG_LEN / 4); g < g_end && !wave_done; ++g) {
         float al[4], w[4];
         bool hit[4];
 #pragma unroll
@@ -158,6 +160,9 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
           }
           t4 = Tc;
           if (dead) pix = f32x2{FAR_PIXEL, FAR_PIXEL};
+          // a wave whose 64 pixels have all finished leaves the walk: what it would still read from LDS and issue
+          // is taken from the tiles that share the CU with this one
+          wave_done = __builtin_amdgcn_ballot_w64(pix.x < 0.5f * FAR_PIXEL) == 0;
         }
         T = t4;
         last_contributor = code ? (uint32_t)(i * BLOCK + 4 * g) + code : last_contributor;

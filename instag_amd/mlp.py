@@ -101,6 +101,9 @@ class _FusedMLP(torch.autograd.Function):
 EAGER_FLUSH_ROWS = 0
 
 
+FUSE_SHARED_HEADS = True      # False: one launch per head (tests compare the two)
+
+
 class _SharedInputMLPs(torch.autograd.Function):
     """Two 2-layer MLPs over the SAME input x plus x itself as a third output (for the input's other consumers):
     (MLP_a(x), MLP_b(x), x).  The reference runs aud_ch_att_net(enc_x), eye_att_net(enc_x) and then concatenates
@@ -113,6 +116,24 @@ class _SharedInputMLPs(torch.autograd.Function):
         x = x.contiguous().float()
         N, K0 = x.shape
         outs, saved, dims = [], [x], []
+        if FUSE_SHARED_HEADS and L.instag_mlp2_supported(K0, wa1.shape[0], wa2.shape[0], wb1.shape[0], wb2.shape[0]):
+            # both heads in one launch: the tile of x is loaded once (csrc/mlp.hip: mlp2_forward_kernel)
+            ws = [w.contiguous().float() for w in (wa1, wa2, wb1, wb2)]
+            (HA, OA), (HB, OB) = (ws[0].shape[0], ws[1].shape[0]), (ws[2].shape[0], ws[3].shape[0])
+            ya = torch.empty(N, OA, dtype=torch.float32, device=x.device)
+            yb = torch.empty(N, OB, dtype=torch.float32, device=x.device)
+            a1a = torch.empty(N, HA, dtype=torch.float32, device=x.device)
+            a1b = torch.empty(N, HB, dtype=torch.float32, device=x.device)
+            check(L.instag_mlp2_forward(ptr(x), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(ws[3]), ptr(ya), ptr(yb),
+                                        ptr(a1a), ptr(a1b), N, K0, HA, OA, HB, OB, _lib.current_stream()),
+                  "mlp2_forward")
+            STATS["fwd_flops"] += 2 * N * (K0 * HA + HA * OA + K0 * HB + HB * OB)
+            ctx.save_for_backward(x, ws[0], ws[1], a1a, ws[2], ws[3], a1b)
+            ctx.weights = (wa1, wa2, wb1, wb2)
+            ctx.dims = (N, K0, [(HA, OA), (HB, OB)])
+            ctx.fused = True
+            return ya, yb, x.view_as(x)
+        ctx.fused = False
         for w1, w2 in ((wa1, wa2), (wb1, wb2)):
             w1c, w2c = w1.contiguous().float(), w2.contiguous().float()
             H, O = w1c.shape[0], w2c.shape[0]
@@ -141,7 +162,20 @@ class _SharedInputMLPs(torch.autograd.Function):
         dx = torch.empty(N, K0, dtype=torch.float32, device=dev) if want_dx else None
         add = None if dx_other is None else dx_other.contiguous().float()
         jobs = []
-        for k, dy in enumerate((dya, dyb)):
+        fused = ctx.fused and dya is not None and dyb is not None
+        if fused:
+            wa1, wa2, a1a, wb1, wb2, a1b = ctx.saved_tensors[1:7]
+            (HA, OA), (HB, OB) = dims
+            dya, dyb = dya.contiguous().float(), dyb.contiguous().float()
+            dz1a = torch.empty(N, HA, dtype=torch.float32, device=dev)
+            dz1b = torch.empty(N, HB, dtype=torch.float32, device=dev)
+            check(L.instag_mlp2_backward(ptr(dya), ptr(dyb), ptr(a1a), ptr(a1b), ptr(wa1), ptr(wa2), ptr(wb1),
+                                         ptr(wb2), ptr(dz1a), ptr(dz1b), ptr(dx), ptr(add) if want_dx else None,
+                                         N, K0, HA, OA, HB, OB, stream), "mlp2_backward")
+            STATS["bwd_flops"] += 2 * N * (HA * OA + HB * OB + (K0 * (HA + HB) if want_dx else 0))
+            add = dx if want_dx else add
+            jobs = [(dz1a, x, 1, (HA, K0)), (dya, a1a, 2, (OA, HA)), (dz1b, x, 3, (HB, K0)), (dyb, a1b, 4, (OB, HB))]
+        for k, dy in enumerate(() if fused else (dya, dyb)):
             if dy is None:
                 continue
             w1, w2, a1 = ctx.saved_tensors[1 + 3 * k:4 + 3 * k]
