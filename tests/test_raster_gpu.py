@@ -592,3 +592,69 @@ def test_full_c3_train_step_100k_512():
     for a_, b_ in zip(losses["eager"], losses["graph"]):
         assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (losses["eager"], losses["graph"])
     assert float((params["eager"] - params["graph"]).abs().max()) <= 1e-5
+
+
+def test_long_walks_cross_many_segments():
+    """Dense, faint scene on a small image: the tiles' lists are thousands of entries long and rays walk far beyond one
+    128-entry segment, so the backward pass starts most of its workgroups from the per-segment state the forward pass
+    left behind (csrc/raster_blend.hip: seg_state) -- every gradient against the fp64 oracle, with the same bars as
+    test_backward_gradients."""
+    from instag_amd import diff_gauss
+    from oracle import rasterize_ref as R
+    n, size = 12000, 96
+    a, settings = make_scene(n, size, sh_degree=1, seed=11)
+    a["opacities"] = a["opacities"] * 0.12            # faint: a ray needs hundreds of Gaussians to saturate
+    s = oracle_settings(settings)
+    inp_o = {k: leaf(v) for k, v in a.items()}
+    m2 = torch.zeros(n, 3, requires_grad=True)
+    outs_o = R.rasterize(inp_o["means3D"], m2, inp_o["shs"], None, inp_o["opacities"], inp_o["scales"],
+                         inp_o["rotations"], None, inp_o["extra"], s, precision="fp64")
+    inp_o["means2D"] = m2
+    diff_gauss.KEEP_LAST_STATE = True
+    try:
+        outs_h, inp_h = run_hip(a, settings)
+        walked = diff_gauss.debug_export(diff_gauss.LAST_STATS.pop("state"))["n_contrib"]
+    finally:
+        diff_gauss.KEEP_LAST_STATE = False
+    assert int(walked.max()) > 4 * 128, f"scene too shallow for this test: longest walk {int(walked.max())}"
+    g = torch.Generator().manual_seed(2)
+    ws = [torch.randn(o.shape, generator=g) if o.is_floating_point() else None for o in outs_o]
+    sum((o * w.double()).sum() for o, w in zip(outs_o, ws) if w is not None).backward()
+    sum((o * w.cuda()).sum() for o, w in zip(outs_h, ws) if w is not None).backward()
+    for name, o, h in zip(("image", "depth", "normal", "alpha", "radii", "extra"), outs_o, outs_h):
+        if o.is_floating_point():
+            assert (h.detach().cpu().double() - o.detach()).abs().max().item() <= 1e-5, name
+    for k in ("means3D", "means2D", "opacities", "extra", "shs", "scales", "rotations"):
+        _grad_check(inp_o[k].grad, inp_h[k].grad, k, "long-walks")
+
+
+def test_second_backward_and_masked_gradient_reuse_the_state():
+    """Backward twice over ONE forward state (retain_graph) with different upstream gradients, the second one zero on
+    most of the image: the gradient rows of the first pass must not leak into the second (the reducing kernel clears the
+    row flags it consumes; tiles without gradient write no rows).  Reference = the same backward on a fresh forward."""
+    a, settings = make_scene(6000, 160, sh_degree=1, seed=4)
+    g = torch.Generator().manual_seed(9)
+    w1 = torch.randn(3, 160, 160, generator=g).cuda()
+    w2 = torch.zeros(3, 160, 160)
+    w2[:, 40:72, 56:120] = torch.randn(3, 32, 64, generator=g)          # a few tiles only
+    w2 = w2.cuda()
+
+    def grads(inp):
+        out = {k: v.grad.clone() for k, v in inp.items() if v is not None and v.grad is not None}
+        for v in inp.values():
+            if v is not None:
+                v.grad = None
+        return out
+
+    outs, inp = run_hip(a, settings)
+    (outs[0] * w1).sum().backward(retain_graph=True)
+    first = grads(inp)
+    (outs[0] * w2).sum().backward()
+    second = grads(inp)
+    outs_f, inp_f = run_hip(a, settings)
+    (outs_f[0] * w2).sum().backward()
+    fresh = grads(inp_f)
+    assert first.keys() == second.keys() == fresh.keys()
+    for k in fresh:
+        assert torch.equal(second[k], fresh[k]), k
+    assert not torch.equal(first["means3D"], second["means3D"])
