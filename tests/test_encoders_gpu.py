@@ -321,3 +321,81 @@ def test_grid_renderer_constructs_runs_and_stays_out_of_adam():
     with_state = [grp["name"] for grp in gm.optimizer.param_groups
                   if any("exp_avg" in gm.optimizer.state.get(p, {}) for p in grp["params"])]
     assert with_state == ["xyz", "f_dc", "f_rest", "identity", "opacity", "scaling", "rotation"]
+
+
+def test_tri_plane_kernels_against_the_numpy_oracle():
+    """The fused tri-plane forward / backward kernels (the ones on the train step's path) directly against
+    oracle/grid_ref.py, plane by plane: features, table gradients and d/dxyz -- not via the per-plane HIP encoder."""
+    from instag_amd.gridencoder import GridEncoder, tri_plane_encode
+    from oracle import grid_ref
+    from oracle.grid_ref import GridEncoderRef
+    bound, n = 0.15, 6000
+    refs = [GridEncoderRef(seed=s, **FACE) for s in (1, 2, 3)]
+    encs = [GridEncoder(**FACE).cuda() for _ in range(3)]
+    rng = np.random.default_rng(7)
+    for r, e in zip(refs, encs):
+        r.embeddings = rng.standard_normal(r.embeddings.shape).astype(np.float32)
+        with torch.no_grad():
+            e.embeddings.copy_(torch.from_numpy(r.embeddings))
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(n, 3, generator=g) * 0.34 - 0.17               # some points outside the bound -> zeros
+    w = torch.randn(n, 36, generator=g)
+    xh = x.cuda().requires_grad_(True)
+    out = tri_plane_encode(xh, *encs, bound)
+    (out * w.cuda()).sum().backward()
+    cols = [(0, 1), (1, 2), (0, 2)]                               # xy, yz, xz (scene/motion_net.py:244-258)
+    L = FACE["num_levels"]
+    gi_total = np.zeros((n, 3), dtype=np.float64)
+    finest = FACE["desired_resolution"]
+    for p, (r, e, c) in enumerate(zip(refs, encs, cols)):
+        xp = x[:, list(c)].numpy()
+        out_ref, dy_dx = r.forward(xp, bound=bound, calc_grad_inputs=True)
+        got = out[:, p * L:(p + 1) * L].detach().cpu().numpy()
+        assert np.abs(got - out_ref).max() <= 1.5e-6 * finest, p
+        grad_lbc = w[:, p * L:(p + 1) * L].reshape(n, L, 1).permute(1, 0, 2).contiguous().numpy()
+        x01 = (xp.astype(np.float32) + np.float32(bound)) / np.float32(2 * bound)
+        ge, gi = grid_ref.grid_encode_backward(grad_lbc, x01, r.embeddings, r.offsets, np.log2(r.per_level_scale),
+                                               r.base_resolution, dy_dx, r.gridtype_id, r.align_corners, r.interp_id)
+        ge_h = e.embeddings.grad.cpu().numpy()
+        assert np.abs(ge_h - ge).max() <= 2e-4 * max(1.0, np.abs(ge).max()), p
+        gi_total[:, list(c)] += gi / (2 * bound)                  # d/dx of (x + bound) / (2 bound)
+    rel = np.abs(xh.grad.cpu().numpy() - gi_total) / max(1.0, np.abs(gi_total).max())
+    assert np.quantile(rel, 0.995) <= 2e-4 and (rel > 2e-4).mean() < 5e-3
+
+
+def test_tri_plane_passthrough_sums_the_other_consumers_gradients():
+    """gridencoder.passthrough: the position (and the shift) handed on by the encode carry their other consumers'
+    gradients back into the encoder's backward kernel (dxyz_add / dshift_add) -- same sums as autograd's own adds."""
+    from instag_amd import gridencoder as ge
+    from instag_amd.gridencoder import GridEncoder, tri_plane_encode
+    torch.manual_seed(1)
+    encs = [GridEncoder(**FACE).cuda() for _ in range(3)]
+    with torch.no_grad():
+        for e in encs:
+            e.embeddings.copy_(torch.randn_like(e.embeddings))
+    n = 4001
+    x0 = (torch.rand(n, 3) * 0.3 - 0.15).cuda()
+    p0 = torch.randn(n, 6).cuda()
+    w, wx, wp = torch.randn(n, 36).cuda(), torch.randn(n, 3).cuda(), torch.randn(n, 6).cuda()
+
+    def run(route):
+        x, p = x0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+        for e in encs:
+            e.embeddings.grad = None
+        if route:
+            carrier = {}
+            with ge.passthrough(carrier):
+                out = tri_plane_encode(x, *encs, 0.15, shift=p, shift_scale=1e-2)
+            xr, pr = carrier["xyz"], carrier["shift"]
+            assert xr.data_ptr() == x.data_ptr() and pr.data_ptr() == p.data_ptr()
+        else:
+            out = tri_plane_encode(x, *encs, 0.15, shift=p, shift_scale=1e-2)
+            xr, pr = x, p
+        ((out * w).sum() + (xr * wx).sum() + (pr * wp).sum()).backward()
+        return x.grad, p.grad, [e.embeddings.grad.clone() for e in encs]
+
+    (gx_a, gp_a, gt_a), (gx_b, gp_b, gt_b) = run(False), run(True)
+    assert float((gx_a - gx_b).abs().max()) <= 1e-6 * float(gx_a.abs().max())
+    assert float((gp_a - gp_b).abs().max()) <= 1e-6 * float(gp_a.abs().max())
+    for a, b in zip(gt_a, gt_b):
+        assert torch.equal(a, b)
