@@ -543,13 +543,10 @@ weight_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int cou
 
 inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256)); }
 
-// Up to three workgroups per CU (what the largest network's weights in LDS allow), each staging the weights once and
-// walking a strided list of 32-row tiles.  100k rows are 3125 tiles: with 512 workgroups (2048 waves) half of the waves
-// walk two tiles one after the other, each with its own exposed load latency; with 768 nearly every wave has one tile
-// and a SIMD overlaps the loads of three of them (sigma_net forward 45 -> see DESIGN.md).
+// Two workgroups per CU, each staging the weights once and walking a strided list of 32-row tiles.  (768 and 1024
+// workgroups -- one tile per wave at 100k rows -- measured the same or slower: sigma_net forward 44.9 / 44.6 / 47.8 us.)
 inline int mlp_blocks(int ntiles) {
-  static const int cap = getenv("INSTAG_MLP_BLOCKS") ? atoi(getenv("INSTAG_MLP_BLOCKS")) : 768;
-  return std::max(1, std::min(cap, (ntiles + 3) / 4));
+  return std::max(1, std::min(512, (ntiles + 3) / 4));
 }
 
 template <int KB0, int HB, int NL>
