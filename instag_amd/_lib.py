@@ -63,6 +63,11 @@ class graph_capture:
 
     def __init__(self, graph, **kw):
         import torch
+        if "stream" not in kw:
+            # capture on a high-priority stream: the side streams operators fork from it (weight gradients, auxiliary
+            # blend pass) keep the default priority, and the nodes of the step's critical chain win the arbitration
+            # where they share the chip with them (C3 step: 0.5-2.5 % faster, four interleaved runs on two boxes)
+            kw = dict(kw, stream=torch.cuda.Stream(priority=-1))
         self._ctx = torch.cuda.graph(graph, **kw)
 
     def __enter__(self):
