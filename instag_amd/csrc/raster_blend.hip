@@ -288,8 +288,13 @@ blend_backward_segment(const int tile, const int seg, const Camera& c, const int
   __shared__ __align__(16) float s_W[XONLY ? 4 : 4 * BB * WROW];   // [pixel quarter kk][gaussian][64 pixels + pad]
   __shared__ __align__(16) float s_T[4 * BB * WROW];
   __shared__ __align__(16) float s_X[AUXX ? 4 * BB * WROW : 4];
-  __shared__ float s_res[BB][NMAT][4][8];              // [gaussian][matrix][wave = 16 steps of every quarter][feature < 8]
-  int* s_max = reinterpret_cast<int*>(&s_res[0][0][0][0]);   // (used once, before the first batch)
+  // [gaussian][matrix][wave = 16 steps of every quarter][feature < 8], one float of padding per Gaussian: the row
+  // assembly reads one Gaussian per lane, and a stride of 64 or 96 floats put all sixteen lanes on one bank
+  // (SQ_LDS_BANK_CONFLICT was 18 % of the kernel's LDS cycles, profiles/r02_pmc_lds_c3.csv)
+  constexpr int RES_STRIDE = NMAT * 32 + 1;
+  __shared__ float s_res_flat[BB * RES_STRIDE];
+  auto s_res = [&](int g, int m, int w, int f) -> float& { return s_res_flat[g * RES_STRIDE + (m * 4 + w) * 8 + f]; };
+  int* s_max = reinterpret_cast<int*>(&s_res_flat[0]);   // (used once, before the first batch)
   // One SEGMENT (SEG_LEN list entries of one tile) per call, not a whole tile: the forward pass left the per-pixel
   // state after every segment (seg_state), so a segment's back-to-front walk starts from the state behind it instead
   // of waiting for the walk over everything behind it.  The kernel's duration used to be the longest tile's chain (C3:
@@ -496,9 +501,9 @@ blend_backward_segment(const int tile, const int seg, const Camera& c, const int
       if ((lane & 15) < 8) {              // (no product uses more than eight feature columns)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (!XONLY) s_res[4 * (lane >> 4) + r][MW][wave][lane & 15] = accW[r];
-          s_res[4 * (lane >> 4) + r][MT][wave][lane & 15] = accT[r];
-          if (AUXX) s_res[4 * (lane >> 4) + r][MX][wave][lane & 15] = accX[r];
+          if (!XONLY) s_res(4 * (lane >> 4) + r, MW, wave, lane & 15) = accW[r];
+          s_res(4 * (lane >> 4) + r, MT, wave, lane & 15) = accT[r];
+          if (AUXX) s_res(4 * (lane >> 4) + r, MX, wave, lane & 15) = accX[r];
         }
       }
     }
@@ -510,10 +515,10 @@ blend_backward_segment(const int tile, const int seg, const Camera& c, const int
       float Dw[NCH], Dt[6];
 #pragma unroll
       for (int k = 0; k < NCH; ++k)
-        Dw[k] = XONLY ? 0.f : (s_res[tid][MW][0][k] + s_res[tid][MW][1][k]) + (s_res[tid][MW][2][k] + s_res[tid][MW][3][k]);
+        Dw[k] = XONLY ? 0.f : (s_res(tid, MW, 0, k) + s_res(tid, MW, 1, k)) + (s_res(tid, MW, 2, k) + s_res(tid, MW, 3, k));
 #pragma unroll
       for (int k = 0; k < 6; ++k)
-        Dt[k] = (s_res[tid][MT][0][k] + s_res[tid][MT][1][k]) + (s_res[tid][MT][2][k] + s_res[tid][MT][3][k]);
+        Dt[k] = (s_res(tid, MT, 0, k) + s_res(tid, MT, 1, k)) + (s_res(tid, MT, 2, k) + s_res(tid, MT, 3, k));
       const float X = ra.x - tile_x0, Y = ra.y - tile_y0;
       const float A = con.x, B = con.y, Cc = con.z, op = rbo.y;
       const float S0 = Dt[0], Sx = Dt[1], Sy = Dt[2], Sxx = Dt[3], Sxy = Dt[4], Syy = Dt[5];
@@ -537,8 +542,8 @@ blend_backward_segment(const int tile, const int seg, const Camera& c, const int
           float Dx[3];
 #pragma unroll
           for (int k = 0; k < 3; ++k)
-            Dx[k] = (s_res[tid][NMAT - 1][0][k] + s_res[tid][NMAT - 1][1][k]) +
-                    (s_res[tid][NMAT - 1][2][k] + s_res[tid][NMAT - 1][3][k]);
+            Dx[k] = (s_res(tid, NMAT - 1, 0, k) + s_res(tid, NMAT - 1, 1, k)) +
+                    (s_res(tid, NMAT - 1, 2, k) + s_res(tid, NMAT - 1, 3, k));
           const float xdx = X * Dx[0] - Dx[1], xdy = Y * Dx[0] - Dx[2];
           r4[3] = make_float4(-op * (A * xdx + B * xdy), -op * (Cc * xdy + B * xdx), 0.f, 0.f);
         }
