@@ -23,7 +23,7 @@ import torch
 from . import _keepalive, _lib
 from ._lib import check, ptr
 
-_STATE = {"active": False, "jobs": [], "streams": {}, "forked": set()}
+_STATE = {"active": False, "jobs": [], "streams": {}, "forked": set(), "extra": []}
 MAX_JOBS = 16
 
 
@@ -51,6 +51,14 @@ def flush_async(device):
 
 def active() -> bool:
     return _STATE["active"]
+
+
+def join_at_exit(stream):
+    """An operator's backward left work on `stream` that nothing downstream is certain to wait for (the consumer may be
+    frozen): the block's exit makes the current stream wait for it.  Only inside an active block."""
+    assert _STATE["active"]
+    if all(stream is not s for s in _STATE["extra"]):
+        _STATE["extra"].append(stream)
 
 
 def defer_weight_grad(dz, inp, weight):
@@ -110,4 +118,7 @@ class deferred_grads:
         for typ, idx in _STATE["forked"]:
             torch.cuda.current_stream(torch.device(typ, idx)).wait_stream(_STATE["streams"][(typ, idx)])
         _STATE["forked"] = set()
+        for st in _STATE["extra"]:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+        _STATE["extra"] = []
         return False

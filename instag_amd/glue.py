@@ -18,8 +18,9 @@ def _c(t):
 
 class _MotionGlue(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc_x, aud, eye_pre, enc_a, enc_e):
+    def forward(ctx, enc_x, aud, eye_pre, enc_a, enc_e, frame_stream=None):
         L = _lib.lib()
+        ctx.frame_stream = frame_stream
         ctx.set_materialize_grads(False)
         enc_x, aud, eye_pre, enc_a, enc_e = _c(enc_x), _c(aud), _c(eye_pre), _c(enc_a), _c(enc_e)
         N, KX = enc_x.shape
@@ -57,13 +58,26 @@ class _MotionGlue(torch.autograd.Function):
                                             ptr(amb), ptr(d_enc_x), ptr(d_aud), ptr(d_eye), ptr(parts),
                                             N, KX, KA, KE, _lib.current_stream()),
               "motion_glue_backward")
-        d_vec = parts.sum(dim=0)          # fixed-order column sums of the per-workgroup partials
-        return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:]
+        side = ctx.frame_stream
+        from . import deferred
+        if side is not None and deferred.active() and _lib.may_fork(dev):
+            # the column sums only feed the per-frame branch, whose backward runs on `side`: summing there keeps the launch
+            # (and its cross-queue hand-over) out of the per-Gaussian chain that continues on this stream
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                d_vec = parts.sum(dim=0)
+            from . import _keepalive
+            _keepalive.cross_stream(parts, side)
+            deferred.join_at_exit(side)       # (the per-frame branch may be frozen: then nobody else joins `side`)
+        else:
+            d_vec = parts.sum(dim=0)      # fixed-order column sums of the per-workgroup partials
+        return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:], None
 
 
-def motion_glue(enc_x, aud, eye_pre, enc_a, enc_e):
+def motion_glue(enc_x, aud, eye_pre, enc_a, enc_e, frame_stream=None):
     """-> (h_in [N, KX+KA+KE], amb [N,3] = (||aud||, ||relu(eye_pre)||, 0)); enc_a [KA], enc_e [KE] per-frame vectors."""
-    return _MotionGlue.apply(enc_x, aud, eye_pre, enc_a.reshape(-1), enc_e.reshape(-1))
+    return _MotionGlue.apply(enc_x, aud, eye_pre, enc_a.reshape(-1), enc_e.reshape(-1), frame_stream)
 
 
 def motion_glue_supported(enc_x, aud, eye_pre) -> bool:

@@ -253,7 +253,8 @@ class _TriPlaneField(nn.Module):
             from . import glue as _glue
             if _glue.motion_glue_supported(enc_x, aud_ch_att, eye_pre):
                 # repeat / mul / relu / cat / norm chain as one HIP kernel per pass (instag_amd/glue.py)
-                h_in, amb = _glue.motion_glue(enc_x, aud_ch_att, eye_pre, enc_a, enc_e)
+                h_in, amb = _glue.motion_glue(enc_x, aud_ch_att, eye_pre, enc_a, enc_e,
+                                              frame_stream=side if fork else None)
                 return enc_x, amb[:, 0:1], amb[:, 1:2], self.sigma_net(h_in), amb
         parts = [enc_x, enc_a.repeat(enc_x.shape[0], 1) * aud_ch_att]
         eye_att = None
