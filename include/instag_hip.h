@@ -268,6 +268,18 @@ int instag_mlp_backward_add(const float* dy, const float* a1, const float* a2, c
                             const float* w2, const float* w3, float* dz1, float* dz2, float* dx,
                             const float* dx_add, int32_t N, int32_t K0, int32_t H, int32_t O, int32_t NL,
                             instag_stream_t stream);
+/* sigma_net's backward with the glue operator's backward (instag_motion_glue_backward) as its epilogue, for the universal
+ * field's widths (K0 = 36 + 32 + 6 = enc_x | enc_a * aud | enc_e * relu(eye_pre), scene/motion_net.py:291-306): the
+ * [N,74] input gradient is never stored; d_enc_x, d_aud, d_eye_pre leave from the accumulator registers and the per-frame
+ * vectors' column sums as one row [KA + KE] per workgroup (num_partials rows, added up in order by the caller).
+ * d_amb [N,3] may be NULL. */
+int instag_mlp_backward_glue_supported(int32_t K0, int32_t H, int32_t O, int32_t KX, int32_t KA, int32_t KE);
+int instag_mlp_backward_glue_num_partials(int32_t N);
+int instag_mlp_backward_glue(const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
+                             const float* w3, float* dz1, float* dz2, const float* aud, const float* eye_pre,
+                             const float* enc_a, const float* enc_e, const float* amb, const float* d_amb,
+                             float* d_enc_x, float* d_aud, float* d_eye_pre, float* col_partials, int32_t N,
+                             int32_t H, int32_t O, instag_stream_t stream);
 /* Two 2-layer MLPs over the SAME input x in one launch: (MLP_a(x), MLP_b(x)) -- the universal field's aud_ch_att_net and
  * eye_att_net both read the tri-plane features (scene/motion_net.py:281-290).  backward: dx = W_a1^T dz1a + W_b1^T dz1b
  * (+ dx_add, which may alias dx).  instag_mlp2_supported: 1 when the shape pair has a kernel (36 -> 32 -> 32 with

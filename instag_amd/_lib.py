@@ -131,6 +131,9 @@ _PROTOS = {
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward_add": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_linear_weight_grad_batched": (C.c_int, [vp, i32, vp, sz, vp]),
+    "instag_mlp_backward_glue_supported": (C.c_int, [i32] * 6),
+    "instag_mlp_backward_glue_num_partials": (C.c_int, [i32]),
+    "instag_mlp_backward_glue": (C.c_int, [vp] * 18 + [i32] * 3 + [vp]),
     "instag_mlp2_supported": (C.c_int, [i32] * 5),
     "instag_mlp2_forward": (C.c_int, [vp] * 9 + [i32] * 6 + [vp]),
     "instag_mlp2_backward": (C.c_int, [vp] * 12 + [i32] * 6 + [vp]),

@@ -215,19 +215,42 @@ mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restri
   }
 }
 
-template <int KQ0, int HQ, int OQ, int NL>
+// GLUE: sigma_net's input is the glue operator's output cat(enc_x [KX], enc_a * aud [KA], enc_e * relu(eye_pre) [KE])
+// (scene/motion_net.py:291-306).  Instead of storing dX [N, K0] for a second kernel to read back, split and multiply
+// (motion_glue_backward_kernel: 35 us + a column-sum launch at 100k rows), the epilogue below writes d_enc_x, d_aud and
+// d_eye_pre straight from the accumulator registers and keeps the per-frame vectors' column sums in registers across the
+// wave's tiles (one row of per-workgroup partial sums at the end, added up in a fixed order by the caller).
+struct GlueBwd {
+  const float* aud; const float* eye_pre; const float* enc_a; const float* enc_e; const float* amb; const float* d_amb;
+  float* d_enc_x; float* d_aud; float* d_eye; float* col_partials;
+};
+constexpr int GLUE_KX = 36, GLUE_KA = 32, GLUE_KE = 6;      // the universal field's widths (groups of four features)
+
+template <int KQ0, int HQ, int OQ, int NL, bool GLUE = false>
 __global__ void __launch_bounds__(MLP_BLOCK)
 mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __restrict__ A1,
                     const float* __restrict__ A2, const float* __restrict__ W1, const float* __restrict__ W2,
                     const float* __restrict__ W3, float* __restrict__ dZ1, float* __restrict__ dZ2,
-                    float* dX, const float* dXadd /* [N,K0] added to the input gradient, may alias dX, or null */) {
+                    float* dX, const float* dXadd /* [N,K0] added to the input gradient, may alias dX, or null */,
+                    GlueBwd gl = GlueBwd{}) {
   extern __shared__ __align__(16) float s_w[];
+  __shared__ float s_col[GLUE ? 4 : 1][GLUE ? 40 : 1];
+  constexpr int KBG = (KQ0 + 3) / 4;
+  float part[GLUE ? KBG : 1][4][4];          // column sums of gw * a over this lane's rows (glue groups only)
+  if (GLUE) {
+#pragma unroll
+    for (int b = 0; b < KBG; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[b][q][i] = 0.f;
+  }
   constexpr int KB0 = (KQ0 + 3) / 4, HB = (HQ + 3) / 4;
   constexpr int KP0 = KB0 * 32, HP = HB * 32;
   float* w1 = s_w;
   float* w2 = w1 + HP * (KP0 + 1);
   float* w3 = w2 + (NL == 3 ? HP : 32) * (HP + 1);
-  if (dX) stage_weights<HP, KB0>(w1, W1, d.H, d.K0);
+  if (dX || GLUE) stage_weights<HP, KB0>(w1, W1, d.H, d.K0);
   stage_weights<(NL == 3 ? HP : 32), HB>(w2, W2, NL == 3 ? d.H : d.O, d.H);
   if (NL == 3) stage_weights<32, HB>(w3, W3, d.O, d.H);
   __syncthreads();
@@ -259,7 +282,45 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
     }
 #pragma unroll
     for (int b = 0; b < HB; ++b) store_block(dZ1, row, valid, d.H, b, h, g1[b]);
-    if (dX) {
+    if (GLUE) {
+      f32x16 gx[KB0];
+      layer_backward<HQ, HB, KB0>(w1, g1, gx, l31, h);
+      if (valid) {
+        const float na = gl.amb[3 * row], ne = gl.amb[3 * row + 1];
+        const float ga = (gl.d_amb && na > 0.f) ? gl.d_amb[3 * row] / na : 0.f;
+        const float ge = (gl.d_amb && ne > 0.f) ? gl.d_amb[3 * row + 1] / ne : 0.f;
+#pragma unroll
+        for (int b = 0; b < KB0; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int f0 = 32 * b + 8 * q + 4 * h;              // first of this lane's four features of the group
+            const float gw[4] = {gx[b][4 * q], gx[b][4 * q + 1], gx[b][4 * q + 2], gx[b][4 * q + 3]};
+            if (f0 + 4 <= GLUE_KX) {
+              *reinterpret_cast<float4*>(gl.d_enc_x + row * GLUE_KX + f0) = make_float4(gw[0], gw[1], gw[2], gw[3]);
+            } else if (f0 >= GLUE_KX && f0 + 4 <= GLUE_KX + GLUE_KA) {
+              const int k = f0 - GLUE_KX;
+              const float4 a = *reinterpret_cast<const float4*>(gl.aud + row * GLUE_KA + k);
+              const float4 ea = *reinterpret_cast<const float4*>(gl.enc_a + k);
+              *reinterpret_cast<float4*>(gl.d_aud + row * GLUE_KA + k) =
+                  make_float4(ea.x * gw[0] + ga * a.x, ea.y * gw[1] + ga * a.y, ea.z * gw[2] + ga * a.z,
+                              ea.w * gw[3] + ga * a.w);
+              part[b][q][0] += gw[0] * a.x; part[b][q][1] += gw[1] * a.y;
+              part[b][q][2] += gw[2] * a.z; part[b][q][3] += gw[3] * a.w;
+            } else if (f0 >= GLUE_KX + GLUE_KA && f0 < GLUE_KX + GLUE_KA + GLUE_KE) {
+              const int k = f0 - GLUE_KX - GLUE_KA;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (k + i < GLUE_KE) {
+                  const float pre = gl.eye_pre[row * GLUE_KE + k + i];
+                  const float act = fmaxf(pre, 0.f);
+                  gl.d_eye[row * GLUE_KE + k + i] = pre > 0.f ? (gl.enc_e[k + i] * gw[i] + ge * act) : 0.f;
+                  part[b][q][i] += gw[i] * act;
+                }
+              }
+            }
+          }
+      }
+    } else if (dX) {
       f32x16 gx[KB0];
       layer_backward<HQ, HB, KB0>(w1, g1, gx, l31, h);
       if (dXadd) {
@@ -275,6 +336,31 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
 #pragma unroll
       for (int b = 0; b < KB0; ++b) store_block(dX, row, valid, d.K0, b, h, gx[b]);
     }
+  }
+  if (GLUE) {
+    // column sums: over the 32 rows of the half wave (xor steps below 32 stay inside it), then over the four waves in
+    // order, one row of partial sums per workgroup
+    for (int i = threadIdx.x; i < 4 * 40; i += MLP_BLOCK) (&s_col[0][0])[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < KBG; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * b + 8 * q + 4 * h;
+        if (f0 >= GLUE_KX && f0 < GLUE_KX + GLUE_KA + GLUE_KE) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = part[b][q][i];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (l31 == 0 && f0 + i < GLUE_KX + GLUE_KA + GLUE_KE) s_col[wave][f0 + i - GLUE_KX] = v;
+          }
+        }
+      }
+    __syncthreads();
+    if ((int)threadIdx.x < GLUE_KA + GLUE_KE)
+      gl.col_partials[(size_t)blockIdx.x * (GLUE_KA + GLUE_KE) + threadIdx.x] =
+          ((s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + s_col[2][threadIdx.x]) + s_col[3][threadIdx.x];
   }
 }
 
@@ -666,6 +752,43 @@ int instag_mlp_backward(const float* dy, const float* a1, const float* a2, const
                         const float* w3, float* dz1, float* dz2, float* dx, int32_t N, int32_t K0, int32_t H,
                         int32_t O, int32_t NL, instag_stream_t stream) {
   return instag_mlp_backward_add(dy, a1, a2, w1, w2, w3, dz1, dz2, dx, nullptr, N, K0, H, O, NL, stream);
+}
+
+/* sigma_net's backward with the glue operator's backward as its epilogue (universal field: K0 = 36 + 32 + 6, H = 64 or 32,
+ * O <= 16): writes dz1, dz2 (for the weight gradients), d_enc_x [N,36], d_aud [N,32], d_eye_pre [N,6] and one row of
+ * column partial sums [KA + KE] per workgroup (instag_mlp_backward_glue_num_partials rows, to be added up in order) --
+ * the [N,74] input gradient is never stored.  d_amb [N,3] may be NULL. */
+int instag_mlp_backward_glue_supported(int32_t K0, int32_t H, int32_t O, int32_t KX, int32_t KA, int32_t KE) {
+  const int kq = (K0 + 7) / 8, hq = (H + 7) / 8, oq = (O + 7) / 8;
+  return K0 == KX + KA + KE && KX == GLUE_KX && KA == GLUE_KA && KE == GLUE_KE && kq == 10 && oq == 2 &&
+         (hq == 8 || hq == 4);
+}
+
+int instag_mlp_backward_glue_num_partials(int32_t N) { return mlp_blocks((N + 31) / 32); }
+
+int instag_mlp_backward_glue(const float* dy, const float* a1, const float* a2, const float* w1, const float* w2,
+                             const float* w3, float* dz1, float* dz2, const float* aud, const float* eye_pre,
+                             const float* enc_a, const float* enc_e, const float* amb, const float* d_amb,
+                             float* d_enc_x, float* d_aud, float* d_eye_pre, float* col_partials, int32_t N,
+                             int32_t H, int32_t O, instag_stream_t stream) {
+  const int K0 = GLUE_KX + GLUE_KA + GLUE_KE;
+  INSTAG_REQUIRE(instag_mlp_backward_glue_supported(K0, H, O, GLUE_KX, GLUE_KA, GLUE_KE), "mlp_backward_glue: unsupported shape");
+  INSTAG_REQUIRE(dy && a1 && a2 && w1 && w2 && w3 && dz1 && dz2 && aud && eye_pre && enc_a && enc_e && amb && d_enc_x &&
+                     d_aud && d_eye_pre && col_partials, "mlp_backward_glue: NULL tensor");
+  if (N <= 0) return INSTAG_OK;
+  const MlpDims d{N, K0, H, O};
+  const GlueBwd gl{aud, eye_pre, enc_a, enc_e, amb, d_amb, d_enc_x, d_aud, d_eye_pre, col_partials};
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = mlp_blocks((N + 31) / 32);
+  ProfScope p(K_MLP_BWD, s);
+  if ((H + 7) / 8 == 8)
+    mlp_backward_kernel<10, 8, 2, 3, true><<<blocks, MLP_BLOCK, mlp_lds_bytes<3, 2, 3>(), s>>>(
+        d, dy, a1, a2, w1, w2, w3, dz1, dz2, nullptr, nullptr, gl);
+  else
+    mlp_backward_kernel<10, 4, 2, 3, true><<<blocks, MLP_BLOCK, mlp_lds_bytes<3, 1, 3>(), s>>>(
+        d, dy, a1, a2, w1, w2, w3, dz1, dz2, nullptr, nullptr, gl);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
 }
 
 /* Two 2-layer MLPs over the same input in one launch (see mlp2_forward_kernel).  Shapes: the universal field's

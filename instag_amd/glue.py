@@ -58,21 +58,118 @@ class _MotionGlue(torch.autograd.Function):
                                             ptr(amb), ptr(d_enc_x), ptr(d_aud), ptr(d_eye), ptr(parts),
                                             N, KX, KA, KE, _lib.current_stream()),
               "motion_glue_backward")
-        side = ctx.frame_stream
-        from . import deferred
-        if side is not None and deferred.active() and _lib.may_fork(dev):
-            # the column sums only feed the per-frame branch, whose backward runs on `side`: summing there keeps the launch
-            # (and its cross-queue hand-over) out of the per-Gaussian chain that continues on this stream
-            main = torch.cuda.current_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                d_vec = parts.sum(dim=0)
-            from . import _keepalive
-            _keepalive.cross_stream(parts, side)
-            deferred.join_at_exit(side)       # (the per-frame branch may be frozen: then nobody else joins `side`)
-        else:
-            d_vec = parts.sum(dim=0)      # fixed-order column sums of the per-workgroup partials
+        d_vec = _column_sums(parts, ctx.frame_stream, dev)
         return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:], None
+
+
+class _GlueSigma(torch.autograd.Function):
+    """motion_glue followed by sigma_net (scene/motion_net.py:291-306) as ONE autograd node whose backward is one
+    kernel: sigma_net's backward writes d_enc_x / d_aud / d_eye_pre from its accumulators and keeps the per-frame
+    vectors' column sums in registers (csrc/mlp.hip: mlp_backward_kernel<..., GLUE>), instead of storing the [N,74]
+    input gradient for motion_glue_backward to read back (35 us + a column-sum launch on the backward's critical path
+    at 100k rows).  Forward is the two existing kernels."""
+
+    @staticmethod
+    def forward(ctx, enc_x, aud, eye_pre, enc_a, enc_e, w1, w2, w3, frame_stream):
+        from . import mlp as _mlp
+        L = _lib.lib()
+        ctx.set_materialize_grads(False)
+        enc_x, aud, eye_pre, enc_a, enc_e = _c(enc_x), _c(aud), _c(eye_pre), _c(enc_a), _c(enc_e)
+        w1c, w2c, w3c = _c(w1), _c(w2), _c(w3)
+        N, KX = enc_x.shape
+        KA, KE = aud.shape[1], eye_pre.shape[1]
+        K0, H, O = KX + KA + KE, w1c.shape[0], w3c.shape[0]
+        dev = enc_x.device
+        stream = _lib.current_stream()
+        h_in = torch.empty(N, K0, dtype=torch.float32, device=dev)
+        amb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        check(L.instag_motion_glue_forward(ptr(enc_x), ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e), ptr(h_in),
+                                           ptr(amb), N, KX, KA, KE, stream), "motion_glue_forward")
+        y = torch.empty(N, O, dtype=torch.float32, device=dev)
+        a1 = torch.empty(N, H, dtype=torch.float32, device=dev)
+        a2 = torch.empty(N, H, dtype=torch.float32, device=dev)
+        check(L.instag_mlp_forward(ptr(h_in), ptr(w1c), ptr(w2c), ptr(w3c), ptr(y), ptr(a1), ptr(a2), N, K0, H, O, 3,
+                                   stream), "mlp_forward")
+        _mlp.STATS["fwd_flops"] += 2 * N * (K0 * H + H * H + H * O)
+        ctx.save_for_backward(aud, eye_pre, enc_a, enc_e, amb, h_in, w1c, w2c, w3c, a1, a2)
+        ctx.weights = (w1, w2, w3)
+        ctx.dims = (N, KX, KA, KE, H, O)
+        ctx.frame_stream = frame_stream
+        return y, amb
+
+    @staticmethod
+    def backward(ctx, dy, d_amb):
+        from . import deferred, mlp as _mlp
+        L = _lib.lib()
+        if d_amb is not None:
+            from . import diff_gauss
+            diff_gauss.join_pending_aux()        # (see _MotionGlue.backward)
+        aud, eye_pre, enc_a, enc_e, amb, h_in, w1, w2, w3, a1, a2 = ctx.saved_tensors
+        N, KX, KA, KE, H, O = ctx.dims
+        dev = aud.device
+        dy = torch.zeros(N, O, dtype=torch.float32, device=dev) if dy is None else _c(dy)
+        d_amb = None if d_amb is None else _c(d_amb)
+        dz1 = torch.empty(N, H, dtype=torch.float32, device=dev)
+        dz2 = torch.empty(N, H, dtype=torch.float32, device=dev)
+        d_enc_x = torch.empty(N, KX, dtype=torch.float32, device=dev)
+        d_aud = torch.empty(N, KA, dtype=torch.float32, device=dev)
+        d_eye = torch.empty(N, KE, dtype=torch.float32, device=dev)
+        parts = torch.empty(L.instag_mlp_backward_glue_num_partials(N), KA + KE, dtype=torch.float32, device=dev)
+        check(L.instag_mlp_backward_glue(ptr(dy), ptr(a1), ptr(a2), ptr(w1), ptr(w2), ptr(w3), ptr(dz1), ptr(dz2),
+                                         ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e), ptr(amb), ptr(d_amb),
+                                         ptr(d_enc_x), ptr(d_aud), ptr(d_eye), ptr(parts), N, H, O,
+                                         _lib.current_stream()), "mlp_backward_glue")
+        _mlp.STATS["bwd_flops"] += 2 * N * (H * O + H * H + (KX + KA + KE) * H)
+        d_vec = _column_sums(parts, ctx.frame_stream, dev)
+        jobs = [(dz1, h_in, 0), (dz2, a1, 1), (dy, a2, 2)]
+        grads = [None, None, None]
+        if deferred.active() and all(w.is_leaf for w in ctx.weights):
+            for dz, inp, idx in jobs:
+                if ctx.needs_input_grad[5 + idx]:
+                    deferred.defer_weight_grad(dz, inp, ctx.weights[idx])
+        else:
+            for dz, inp, idx in jobs:
+                if ctx.needs_input_grad[5 + idx]:
+                    dw = torch.empty(dz.shape[1], inp.shape[1], dtype=torch.float32, device=dev)
+                    ws = torch.empty(L.instag_linear_weight_grad_workspace_bytes(N, dz.shape[1], inp.shape[1]),
+                                     dtype=torch.uint8, device=dev)
+                    _mlp._weight_grad(L, dz, inp, dw, ws)
+                    grads[idx] = dw
+        return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:], grads[0], grads[1], grads[2], None
+
+
+def _column_sums(parts, side, dev):
+    """Fixed-order column sums of the per-workgroup partials; on the per-frame branch's stream when there is one (they
+    only feed that branch, whose backward runs there: the launch and its cross-queue hand-over stay out of the
+    per-Gaussian chain that continues on the current stream)."""
+    from . import deferred
+    if side is not None and deferred.active() and _lib.may_fork(dev):
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            d_vec = parts.sum(dim=0)
+        from . import _keepalive
+        _keepalive.cross_stream(parts, side)
+        deferred.join_at_exit(side)           # (the per-frame branch may be frozen: then nobody else joins `side`)
+        return d_vec
+    return parts.sum(dim=0)
+
+
+def glue_sigma_supported(enc_x, aud, eye_pre, sigma_net) -> bool:
+    if not (motion_glue_supported(enc_x, aud, eye_pre) and sigma_net.num_layers == 3):
+        return False
+    ws = [layer.weight for layer in sigma_net.net]
+    if any(layer.bias is not None for layer in sigma_net.net) or not all(w.is_cuda and w.dtype == torch.float32 for w in ws):
+        return False
+    KX, KA, KE = enc_x.shape[1], aud.shape[1], eye_pre.shape[1]
+    return bool(_lib.lib().instag_mlp_backward_glue_supported(KX + KA + KE, ws[0].shape[0], ws[2].shape[0], KX, KA, KE)) \
+        and ws[0].shape[1] == KX + KA + KE
+
+
+def glue_sigma(enc_x, aud, eye_pre, enc_a, enc_e, sigma_net, frame_stream=None):
+    """-> (sigma_net(cat(enc_x, enc_a * aud, enc_e * relu(eye_pre))) [N, out], amb [N,3]); see _GlueSigma."""
+    w = [layer.weight for layer in sigma_net.net]
+    return _GlueSigma.apply(enc_x, aud, eye_pre, enc_a.reshape(-1), enc_e.reshape(-1), w[0], w[1], w[2], frame_stream)
 
 
 def motion_glue(enc_x, aud, eye_pre, enc_a, enc_e, frame_stream=None):

@@ -253,6 +253,12 @@ class _TriPlaneField(nn.Module):
             from . import glue as _glue
             if _glue.motion_glue_supported(enc_x, aud_ch_att, eye_pre):
                 # repeat / mul / relu / cat / norm chain as one HIP kernel per pass (instag_amd/glue.py)
+                if torch.is_grad_enabled() and enc_x.requires_grad and \
+                        _glue.glue_sigma_supported(enc_x, aud_ch_att, eye_pre, self.sigma_net):
+                    # glue + sigma_net as one autograd node: its backward is ONE kernel (instag_amd/glue.py:_GlueSigma)
+                    h, amb = _glue.glue_sigma(enc_x, aud_ch_att, eye_pre, enc_a, enc_e, self.sigma_net,
+                                              frame_stream=side if fork else None)
+                    return enc_x, amb[:, 0:1], amb[:, 1:2], h, amb
                 h_in, amb = _glue.motion_glue(enc_x, aud_ch_att, eye_pre, enc_a, enc_e,
                                               frame_stream=side if fork else None)
                 return enc_x, amb[:, 0:1], amb[:, 1:2], self.sigma_net(h_in), amb

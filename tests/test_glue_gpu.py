@@ -439,3 +439,39 @@ def test_geometry_prior_matches_torch(use_depth, size):
         assert err <= 2e-3 * scale, (err, scale)
     else:
         assert dd.grad is None
+
+
+@pytest.mark.parametrize("hidden,with_amb", [(64, True), (32, True), (64, False)])
+def test_glue_sigma_backward_kernel_matches_the_two_operators(hidden, with_amb):
+    """glue + sigma_net as one autograd node (sigma_net's backward with the glue backward as its epilogue, the [N,74]
+    input gradient never stored) == motion_glue followed by fused_mlp: outputs and every gradient."""
+    from instag_amd import glue
+    from instag_amd.mlp import fused_mlp
+    from instag_amd.motion_net import MLP
+    torch.manual_seed(5)
+    N = 5003
+    net = MLP(74, 11, hidden, 3).cuda()
+    assert glue.glue_sigma_supported(torch.empty(N, 36, device="cuda"), torch.empty(N, 32, device="cuda"),
+                                     torch.empty(N, 6, device="cuda"), net)
+    base = [torch.randn(N, 36), torch.randn(N, 32), torch.randn(N, 6), torch.randn(32), torch.randn(6)]
+    gy, gamb = torch.randn(N, 11).cuda(), torch.randn(N, 3).cuda()
+    gamb[:, 2] = 0
+
+    def run(fused):
+        ins = [t.clone().cuda().requires_grad_(True) for t in base]
+        for p in net.parameters():
+            p.grad = None
+        if fused:
+            y, amb = glue.glue_sigma(*ins, net)
+        else:
+            h_in, amb = glue.motion_glue(*ins)
+            y = fused_mlp(h_in, [l.weight for l in net.net])
+        loss = (y * gy).sum() + ((amb * gamb).sum() if with_amb else 0.0)
+        loss.backward()
+        return [y.detach(), amb.detach()] + [t.grad for t in ins] + [p.grad.clone() for p in net.parameters()]
+
+    ref, got = run(False), run(True)
+    names = ["y", "amb", "d_enc_x", "d_aud", "d_eye_pre", "d_enc_a", "d_enc_e", "dW1", "dW2", "dW3"]
+    for n_, r, g in zip(names, ref, got):
+        scale = float(r.abs().max())
+        assert float((r - g).abs().max()) <= 2e-5 * scale + 1e-6, (n_, float((r - g).abs().max()), scale)
