@@ -280,6 +280,13 @@ int instag_mlp_backward_glue(const float* dy, const float* a1, const float* a2, 
                              const float* enc_a, const float* enc_e, const float* amb, const float* d_amb,
                              float* d_enc_x, float* d_aud, float* d_eye_pre, float* col_partials, int32_t N,
                              int32_t H, int32_t O, instag_stream_t stream);
+/* ... and its forward with the glue operator's forward (instag_motion_glue_forward) in front of the first layer: the
+ * input rows are formed in registers; h_in [N,74] (read by the first layer's weight gradient) and amb [N,3] are still
+ * written once.  a1 / a2 may be NULL (no gradient wanted). */
+int instag_mlp_forward_glue(const float* enc_x, const float* aud, const float* eye_pre, const float* enc_a,
+                            const float* enc_e, const float* w1, const float* w2, const float* w3, float* y, float* a1,
+                            float* a2, float* h_in, float* amb, int32_t N, int32_t H, int32_t O,
+                            instag_stream_t stream);
 /* Two 2-layer MLPs over the SAME input x in one launch: (MLP_a(x), MLP_b(x)) -- the universal field's aud_ch_att_net and
  * eye_att_net both read the tri-plane features (scene/motion_net.py:281-290).  backward: dx = W_a1^T dz1a + W_b1^T dz1b
  * (+ dx_add, which may alias dx).  instag_mlp2_supported: 1 when the shape pair has a kernel (36 -> 32 -> 32 with

@@ -134,6 +134,7 @@ _PROTOS = {
     "instag_mlp_backward_glue_supported": (C.c_int, [i32] * 6),
     "instag_mlp_backward_glue_num_partials": (C.c_int, [i32]),
     "instag_mlp_backward_glue": (C.c_int, [vp] * 18 + [i32] * 3 + [vp]),
+    "instag_mlp_forward_glue": (C.c_int, [vp] * 13 + [i32] * 3 + [vp]),
     "instag_mlp2_supported": (C.c_int, [i32] * 5),
     "instag_mlp2_forward": (C.c_int, [vp] * 9 + [i32] * 6 + [vp]),
     "instag_mlp2_backward": (C.c_int, [vp] * 12 + [i32] * 6 + [vp]),

@@ -167,12 +167,22 @@ __device__ __forceinline__ void mask_blocks(f32x16 (&g)[NB], const f32x16 (&act)
 
 struct MlpDims { int N, K0, H, O; };
 
+constexpr int GLUE_KX = 36, GLUE_KA = 32, GLUE_KE = 6;      // the universal field's widths (groups of four features)
+
+// GLUE (forward): sigma_net's input cat(enc_x, enc_a * aud, enc_e * relu(eye_pre)) is formed in the registers that feed
+// the first layer instead of by motion_glue_forward_kernel (17 us at 100k rows); the assembled rows are still written
+// out once (h_in: the first layer's weight gradient reads them), and so are the two row norms (amb).
+struct GlueFwd {
+  const float* enc_x; const float* aud; const float* eye_pre; const float* enc_a; const float* enc_e;
+  float* h_in; float* amb;
+};
+
 // KQ0 / HQ / OQ: input, hidden and output widths in groups of 8 features (rounded up)
-template <int KQ0, int HQ, int OQ, int NL>
+template <int KQ0, int HQ, int OQ, int NL, bool GLUE = false>
 __global__ void __launch_bounds__(MLP_BLOCK)
 mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restrict__ W1,
                    const float* __restrict__ W2, const float* __restrict__ W3, float* __restrict__ Y,
-                   float* __restrict__ A1, float* __restrict__ A2) {
+                   float* __restrict__ A1, float* __restrict__ A2, GlueFwd gf = GlueFwd{}) {
   extern __shared__ __align__(16) float s_w[];
   constexpr int KB0 = (KQ0 + 3) / 4, HB = (HQ + 3) / 4;
   constexpr int KP0 = KB0 * 32, HP = HB * 32;
@@ -189,8 +199,50 @@ mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restri
     const size_t row = (size_t)tile * 32 + l31;
     const bool valid = row < (size_t)d.N;
     f32x16 in0[KB0];
+    if (GLUE) {
+      constexpr int K0 = GLUE_KX + GLUE_KA + GLUE_KE;
+      float sa = 0.f, se = 0.f;
 #pragma unroll
-    for (int b = 0; b < KB0; ++b) load_block(X, row, valid, d.K0, b, h, in0[b]);
+      for (int b = 0; b < KB0; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f0 = 32 * b + 8 * q + 4 * h;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (valid) {
+            if (f0 + 4 <= GLUE_KX) {
+              const float4 t = *reinterpret_cast<const float4*>(gf.enc_x + row * GLUE_KX + f0);
+              v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else if (f0 >= GLUE_KX && f0 + 4 <= GLUE_KX + GLUE_KA) {
+              const int k = f0 - GLUE_KX;
+              const float4 a = *reinterpret_cast<const float4*>(gf.aud + row * GLUE_KA + k);
+              const float4 ea = *reinterpret_cast<const float4*>(gf.enc_a + k);
+              v[0] = ea.x * a.x; v[1] = ea.y * a.y; v[2] = ea.z * a.z; v[3] = ea.w * a.w;
+              sa += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+            } else if (f0 >= GLUE_KX + GLUE_KA && f0 < K0) {
+              const int k = f0 - GLUE_KX - GLUE_KA;
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (k + i < GLUE_KE) {
+                  const float act = fmaxf(gf.eye_pre[row * GLUE_KE + k + i], 0.f);
+                  v[i] = gf.enc_e[k + i] * act;
+                  se += act * act;
+                }
+            }
+            if (f0 < K0) {                   // (K0 = 74 is even: 8-byte stores)
+              float* hp = gf.h_in + row * K0 + f0;
+              *reinterpret_cast<float2*>(hp) = make_float2(v[0], v[1]);
+              if (f0 + 2 < K0) *reinterpret_cast<float2*>(hp + 2) = make_float2(v[2], v[3]);
+            }
+          }
+          in0[b][4 * q] = v[0]; in0[b][4 * q + 1] = v[1]; in0[b][4 * q + 2] = v[2]; in0[b][4 * q + 3] = v[3];
+        }
+      sa += __shfl_xor(sa, 32);            // the other half wave holds the row's other feature groups
+      se += __shfl_xor(se, 32);
+      if (valid && h == 0) { gf.amb[3 * row] = sqrtf(sa); gf.amb[3 * row + 1] = sqrtf(se); gf.amb[3 * row + 2] = 0.f; }
+    } else {
+#pragma unroll
+      for (int b = 0; b < KB0; ++b) load_block(X, row, valid, d.K0, b, h, in0[b]);
+    }
     f32x16 h1[HB];
     layer_forward<KQ0, KB0, HB>(w1, in0, h1, l31, h);
     relu_blocks<HB>(h1);
@@ -224,7 +276,6 @@ struct GlueBwd {
   const float* aud; const float* eye_pre; const float* enc_a; const float* enc_e; const float* amb; const float* d_amb;
   float* d_enc_x; float* d_aud; float* d_eye; float* col_partials;
 };
-constexpr int GLUE_KX = 36, GLUE_KA = 32, GLUE_KE = 6;      // the universal field's widths (groups of four features)
 
 template <int KQ0, int HQ, int OQ, int NL, bool GLUE = false>
 __global__ void __launch_bounds__(MLP_BLOCK)
@@ -787,6 +838,32 @@ int instag_mlp_backward_glue(const float* dy, const float* a1, const float* a2, 
   else
     mlp_backward_kernel<10, 4, 2, 3, true><<<blocks, MLP_BLOCK, mlp_lds_bytes<3, 1, 3>(), s>>>(
         d, dy, a1, a2, w1, w2, w3, dz1, dz2, nullptr, nullptr, gl);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+/* sigma_net's forward with the glue operator's forward in front of its first layer (same shapes as
+ * instag_mlp_backward_glue): reads enc_x [N,36], aud [N,32], eye_pre [N,6], enc_a [32], enc_e [6]; writes y [N,O], the
+ * saved activations a1, a2 [N,H], the assembled input h_in [N,74] and amb [N,3]. */
+int instag_mlp_forward_glue(const float* enc_x, const float* aud, const float* eye_pre, const float* enc_a,
+                            const float* enc_e, const float* w1, const float* w2, const float* w3, float* y, float* a1,
+                            float* a2, float* h_in, float* amb, int32_t N, int32_t H, int32_t O,
+                            instag_stream_t stream) {
+  const int K0 = GLUE_KX + GLUE_KA + GLUE_KE;
+  INSTAG_REQUIRE(instag_mlp_backward_glue_supported(K0, H, O, GLUE_KX, GLUE_KA, GLUE_KE), "mlp_forward_glue: unsupported shape");
+  INSTAG_REQUIRE(enc_x && aud && eye_pre && enc_a && enc_e && w1 && w2 && w3 && y && h_in && amb, "mlp_forward_glue: NULL tensor");
+  if (N <= 0) return INSTAG_OK;
+  const MlpDims d{N, K0, H, O};
+  const GlueFwd gf{enc_x, aud, eye_pre, enc_a, enc_e, h_in, amb};
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = mlp_blocks((N + 31) / 32);
+  ProfScope p(K_MLP_FWD, s);
+  if ((H + 7) / 8 == 8)
+    mlp_forward_kernel<10, 8, 2, 3, true><<<blocks, MLP_BLOCK, mlp_lds_bytes<3, 2, 3>(), s>>>(
+        d, nullptr, w1, w2, w3, y, a1, a2, gf);
+  else
+    mlp_forward_kernel<10, 4, 2, 3, true><<<blocks, MLP_BLOCK, mlp_lds_bytes<3, 1, 3>(), s>>>(
+        d, nullptr, w1, w2, w3, y, a1, a2, gf);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -67,7 +67,8 @@ class _GlueSigma(torch.autograd.Function):
     kernel: sigma_net's backward writes d_enc_x / d_aud / d_eye_pre from its accumulators and keeps the per-frame
     vectors' column sums in registers (csrc/mlp.hip: mlp_backward_kernel<..., GLUE>), instead of storing the [N,74]
     input gradient for motion_glue_backward to read back (35 us + a column-sum launch on the backward's critical path
-    at 100k rows).  Forward is the two existing kernels."""
+    at 100k rows).  The forward forms sigma_net's input rows in the registers that feed its first layer (GLUE variant
+    of mlp_forward_kernel) instead of in a kernel of its own."""
 
     @staticmethod
     def forward(ctx, enc_x, aud, eye_pre, enc_a, enc_e, w1, w2, w3, frame_stream):
@@ -83,13 +84,12 @@ class _GlueSigma(torch.autograd.Function):
         stream = _lib.current_stream()
         h_in = torch.empty(N, K0, dtype=torch.float32, device=dev)
         amb = torch.empty(N, 3, dtype=torch.float32, device=dev)
-        check(L.instag_motion_glue_forward(ptr(enc_x), ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e), ptr(h_in),
-                                           ptr(amb), N, KX, KA, KE, stream), "motion_glue_forward")
         y = torch.empty(N, O, dtype=torch.float32, device=dev)
         a1 = torch.empty(N, H, dtype=torch.float32, device=dev)
         a2 = torch.empty(N, H, dtype=torch.float32, device=dev)
-        check(L.instag_mlp_forward(ptr(h_in), ptr(w1c), ptr(w2c), ptr(w3c), ptr(y), ptr(a1), ptr(a2), N, K0, H, O, 3,
-                                   stream), "mlp_forward")
+        check(L.instag_mlp_forward_glue(ptr(enc_x), ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e), ptr(w1c), ptr(w2c),
+                                        ptr(w3c), ptr(y), ptr(a1), ptr(a2), ptr(h_in), ptr(amb), N, H, O, stream),
+              "mlp_forward_glue")
         _mlp.STATS["fwd_flops"] += 2 * N * (K0 * H + H * H + H * O)
         ctx.save_for_backward(aud, eye_pre, enc_a, enc_e, amb, h_in, w1c, w2c, w3c, a1, a2)
         ctx.weights = (w1, w2, w3)
