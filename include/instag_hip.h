@@ -359,6 +359,12 @@ int instag_motion_l1_reg_backward(const float* h, const float* p, const float* g
 int instag_densify_stats(const float* viewspace_grad, const int32_t* radii, float* max_radii2D, float* grad_accum,
                          float* denom, int32_t N, instag_stream_t stream);
 
+/* The k largest (descending) and k smallest (ascending) VALUES of v [N], 1 <= k <= 64 (csrc/select.hip): the two
+ * torch.topk selections behind the mouth branch's jaw-movement feature, gaussian_renderer/__init__.py:341-349. */
+size_t instag_extreme_values_workspace_bytes(int32_t N, int32_t k);
+int instag_extreme_values(const float* v, int32_t N, int32_t k, float* largest, float* smallest, void* workspace,
+                          size_t workspace_bytes, instag_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * `simple_knn._C.distCUDA2` provider (scene/gaussian_model.py:20,246; the package itself is an absent third-party
  * submodule): out[i] = mean of the squared distances from point i to its three nearest OTHER points

@@ -135,6 +135,8 @@ _PROTOS = {
     "instag_mlp_backward_glue_num_partials": (C.c_int, [i32]),
     "instag_mlp_backward_glue": (C.c_int, [vp] * 18 + [i32] * 3 + [vp]),
     "instag_mlp_forward_glue": (C.c_int, [vp] * 13 + [i32] * 3 + [vp]),
+    "instag_extreme_values_workspace_bytes": (sz, [i32, i32]),
+    "instag_extreme_values": (C.c_int, [vp, i32, i32, vp, vp, vp, sz, vp]),
     "instag_mlp2_supported": (C.c_int, [i32] * 5),
     "instag_mlp2_forward": (C.c_int, [vp] * 9 + [i32] * 6 + [vp]),
     "instag_mlp2_backward": (C.c_int, [vp] * 12 + [i32] * 6 + [vp]),

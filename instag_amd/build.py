@@ -43,6 +43,7 @@ SOURCES = {
     "adam.hip": [],
     "audio.hip": [],
     "knn.hip": [],
+    "select.hip": [],
     "prior.hip": [],
 }
 

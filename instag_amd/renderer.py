@@ -247,6 +247,24 @@ def _top_values(v, kmax, largest):
     return v.topk(min(kmax, v.numel()), 0, largest, True).values
 
 
+def _extreme_values(v, k):
+    """(the k largest values descending, the k smallest ascending) of a 1-D tensor: one HIP operator on the device
+    (csrc/select.hip, k <= 64), torch.topk otherwise."""
+    v = v.reshape(-1)
+    k = min(int(k), v.numel())
+    if v.is_cuda and v.dtype == torch.float32 and 1 <= k <= 64:
+        from . import _lib
+        L = _lib.lib()
+        v = v.contiguous()
+        top = torch.empty(k, dtype=torch.float32, device=v.device)
+        bottom = torch.empty(k, dtype=torch.float32, device=v.device)
+        ws = torch.empty(L.instag_extreme_values_workspace_bytes(v.numel(), k), dtype=torch.uint8, device=v.device)
+        _lib.check(L.instag_extreme_values(_lib.ptr(v), v.numel(), k, _lib.ptr(top), _lib.ptr(bottom), _lib.ptr(ws),
+                                           ws.numel(), _lib.current_stream()), "extreme_values")
+        return top, bottom
+    return _top_values(v, k, True), _top_values(v, k, False)
+
+
 def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_net_face, pipe=None, bg_color=None,
                             scaling_modifier=1.0, frame_idx=None, return_attn=False, personalized=False, align=False,
                             k=10, inference=False):
@@ -276,11 +294,12 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
             # round trip -- the 50 largest / smallest once, the k-th of them by index
             kmax = min(50, dy.shape[0])
             kidx = (k.reshape(1) - 1).clamp(0, kmax - 1)
-            motion_max = _top_values(dy, kmax, True).gather(0, kidx)[0]
-            motion_min = _top_values(dy, kmax, False).gather(0, kidx)[0]
+            top, bottom = _extreme_values(dy, kmax)
+            motion_max = top.gather(0, kidx)[0]
+            motion_min = bottom.gather(0, kidx)[0]
         else:
-            motion_max = _top_values(dy, k, True)[-1]
-            motion_min = _top_values(dy, k, False)[-1]
+            top, bottom = _extreme_values(dy, k)
+            motion_max, motion_min = top[-1], bottom[-1]
         move_feat = torch.stack([motion_max, motion_min, motion_max - motion_min]).reshape(1, 3) * 1e2
     motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
     d_xyz = motion_preds["d_xyz"]

@@ -171,6 +171,13 @@ class GraphedStage:
         return bool(self.plan.poll_overflow())        # asynchronous: the answer of the previous poll, no device wait
 
 
+def _backward(loss, device):
+    """loss.backward() with the MLPs' weight-gradient GEMMs batched into one launch behind it (instag_amd/deferred.py)."""
+    from .deferred import deferred_grads
+    with deferred_grads(device if device.type == "cuda" else None):
+        loss.backward()
+
+
 def _drop_graph(trainer):
     if getattr(trainer, "_graph", None) is not None:
         from . import diff_gauss
@@ -281,7 +288,7 @@ class MouthTrainer:
         """Everything of an iteration without a density-control event; free of host round trips when `k` is a
         device tensor (the captured form)."""
         pkg, loss, Ll1 = self.forward(frame, phase, k)
-        loss.backward()
+        _backward(loss, self.device)
         if stats_on:
             self._accumulate_stats(pkg)
         self._step_optimizers()
@@ -337,7 +344,7 @@ class MouthTrainer:
             if diff_gauss._CAPACITY_PLAN is not None:
                 diff_gauss._CAPACITY_PLAN.begin_step()
             pkg, loss, Ll1 = self.forward(frame, phase, k)
-            loss.backward()
+            _backward(loss, self.device)
             if self._stats_on(it):
                 self._accumulate_stats(pkg)
                 self._density_control(it, frame)
@@ -392,7 +399,7 @@ class FuseTrainer:
 
     def _body(self, frame: Frame):
         out, loss, Ll1 = self.forward(frame)
-        loss.backward()
+        _backward(loss, self.device)
         self.g.optimizer.step()
         self.g_mouth.optimizer.step()
         self.g.optimizer.zero_grad(set_to_none=True)
@@ -426,7 +433,7 @@ class FuseTrainer:
             loss, Ll1, image = self._body(frame)[:3]
         else:
             out, loss, Ll1 = self.forward(frame)         # last iteration: no optimizer step (:242)
-            loss.backward()
+            _backward(loss, self.device)
             self.g.optimizer.zero_grad(set_to_none=True)
             self.g_mouth.optimizer.zero_grad(set_to_none=True)
             image = out["image"]

@@ -475,3 +475,17 @@ def test_glue_sigma_backward_kernel_matches_the_two_operators(hidden, with_amb):
     for n_, r, g in zip(names, ref, got):
         scale = float(r.abs().max())
         assert float((r - g).abs().max()) <= 2e-5 * scale + 1e-6, (n_, float((r - g).abs().max()), scale)
+
+
+@pytest.mark.parametrize("n,k", [(1, 1), (37, 50), (4096, 50), (4097, 10), (100000, 50), (400003, 64)])
+def test_extreme_values_match_topk(n, k):
+    """csrc/select.hip (the jaw-movement feature's two selections) == torch.topk values, largest and smallest."""
+    from instag_amd.renderer import _extreme_values
+    g = torch.Generator().manual_seed(n)
+    v = torch.randn(n, generator=g)
+    if n > 100:
+        v[7] = v[11]                                 # ties
+    top, bottom = _extreme_values(v.cuda(), k)
+    kk = min(k, n)
+    assert torch.equal(top.cpu(), v.topk(kk, largest=True, sorted=True).values)
+    assert torch.equal(bottom.cpu(), v.topk(kk, largest=False, sorted=True).values)
