@@ -435,6 +435,11 @@ int instag_l1_ssim_backward(const float* img1, const float* img2, const float* m
 #define INSTAG_FACE_LOSS_ALPHA 2
 #define INSTAG_FACE_LOSS_HAIR_ATTN 4
 #define INSTAG_FACE_LOSS_LIPS 8
+/* the mouth branch's loss block instead (train_mouth.py:186-221): image_green = (lips ^ mouth) ? bg : image,
+ * gt_green = mouth ? gt : bg, the alpha terms (INSTAG_FACE_LOSS_ALPHA) over the lips rectangle = rows
+ * [lips_rect[0], lips_rect[1]) x columns [lips_rect[2], lips_rect[3]); face_mask / hair_mask may be NULL, lips_rect is
+ * required, none of the three face-branch flags may be set */
+#define INSTAG_FACE_LOSS_MOUTH 16
 typedef struct {
   int32_t H, W, flags;
   float w_dssim, w_alpha, w_attn_hair, w_attn_lips, w_extra;

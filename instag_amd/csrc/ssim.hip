@@ -163,16 +163,31 @@ struct FaceCfg {
   float w_dssim, w_alpha, w_hair, w_lips, w_extra;
 };
 constexpr int F_HAIR_BG = 1, F_ALPHA = 2, F_HAIR_ATTN = 4, F_LIPS = 8;
+// F_MOUTH: the mouth branch's compositing (train_mouth.py:186-221) instead of the face branch's --
+//   image_green = (lips ^ mouth) ? bg : image,  gt_green = mouth ? gt : bg,  alpha terms over the lips rectangle
+// (lips = rows [lips[0], lips[1]) x columns [lips[2], lips[3]) of the image); face / hair masks are not read.
+constexpr int F_MOUTH = 16;
 
 struct FaceIn {
   const float* image; const float* gt; const uint8_t* face; const uint8_t* hair; const uint8_t* mouth;
   const float* bg; const float* alpha; const float* attn; const int32_t* lips; const float* extra;
 };
 
+__device__ __forceinline__ bool in_lips(const FaceIn& in, int gy, int gx) {
+  return gy >= in.lips[0] && gy < in.lips[1] && gx >= in.lips[2] && gx < in.lips[3];
+}
+
 __device__ __forceinline__ void face_pixel(const FaceCfg& cfg, const FaceIn& in, int c, size_t plane, size_t pix,
                                            float& x, float& y) {
-  const bool hair = in.hair[pix] != 0, head = hair || in.face[pix] != 0, mouth = in.mouth[pix] != 0;
   const float bgc = in.bg[c];
+  if (cfg.flags & F_MOUTH) {
+    const int gy = (int)(pix / (size_t)cfg.W), gx = (int)(pix - (size_t)gy * cfg.W);
+    const bool mouth = in.mouth[pix] != 0, lips = in_lips(in, gy, gx);
+    x = (lips != mouth) ? bgc : in.image[c * plane + pix];
+    y = mouth ? in.gt[c * plane + pix] : bgc;
+    return;
+  }
+  const bool hair = in.hair[pix] != 0, head = hair || in.face[pix] != 0, mouth = in.mouth[pix] != 0;
   const bool hair_bg = (cfg.flags & F_HAIR_BG) && hair;
   x = hair_bg ? bgc : in.image[c * plane + pix];
   y = (head && !mouth && !hair_bg) ? in.gt[c * plane + pix] : bgc;
@@ -235,7 +250,9 @@ face_loss_forward_kernel(FaceCfg cfg, FaceIn in, float* __restrict__ maps, float
     v[0] = ssim_v;
     v[1] = fabsf(s_x[ty + RAD][tx + RAD] - s_y[ty + RAD][tx + RAD]);
     if (c == 0) {
-      const bool hair = in.hair[pix] != 0, head = hair || in.face[pix] != 0;
+      const bool mouth_mode = (cfg.flags & F_MOUTH) != 0;
+      const bool hair = !mouth_mode && in.hair[pix] != 0;
+      const bool head = mouth_mode ? in_lips(in, gy, gx) : (hair || in.face[pix] != 0);
       if (cfg.flags & F_ALPHA) {
         const float a = in.alpha[pix];
         v[2] = head ? 1.f - a : 0.f;
@@ -359,11 +376,13 @@ face_loss_backward_kernel(FaceCfg cfg, FaceIn in, const float* __restrict__ maps
   const float gs = -cfg.w_dssim * g;
   const float diff = x - y;
   const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-  const bool hair = in.hair[pix] != 0;
-  const bool frozen = (cfg.flags & F_HAIR_BG) && hair;      // pixel overwritten by the background: no gradient
+  const bool mouth_mode = (cfg.flags & F_MOUTH) != 0;
+  const bool hair = !mouth_mode && in.hair[pix] != 0;
+  // pixel overwritten by the background: no gradient
+  const bool frozen = mouth_mode ? (in_lips(in, gy, gx) != (in.mouth[pix] != 0)) : ((cfg.flags & F_HAIR_BG) && hair);
   d_image[c * plane + pix] = frozen ? 0.f : (1.f / (float)C3) * (gs * (fm + 2.f * x * f11 + y * f12) + gl * sgn);
   if (c == 0) {
-    const bool head = hair || in.face[pix] != 0;
+    const bool head = mouth_mode ? in_lips(in, gy, gx) : (hair || in.face[pix] != 0);
     if (d_alpha) d_alpha[pix] = (cfg.flags & F_ALPHA) ? g * cfg.w_alpha / (float)plane * (head ? -1.f : 1.f) : 0.f;
     if (d_attn) {
       const float gh = ((cfg.flags & F_HAIR_ATTN) && hair) ? g * cfg.w_hair * out[3] : 0.f;
@@ -429,8 +448,11 @@ int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image
                              instag_stream_t stream) {
   FaceCfg c;
   if (int rc = face_cfg(cfg, &c)) return rc;
-  INSTAG_REQUIRE(image && gt && face_mask && hair_mask && mouth_mask && bg && maps && partials && out,
+  const bool mouth_mode = (c.flags & F_MOUTH) != 0;
+  INSTAG_REQUIRE(image && gt && mouth_mask && bg && maps && partials && out && (mouth_mode || (face_mask && hair_mask)),
                  "face_loss_forward: NULL tensor");
+  INSTAG_REQUIRE(!mouth_mode || (lips_rect && !(c.flags & (F_HAIR_BG | F_HAIR_ATTN | F_LIPS))),
+                 "face_loss_forward: the mouth mode needs lips_rect and none of the face-branch terms");
   INSTAG_REQUIRE(!(c.flags & F_ALPHA) || alpha, "face_loss_forward: alpha term without alpha");
   INSTAG_REQUIRE(!(c.flags & (F_HAIR_ATTN | F_LIPS)) || attn, "face_loss_forward: attention term without attn");
   INSTAG_REQUIRE(!(c.flags & F_LIPS) || lips_rect, "face_loss_forward: lips term without lips_rect");
@@ -455,8 +477,10 @@ int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* imag
                               instag_stream_t stream) {
   FaceCfg c;
   if (int rc = face_cfg(cfg, &c)) return rc;
-  INSTAG_REQUIRE(image && gt && face_mask && hair_mask && mouth_mask && bg && maps && out && d_image,
+  const bool mouth_mode = (c.flags & F_MOUTH) != 0;
+  INSTAG_REQUIRE(image && gt && mouth_mask && bg && maps && out && d_image && (mouth_mode || (face_mask && hair_mask)),
                  "face_loss_backward: NULL tensor");
+  INSTAG_REQUIRE(!mouth_mode || lips_rect, "face_loss_backward: the mouth mode needs lips_rect");
   INSTAG_REQUIRE(!(c.flags & F_LIPS) || lips_rect, "face_loss_backward: lips term without lips_rect");
   const FaceIn in{image, gt, face_mask, hair_mask, mouth_mask, bg, nullptr, nullptr, lips_rect, nullptr};
   dim3 grid((c.W + TS - 1) / TS, (c.H + TS - 1) / TS, 3);

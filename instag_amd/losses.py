@@ -178,7 +178,7 @@ def l1_and_ssim(img1, img2):
 
 
 # ---- the face branch's whole loss block ---------------------------------------------------------------------------
-FLAG_HAIR_TO_BG, FLAG_ALPHA, FLAG_HAIR_ATTN, FLAG_LIPS = 1, 2, 4, 8
+FLAG_HAIR_TO_BG, FLAG_ALPHA, FLAG_HAIR_ATTN, FLAG_LIPS, FLAG_MOUTH = 1, 2, 4, 8, 16
 
 
 def face_loss_torch(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None, attn=None, lips_rect=None,
@@ -225,7 +225,8 @@ class _FusedFaceLoss(torch.autograd.Function):
         dev = image.device
         flags, w_dssim, w_alpha, w_hair, w_lips, w_extra = cfg_tuple
         cfg = _lib.FaceLossCfg(H, W, flags, w_dssim, w_alpha, w_hair, w_lips, w_extra)
-        as_u8 = lambda m: m.contiguous().view(torch.uint8) if m.dtype == torch.bool else m.contiguous().to(torch.uint8)
+        as_u8 = lambda m: None if m is None else (m.contiguous().view(torch.uint8) if m.dtype == torch.bool
+                                                  else m.contiguous().to(torch.uint8))
         face_mask, hair_mask, mouth_mask = as_u8(face_mask), as_u8(hair_mask), as_u8(mouth_mask)
         gt, bg = gt.contiguous().float(), bg.contiguous().float()
         alpha = None if alpha is None else alpha.contiguous().float()
@@ -286,3 +287,16 @@ def face_loss(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None, attn=
         lips_rect = torch.tensor(list(lips_rect), dtype=torch.int32, device=image.device)
     cfg = (flags, float(lambda_dssim), float(w_alpha), float(w_attn), float(w_attn), float(w_extra))
     return _FusedFaceLoss.apply(image, alpha, attn, extra, gt, face_mask, hair_mask, mouth_mask, bg, lips_rect, cfg)
+
+
+def mouth_loss_fused(image, alpha, gt, mouth_mask, lips_rect, bg, p_xyz=None, warm=True, lambda_dssim=0.2):
+    """Loss block of the mouth branch (train_mouth.py:186-221) on the device -> (loss, Ll1): the face branch's fused
+    kernels in their mouth mode (csrc/ssim.hip F_MOUTH) -- two launches forward, one backward, instead of ~45 elementwise
+    / reduce launches.  ``lips_rect`` = int32 [4] (row0, row1, col0, col1) on the device."""
+    flags = FLAG_MOUTH | (FLAG_ALPHA if warm else 0)
+    extra = None
+    if warm and p_xyz is not None:
+        extra = p_xyz.abs().mean().reshape(1)
+    cfg = (flags, float(lambda_dssim), 1e-3, 0.0, 0.0, 1e-5)
+    return _FusedFaceLoss.apply(image, alpha if warm else None, None, extra, gt, None, None, mouth_mask, bg,
+                                lips_rect.to(torch.int32), cfg)

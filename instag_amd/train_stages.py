@@ -232,8 +232,14 @@ class MouthTrainer:
         td = frame.talking_dict
         dev = self.device
         mouth = td["mouth_mask"].to(dev)
-        lips = _lips_mask(mouth, td["lips_rect"])
         p_xyz = pkg["p_motion"]["p_xyz"] if (phase.warm and pkg["p_motion"] is not None) else None
+        if self.on_gpu and torch.is_tensor(td["lips_rect"]) and pkg["render"].shape[0] == 3:
+            from .losses import mouth_loss_fused
+            loss, Ll1 = mouth_loss_fused(pkg["render"], pkg["alpha"], frame.original_image.to(dev), mouth,
+                                         td["lips_rect"].to(dev), bg, p_xyz, warm=phase.warm,
+                                         lambda_dssim=self.opt.lambda_dssim)
+            return pkg, loss, Ll1
+        lips = _lips_mask(mouth, td["lips_rect"])
         loss, Ll1 = mouth_loss(pkg["render"], pkg["alpha"], frame.original_image.to(dev), mouth, lips, bg, p_xyz,
                                warm=phase.warm, lambda_dssim=self.opt.lambda_dssim)
         return pkg, loss, Ll1

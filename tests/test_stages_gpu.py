@@ -484,3 +484,40 @@ def test_static_render_matches_direct_rasterizer_call():
         img.sum().backward()
         assert torch.equal(pkg["viewspace_points"].grad, m2.grad)
         tr._zero_grad()
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_fused_mouth_loss_matches_plain_torch(warm):
+    """Mouth-branch loss block as the fused kernels' mouth mode == instag_amd.train_stages.mouth_loss (the plain-torch
+    statement of train_mouth.py:186-221, itself checked against the reference's lines on the CPU): loss, L1 and the
+    gradients of image, alpha and p_xyz."""
+    from instag_amd.losses import mouth_loss_fused
+    from instag_amd.train_stages import _lips_mask, mouth_loss
+    g = torch.Generator().manual_seed(4)
+    H, W = 150, 170
+    image0, alpha0 = torch.rand(3, H, W, generator=g), torch.rand(1, H, W, generator=g)
+    gt = torch.rand(3, H, W, generator=g).cuda()
+    mouth = torch.zeros(H, W, dtype=torch.bool)
+    mouth[60:110, 50:130] = torch.rand(50, 80, generator=g) > 0.3
+    mouth = mouth.cuda()
+    rect = torch.tensor([70, 120, 40, 120], dtype=torch.int32, device="cuda")
+    bg = torch.tensor([0.0, 1.0, 0.0], device="cuda")
+    p0 = torch.randn(3000, 3, generator=g) * 1e-2
+
+    def run(fused):
+        image, alpha, p = (t.clone().cuda().requires_grad_(True) for t in (image0, alpha0, p0))
+        if fused:
+            loss, l1 = mouth_loss_fused(image, alpha, gt, mouth, rect, bg, p, warm=warm)
+        else:
+            loss, l1 = mouth_loss(image, alpha, gt, mouth, _lips_mask(mouth, rect), bg, p, warm=warm)
+        (loss + 0.5 * l1).backward()
+        return loss.detach(), l1.detach(), image.grad, alpha.grad, p.grad
+
+    ref, got = run(False), run(True)
+    assert abs(float(ref[0]) - float(got[0])) <= 2e-6 and abs(float(ref[1]) - float(got[1])) <= 2e-6
+    assert float((ref[2] - got[2]).abs().max()) <= 2e-5 * float(ref[2].abs().max())
+    if warm:
+        assert float((ref[3] - got[3]).abs().max()) <= 1e-6 * float(ref[3].abs().max()) + 1e-12
+        assert float((ref[4] - got[4]).abs().max()) <= 1e-6 * float(ref[4].abs().max()) + 1e-12
+    else:
+        assert got[3] is None or float(got[3].abs().max()) == 0.0
