@@ -393,9 +393,14 @@ int64_t instag_frame_code_saved_floats(int32_t dim_in, int32_t mid, int32_t dim_
 int instag_frame_code_forward(const float* a, const float* e, const float* const* params, float* enc_a,
                               float* enc_e, float* saved, int32_t dim_in, int32_t mid, int32_t dim_aud,
                               uint32_t* arrivals, instag_stream_t stream);
+/* backward: with a workspace of instag_frame_code_backward_workspace_bytes() the eight audio windows run on eight
+ * workgroups (each writes a row of parameter gradients there, a second launch adds the rows up in a fixed order);
+ * workspace NULL selects the single-workgroup form. */
+size_t instag_frame_code_backward_workspace_bytes(int32_t dim_in, int32_t mid, int32_t dim_aud);
 int instag_frame_code_backward(const float* a, const float* e, const float* const* params, const float* saved,
                                const float* d_enc_a, const float* d_enc_e, float* const* grads, int32_t dim_in,
-                               int32_t mid, int32_t dim_aud, instag_stream_t stream);
+                               int32_t mid, int32_t dim_aud, void* workspace, size_t workspace_bytes,
+                               instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused L1 + SSIM image loss.  Replaces utils/loss_utils.py l1_loss :26-27 and ssim :42-72 (11x11

@@ -155,7 +155,8 @@ _PROTOS = {
     "instag_densify_stats": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
     "instag_frame_code_saved_floats": (C.c_int64, [i32, i32, i32]),
     "instag_frame_code_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
-    "instag_frame_code_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "instag_frame_code_backward_workspace_bytes": (sz, [i32, i32, i32]),
+    "instag_frame_code_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]),
     "instag_l1_ssim_num_partials": (C.c_int, [i32, i32, i32]),
     "instag_l1_ssim_forward": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "instag_l1_ssim_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
@@ -178,7 +179,7 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
-ABI_VERSION = 6     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
+ABI_VERSION = 7     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
 
 
 def lib():

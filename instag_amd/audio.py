@@ -24,6 +24,8 @@ def _ptr_array(tensors):
     return arr
 
 
+SPLIT_BACKWARD = True        # False: the single-workgroup backward kernel (tests compare the two)
+
 class _FrameCodes(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, e, dims, arrivals, *params):
@@ -66,8 +68,12 @@ class _FrameCodes(torch.autograd.Function):
         d_enc_a = d_enc_a.contiguous().float()
         d_enc_e = d_enc_e.contiguous().float() if (ctx.has_e and d_enc_e is not None) else None
         grads = [None if p is None else torch.empty_like(p) for p in params]
+        # eight workgroups (one per audio window), each with its own row of parameter gradients in `ws`
+        ws = torch.empty(L.instag_frame_code_backward_workspace_bytes(dim_in, mid, dim_aud), dtype=torch.uint8,
+                         device=a.device) if SPLIT_BACKWARD else None
         check(L.instag_frame_code_backward(ptr(a), ptr(e), _ptr_array(params), ptr(saved), ptr(d_enc_a), ptr(d_enc_e),
-                                           _ptr_array(grads), dim_in, mid, dim_aud, _lib.current_stream()),
+                                           _ptr_array(grads), dim_in, mid, dim_aud, ptr(ws),
+                                           0 if ws is None else ws.numel(), _lib.current_stream()),
               "frame_code_backward")
         return (None, None, None, None, *grads)
 

@@ -450,13 +450,39 @@ frame_code_forward_split_kernel(FrameDims d, ParamPtrs P, const float* __restric
   }
 }
 
+// floats of parameter i (C ABI order: 4 conv + 2 fc layers of AudioNet, 5 conv + 1 linear of AudioAttNet, the two
+// expression layers; weight, bias each)
+__host__ __device__ inline int param_floats(int i, int D, int M, int A) {
+  const int n[NPARAM] = {M * D * 3, M, M * M * 3, M, 64 * M * 3, 64, 64 * 64 * 3, 64, 4096, 64, A * 64, A,
+                         16 * A * 3, 16, 8 * 16 * 3, 8, 4 * 8 * 3, 4, 2 * 4 * 3, 2, 1 * 2 * 3, 1, NB * NB, NB, 80, 80};
+  return n[i];
+}
+__host__ __device__ inline int param_total(int D, int M, int A) {
+  int t = 0;
+  for (int i = 0; i < NPARAM; ++i) t += param_floats(i, D, M, A);
+  return t;
+}
+
+// SPLIT: one workgroup per audio window.  Every workgroup repeats the small attention / expression
+// stage (it needs all eight windows' features) and then runs AudioNet's backward for ITS window only; the parameter
+// gradients go to the workgroup's own row of `partial` [NB][param_total] and frame_code_grad_reduce_kernel adds the rows up
+// in order (AudioNet's parameters) or takes row 0 (the attention stage's, identical in every row).
+template <bool SPLIT>
 __global__ void __launch_bounds__(FT)
 frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __restrict__ a,
                            const float* __restrict__ e, const float* __restrict__ saved,
-                           const float* __restrict__ d_enc_a, const float* __restrict__ d_enc_e) {
+                           const float* __restrict__ d_enc_a, const float* __restrict__ d_enc_e,
+                           float* __restrict__ partial) {
   extern __shared__ __align__(16) float s[];
   const FrameLayout L = frame_layout(d.D, d.M, d.A);
   const int D = d.D, M = d.M, A = d.A;
+  const int wb = SPLIT ? (int)blockIdx.x : 0;       // first window and number of windows of this workgroup
+  const int WB = SPLIT ? 1 : NB;
+  if (SPLIT) {
+    float* row = partial + (size_t)blockIdx.x * param_total(D, M, A);
+    int off = 0;
+    for (int i = 0; i < NPARAM; ++i) { G.p[i] = row + off; off += param_floats(i, D, M, A); }
+  }
   float* g = s + L.end - L.a1;                  // g[L.<act>] = gradient buffer of activation <act> (offsets >= a1)
   float* sw = s + ((2 * L.end - L.a1 + 3) & ~3);
   const AttW aw = att_layout(A);
@@ -510,23 +536,46 @@ frame_code_backward_kernel(FrameDims d, ParamPtrs P, GradPtrs G, const float* __
   }
   stage(sw, P.p[8], 4096); stage(sw + 4096, P.p[10], A * 64);
   __syncthreads();
-  conv_backward<1, 1>(s + L.f1, g + L.f2, sw + 4096, G.p[10], G.p[11], g + L.f1, NB, 64, A, 1, 1, true); __syncthreads();
-  conv_backward<1, 1>(s + L.a4, g + L.f1, sw, G.p[8], G.p[9], g + L.a4, NB, 64, 64, 1, 1, true);         __syncthreads();
+  // AudioNet, windows wb .. wb + WB - 1 (activations are [window][channel][position])
+#define WIN_AT(base, c, l) ((base) + wb * (c) * (l))
+  conv_backward<1, 1>(WIN_AT(s + L.f1, 64, 1), WIN_AT(g + L.f2, A, 1), sw + 4096, G.p[10], G.p[11], WIN_AT(g + L.f1, 64, 1), WB, 64, A, 1, 1, true); __syncthreads();
+  conv_backward<1, 1>(WIN_AT(s + L.a4, 64, 1), WIN_AT(g + L.f1, 64, 1), sw, G.p[8], G.p[9], WIN_AT(g + L.a4, 64, 1), WB, 64, 64, 1, 1, true);         __syncthreads();
   stage(sw, P.p[6], 64 * 64 * 3);
   __syncthreads();
-  conv_backward<3, 2>(s + L.a3, g + L.a4, sw, G.p[6], G.p[7], g + L.a3, NB, 64, 64, 2, 1, true);         __syncthreads();
+  conv_backward<3, 2>(WIN_AT(s + L.a3, 64, 2), WIN_AT(g + L.a4, 64, 1), sw, G.p[6], G.p[7], WIN_AT(g + L.a3, 64, 2), WB, 64, 64, 2, 1, true);         __syncthreads();
   stage(sw, P.p[4], 64 * M * 3);
   __syncthreads();
-  conv_backward<3, 2>(s + L.a2, g + L.a3, sw, G.p[4], G.p[5], g + L.a2, NB, M, 64, 4, 2, true);          __syncthreads();
+  conv_backward<3, 2>(WIN_AT(s + L.a2, M, 4), WIN_AT(g + L.a3, 64, 2), sw, G.p[4], G.p[5], WIN_AT(g + L.a2, M, 4), WB, M, 64, 4, 2, true);          __syncthreads();
   stage(sw, P.p[2], M * M * 3);
   __syncthreads();
-  conv_backward<3, 2>(s + L.a1, g + L.a2, sw, G.p[2], G.p[3], g + L.a1, NB, M, M, 8, 4, true);           __syncthreads();
-  conv_backward<3, 2>(s + L.x0, g + L.a1, nullptr, G.p[0], G.p[1], nullptr, NB, D, M, 16, 8, false);
+  conv_backward<3, 2>(WIN_AT(s + L.a1, M, 8), WIN_AT(g + L.a2, M, 4), sw, G.p[2], G.p[3], WIN_AT(g + L.a1, M, 8), WB, M, M, 8, 4, true);           __syncthreads();
+  conv_backward<3, 2>(WIN_AT(s + L.x0, D, 16), WIN_AT(g + L.a1, M, 8), nullptr, G.p[0], G.p[1], nullptr, WB, D, M, 16, 8, false);
+#undef WIN_AT
+}
+
+__global__ void __launch_bounds__(256)
+frame_code_grad_reduce_kernel(FrameDims d, GradPtrs G, const float* __restrict__ partial) {
+  const int PT = param_total(d.D, d.M, d.A);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= PT) return;
+  int i = 0, off = 0;
+  for (; i < NPARAM; ++i) {
+    const int n = param_floats(i, d.D, d.M, d.A);
+    if (t < off + n) break;
+    off += n;
+  }
+  if (G.p[i] == nullptr) return;
+  float v = partial[t];
+  if (i < 12) {                         // AudioNet: one contribution per window, fixed order
+    for (int b = 1; b < NB; ++b) v += partial[(size_t)b * PT + t];
+  }
+  G.p[i][t - off] = v;
 }
 
 inline int set_lds_limit() {
   if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(frame_code_forward_kernel), 160 * 1024)) return rc;
-  if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(frame_code_backward_kernel), 160 * 1024)) return rc;
+  if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(frame_code_backward_kernel<false>), 160 * 1024)) return rc;
+  if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(frame_code_backward_kernel<true>), 160 * 1024)) return rc;
   return set_max_dynamic_lds(reinterpret_cast<const void*>(frame_code_forward_split_kernel), 160 * 1024);
 }
 
@@ -588,9 +637,15 @@ int instag_frame_code_forward(const float* a, const float* e, const float* const
   return INSTAG_OK;
 }
 
+size_t instag_frame_code_backward_workspace_bytes(int32_t dim_in, int32_t mid, int32_t dim_aud) {
+  if (!dims_ok(dim_in, mid, dim_aud)) return 0;
+  return (size_t)NB * param_total(dim_in, mid, dim_aud) * sizeof(float);
+}
+
 int instag_frame_code_backward(const float* a, const float* e, const float* const* params, const float* saved,
                                const float* d_enc_a, const float* d_enc_e, float* const* grads, int32_t dim_in,
-                               int32_t mid, int32_t dim_aud, instag_stream_t stream) {
+                               int32_t mid, int32_t dim_aud, void* workspace, size_t workspace_bytes,
+                               instag_stream_t stream) {
   INSTAG_REQUIRE(a && params && saved && d_enc_a && grads, "frame_code_backward: NULL tensor");
   INSTAG_REQUIRE(dims_ok(dim_in, mid, dim_aud), "frame_code: activations do not fit the 160 KB LDS");
   const int has_exp = e != nullptr;
@@ -604,9 +659,18 @@ int instag_frame_code_backward(const float* a, const float* e, const float* cons
   if (int rc = set_lds_limit()) return rc;
   const FrameLayout L = frame_layout(dim_in, mid, dim_aud);
   const FrameDims d{dim_in, mid, dim_aud, has_exp};
-  frame_code_backward_kernel<<<1, FT, (size_t)(2 * L.end - L.a1 + 4 + weight_stage_floats(dim_in, mid, dim_aud)) *
-                                          sizeof(float), (hipStream_t)stream>>>(
-      d, P, G, a, e, saved, d_enc_a, d_enc_e);
+  const size_t lds = (size_t)(2 * L.end - L.a1 + 4 + weight_stage_floats(dim_in, mid, dim_aud)) * sizeof(float);
+  if (workspace != nullptr && workspace_bytes >= instag_frame_code_backward_workspace_bytes(dim_in, mid, dim_aud)) {
+    // one workgroup per audio window + a fixed-order sum of the eight rows of parameter gradients
+    frame_code_backward_kernel<true><<<NB, FT, lds, (hipStream_t)stream>>>(d, P, G, a, e, saved, d_enc_a, d_enc_e,
+                                                                          (float*)workspace);
+    INSTAG_CHECK_LAUNCH();
+    const int PT = param_total(dim_in, mid, dim_aud);
+    frame_code_grad_reduce_kernel<<<(PT + 255) / 256, 256, 0, (hipStream_t)stream>>>(d, G, (const float*)workspace);
+    INSTAG_CHECK_LAUNCH();
+    return INSTAG_OK;
+  }
+  frame_code_backward_kernel<false><<<1, FT, lds, (hipStream_t)stream>>>(d, P, G, a, e, saved, d_enc_a, d_enc_e, nullptr);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -117,12 +117,15 @@ def test_multi_tensor_adam_matches_torch():
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("split", [True, False], ids=["bwd-8wg", "bwd-1wg"])
 @pytest.mark.parametrize("extractor,net", [("deepspeech", "umf"), ("esperanto", "pmf")])
-def test_frame_codes_match_torch_modules(extractor, net):
-    """AudioNet + AudioAttNet + expression MLP in one workgroup vs the nn.Module chain (fp64, CPU)."""
+def test_frame_codes_match_torch_modules(extractor, net, split, monkeypatch):
+    """AudioNet + AudioAttNet + expression MLP as fused kernels vs the nn.Module chain (fp64, CPU); backward with one
+    workgroup per audio window (default) and as a single workgroup."""
     import copy
     from types import SimpleNamespace
     from instag_amd import audio as A
+    monkeypatch.setattr(A, "SPLIT_BACKWARD", split)
     from instag_amd.motion_net import MotionNetwork, PersonalizedMotionNetwork, audio_in_dim
 
     class NoEncoder(torch.nn.Module):          # the tri-plane encoders play no part in the per-frame branch
