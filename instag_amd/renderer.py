@@ -132,7 +132,25 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     fused = (align and not personalized and not detach_motion and pc.get_xyz.is_cuda
              and motion_preds.get("_h") is not None and dict.get(p_motion_preds, "_p") is not None
              and motion_preds["_h"].shape[-1] == 11)
-    if fused:
+    # personalized + align (synthesize_fuse.py:55 with --personalized): the two fields' head outputs add
+    # before everything the deform operator does ((d_xyz + p.d_xyz) * p_scale, scaling + d_scale + p.d_scale, ...), so the
+    # same operator serves with h + h_p -- one add launch instead of ~20 elementwise ones each way
+    fused_pers = (align and personalized and not detach_motion and pc.get_xyz.is_cuda and motion_reg_weight is None
+                  and motion_preds.get("_h") is not None and dict.get(p_motion_preds, "_p") is not None
+                  and dict.get(p_motion_preds, "_h") is not None and motion_preds["_h"].shape[-1] == 11)
+    if fused_pers:
+        from .glue import deform_activate
+        h_sum = motion_preds["_h"] + p_motion_preds["_h"]
+        p_ = p_route if p_route is not None else p_motion_preds["_p"]
+        means3D, scales, rotations, opacity = deform_activate(xyz_route, pc._scaling, pc._rotation, pc._opacity, h_sum, p_)
+        # (the reference's in-place updates of the returned dictionary / motion_net.cache, :207-217, rebuilt on access)
+        motion_preds["d_xyz"] = lambda: (h_sum[..., :3] * 1e-2) * (torch.tanh(p_[..., 3:] / 5) * 0.25 + 1)
+        motion_preds["d_scale"], motion_preds["d_rot"] = h_sum[..., 8:11], h_sum[..., 3:7]
+        if getattr(motion_net, "cache", None) is not None:
+            hd, pd = h_sum.detach(), p_.detach()
+            motion_net.cache["d_xyz"] = lambda: (hd[..., :3] * 1e-2) * (torch.tanh(pd[..., 3:] / 5) * 0.25 + 1)
+            motion_net.cache["d_scale"], motion_net.cache["d_rot"] = hd[..., 8:11], hd[..., 3:7]
+    elif fused:
         # deltas + softplus / normalize / sigmoid in one HIP kernel per pass (instag_amd/glue.py)
         from .glue import deform_activate
         outs_d = deform_activate(xyz_route, pc._scaling, pc._rotation, pc._opacity, motion_preds["_h"],
