@@ -59,8 +59,6 @@ constexpr int MAX_LANES = 8;
 thread_local SideLane g_lanes[MAX_LANES];
 
 SideLane* side_lane(hipStream_t caller) {
-  static const bool disabled = getenv("INSTAG_NO_SIDE_LANE") != nullptr;      // diagnostics
-  if (disabled) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   SideLane* free_slot = nullptr;
