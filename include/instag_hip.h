@@ -64,10 +64,14 @@ int instag_grid_total_variation(const float* inputs, const float* embeddings, fl
 
 /* Tri-plane encoder: the three identically configured 2-D, C=1 grid encoders of a motion field (planes xy, yz, xz;
  * scene/motion_net.py:214-216,244-258) in one pass: xyz [N,3] in [-bound,bound] -> out [N,3L] = cat(enc_xy, enc_yz,
- * enc_xz), including the (x+bound)/(2 bound) mapping (gridencoder/grid.py:149).  Each plane's table ([total_params,1],
- * shared `offsets` [L+1]) must fit 64 KB.  backward: grad [N,3L] -> dxyz [N,3] (written, may be NULL) and the three
- * table gradients (written, not accumulated; summed over workgroups in a fixed order).  workspace:
+ * enc_xz), including the (x+bound)/(2 bound) mapping (gridencoder/grid.py:149).  Each plane's table is
+ * [total_params,1] with shared `offsets` [L+1], every level dense.  backward: grad [N,3L] -> dxyz [N,3] (written, may
+ * be NULL) and the three table gradients (written, not accumulated).  workspace:
  * instag_triplane_backward_workspace_bytes(N, total_params) bytes of scratch.
+ * Tables of up to 13,312 entries per plane (the face fields) are staged in LDS and their gradient is summed in a
+ * fixed order (bitwise reproducible); larger tables (the mouth field, 46,600 entries) are read in place and their
+ * gradient is scattered with global float atomics (summation order not fixed, as in gridencoder.cu:300-330); the
+ * workspace size is then 0.
  * shift (optional, [N, shift_stride >= 3]): the encoders are evaluated at xyz + shift_scale * shift[:, :3] (the universal
  * field sits behind the personalised alignment, gaussian_renderer/__init__.py:196-197); backward then also writes
  * dshift [N, shift_stride] = (shift_scale * d/dpoint, 0, ...) when it is non-NULL (needs dxyz).

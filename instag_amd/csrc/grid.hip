@@ -595,6 +595,9 @@ namespace instag {
 namespace {
 
 constexpr uint32_t TP_MAX_L = 16;
+// the LDS kernels keep a plane's table (4 B / entry) and its gradient (8 B / entry) on chip; larger tables are read
+// and accumulated in place (triplane_global_*)
+inline bool tp_fits_lds(uint32_t total_params) { return (size_t)12 * total_params <= 156 * 1024; }
 
 struct TriPlaneArgs {
   const float* xyz;           // [N,3]
@@ -695,6 +698,42 @@ triplane_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
   }
 }
 
+// one (point, plane) work item of the forward: the plane's L levels, written as 16-byte stores when L % 4 == 0
+__device__ __forceinline__ void tp_forward_item(const TriPlaneArgs& a, const TpLevel* s_lv, const float* __restrict__ tabp,
+                                                uint32_t b, uint32_t plane, float inv2b, bool vec,
+                                                float* __restrict__ out) {
+  float p[3];
+  tp_point(a, b, p);
+  float xw[2];
+  plane_coords((int)plane, p, xw);
+  const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
+  const bool oob = x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f;
+  float* o = out + ((size_t)b * 3 + plane) * a.L;
+  for (uint32_t l4 = 0; l4 < a.L; l4 += 4) {
+    float v[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+      const uint32_t l = min(l4 + q, a.L - 1);
+      const TpLevel lv = s_lv[l];
+      const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
+      const float flx = floorf(px), fly = floorf(py);
+      const float fx = px - flx, fy = py - fly;
+      // (out-of-range points read cell 0: the value is discarded)
+      const float* tab = tabp + lv.offset + (oob ? 0u : (uint32_t)flx + (uint32_t)fly * lv.stride);
+      const float v00 = tab[0], v10 = tab[1], v01 = tab[lv.stride], v11 = tab[lv.stride + 1];
+      const float r = ((1.f - fx) * (1.f - fy)) * v00 + (fx * (1.f - fy)) * v10 + ((1.f - fx) * fy) * v01 + (fx * fy) * v11;
+      v[q] = oob ? 0.f : r;
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(o + l4) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (uint32_t q = 0; q < 4; ++q)
+        if (l4 + q < a.L) o[l4 + q] = v[q];
+    }
+  }
+}
+
 // All three tables resident in LDS at once (3T floats; the face fields' 3 x 37.9 KB), one work item per (point, plane):
 // one staging phase and one barrier per workgroup instead of three, three times as many threads in flight, and a
 // thread's 12 levels leave as three 16-byte stores into an output row that consecutive threads write contiguously
@@ -720,39 +759,25 @@ triplane_forward_all_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) 
   const uint32_t items = 3u * (b1 - b0);
   const bool vec = (a.L & 3u) == 0;
   for (uint32_t w = threadIdx.x; w < items; w += TPF_BLOCK) {
-    const uint32_t pt = w / 3u, plane = w - 3u * pt, b = b0 + pt;
-    float p[3];
-    tp_point(a, b, p);
-    float xw[2];
-    plane_coords((int)plane, p, xw);
-    const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
-    const bool oob = x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f;
-    const float* __restrict__ tabp = s_tab + plane * T;
-    float* o = out + ((size_t)b * 3 + plane) * a.L;
-    for (uint32_t l4 = 0; l4 < a.L; l4 += 4) {
-      float v[4];
-#pragma unroll
-      for (uint32_t q = 0; q < 4; ++q) {
-        const uint32_t l = min(l4 + q, a.L - 1);
-        const TpLevel lv = s_lv[l];
-        const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
-        const float flx = floorf(px), fly = floorf(py);
-        const float fx = px - flx, fy = py - fly;
-        // (out-of-range points read cell 0: the value is discarded)
-        const float* tab = tabp + lv.offset + (oob ? 0u : (uint32_t)flx + (uint32_t)fly * lv.stride);
-        const float v00 = tab[0], v10 = tab[1], v01 = tab[lv.stride], v11 = tab[lv.stride + 1];
-        const float r = ((1.f - fx) * (1.f - fy)) * v00 + (fx * (1.f - fy)) * v10 + ((1.f - fx) * fy) * v01 + (fx * fy) * v11;
-        v[q] = oob ? 0.f : r;
-      }
-      if (vec) {
-        *reinterpret_cast<float4*>(o + l4) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (uint32_t q = 0; q < 4; ++q)
-          if (l4 + q < a.L) o[l4 + q] = v[q];
-      }
-    }
+    const uint32_t pt = w / 3u, plane = w - 3u * pt;
+    tp_forward_item(a, s_lv, s_tab + plane * T, b0 + pt, plane, inv2b, vec, out);
   }
+}
+
+// Tables too large for LDS (the mouth field, scene/motion_net.py:346-478: 46,600 entries per plane): the same work
+// items with the tables read in place -- 3 x 186 KB stay resident in L2 -- in one launch instead of the generic
+// encoder's three plus the slicing and concatenation around them.
+constexpr int TPG_BLOCK = 256;
+
+__global__ void __launch_bounds__(TPG_BLOCK)
+triplane_global_forward_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) {
+  __shared__ TpLevel s_lv[TP_MAX_L];
+  tp_levels(a, s_lv);
+  __syncthreads();
+  const uint32_t w = blockIdx.x * TPG_BLOCK + threadIdx.x;
+  if (w >= 3u * a.N) return;
+  const uint32_t pt = w / 3u, plane = w - 3u * pt;
+  tp_forward_item(a, s_lv, a.tables[plane], pt, plane, 1.0f / (2.0f * a.bound), (a.L & 3u) == 0, out);
 }
 
 // Backward, stage 1: plane by plane, the plane's table (T floats) and the gradient of the workgroup's points
@@ -903,6 +928,91 @@ triplane_reduce_kernel(const float* __restrict__ ws, uint32_t nslices, uint32_t 
   }
 }
 
+
+// Backward for tables read in place.  A wave owns 21 points: lanes 3i, 3i+1, 3i+2 hold the three planes of point i
+// (lane 63 idles), so the position gradient is assembled with two shuffles and stored by one lane -- no atomics, no
+// zeroed buffer, the same summation order as the LDS kernel.  The table gradient is scattered with global float
+// atomics onto tables the caller (instag_triplane_backward) zeroed: the summation order is not fixed, as in the
+// reference (gridencoder.cu:300-330 kernel_grid_backward's atomicAdd).
+constexpr uint32_t TPG_PTS_PER_WAVE = 21;
+
+__global__ void __launch_bounds__(256)
+triplane_zero_kernel(float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2, uint32_t T) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < T) { d0[i] = 0.f; d1[i] = 0.f; d2[i] = 0.f; }
+}
+
+__global__ void __launch_bounds__(TPG_BLOCK)
+triplane_global_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]*/,
+                                float* __restrict__ dxyz /*[N,3] or null*/,
+                                float* __restrict__ dshift /*[N, shift_stride] or null*/, float* __restrict__ dtab0,
+                                float* __restrict__ dtab1, float* __restrict__ dtab2,
+                                const float* __restrict__ dxyz_add, const float* __restrict__ dshift_add) {
+  __shared__ TpLevel s_lv[TP_MAX_L];
+  tp_levels(a, s_lv);
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (blockIdx.x * TPG_BLOCK + threadIdx.x) >> 6;
+  const uint32_t pt = lane / 3u, plane = lane - 3u * pt;
+  const uint32_t b = wave * TPG_PTS_PER_WAVE + pt;
+  const bool live = lane < 3u * TPG_PTS_PER_WAVE && b < a.N;
+  const float inv2b = 1.0f / (2.0f * a.bound);
+  float gx = 0.f, gy = 0.f;
+  if (live) {
+    float p[3];
+    tp_point(a, b, p);
+    float xw[2];
+    plane_coords((int)plane, p, xw);
+    const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
+    if (!(x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f)) {
+      const float* __restrict__ g = grad + ((size_t)b * 3 + plane) * a.L;
+      const float* __restrict__ tab = a.tables[plane];
+      float* __restrict__ dtab = plane == 0 ? dtab0 : (plane == 1 ? dtab1 : dtab2);
+#pragma unroll 4
+      for (uint32_t l = 0; l < a.L; ++l) {
+        const TpLevel lv = s_lv[l];
+        const float gl = g[l];
+        const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
+        const float flx = floorf(px), fly = floorf(py);
+        const float fx = px - flx, fy = py - fly;
+        const uint32_t i00 = lv.offset + (uint32_t)flx + (uint32_t)fly * lv.stride;
+        const uint32_t i10 = i00 + 1, i01 = i00 + lv.stride, i11 = i01 + 1;
+        if (gl != 0.f) {
+          atomicAdd(&dtab[i00], ((1.f - fx) * (1.f - fy)) * gl);
+          atomicAdd(&dtab[i10], (fx * (1.f - fy)) * gl);
+          atomicAdd(&dtab[i01], ((1.f - fx) * fy) * gl);
+          atomicAdd(&dtab[i11], (fx * fy) * gl);
+        }
+        if (dxyz) {
+          const float v00 = tab[i00], v10 = tab[i10], v01 = tab[i01], v11 = tab[i11];
+          gx += gl * lv.scale * ((1.f - fy) * (v10 - v00) + fy * (v11 - v01));
+          gy += gl * lv.scale * ((1.f - fx) * (v01 - v00) + fx * (v11 - v10));
+        }
+      }
+    }
+  }
+  if (!dxyz) return;                                   // uniform
+  gx *= inv2b; gy *= inv2b;
+  const float gx1 = __shfl_down(gx, 1), gy1 = __shfl_down(gy, 1), gx2 = __shfl_down(gx, 2), gy2 = __shfl_down(gy, 2);
+  if (live && plane == 0) {
+    // xy = (x,y), yz = (y,z), xz = (x,z)
+    float d0 = gx + gx2, d1 = gy + gx1, d2 = gy1 + gy2;
+    if (dshift) {
+      float* ds = dshift + (size_t)b * a.shift_stride;
+      const float* da = dshift_add ? dshift_add + (size_t)b * a.shift_stride : nullptr;
+      ds[0] = a.shift_scale * d0 + (da ? da[0] : 0.f);
+      ds[1] = a.shift_scale * d1 + (da ? da[1] : 0.f);
+      ds[2] = a.shift_scale * d2 + (da ? da[2] : 0.f);
+      for (uint32_t k = 3; k < a.shift_stride; ++k) ds[k] = da ? da[k] : 0.f;
+    }
+    if (dxyz_add) {
+      d0 += dxyz_add[(size_t)b * 3]; d1 += dxyz_add[(size_t)b * 3 + 1]; d2 += dxyz_add[(size_t)b * 3 + 2];
+    }
+    float* d = dxyz + (size_t)b * 3;
+    d[0] = d0; d[1] = d1; d[2] = d2;
+  }
+}
+
 }  // namespace
 }  // namespace instag
 
@@ -915,14 +1025,16 @@ int instag_triplane_forward(const float* xyz, const float* table_xy, const float
   using namespace instag;
   INSTAG_REQUIRE(xyz && table_xy && table_yz && table_xz && offsets && out, "triplane_forward: NULL tensor");
   INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
-  INSTAG_REQUIRE(total_params * sizeof(float) <= 64 * 1024, "triplane: a plane's table must fit 64 KB of LDS");
   INSTAG_REQUIRE(shift == nullptr || shift_stride >= 3, "triplane: shift needs at least 3 columns");
   if (N == 0) return INSTAG_OK;
   TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound, shift, shift_stride, shift_scale};
   hipStream_t s = (hipStream_t)stream;
   ProfScope p(K_GRID_FWD, s);
   const size_t all_bytes = (size_t)3 * total_params * sizeof(float);
-  if (all_bytes <= 150 * 1024) {
+  if (!tp_fits_lds(total_params)) {
+    INSTAG_REQUIRE(N <= 0x7fffffffu / 3u, "triplane: N too large");
+    triplane_global_forward_kernel<<<div_up<uint32_t>(3u * N, TPG_BLOCK), TPG_BLOCK, 0, s>>>(a, out);
+  } else if (all_bytes <= 150 * 1024) {
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(triplane_forward_all_kernel), 150 * 1024)) return rc;
     const unsigned blocks = std::max(1u, std::min(256u, div_up<uint32_t>(3u * N, TPF_BLOCK)));
     triplane_forward_all_kernel<<<blocks, TPF_BLOCK, all_bytes, s>>>(a, out);
@@ -934,6 +1046,7 @@ int instag_triplane_forward(const float* xyz, const float* table_xy, const float
 }
 
 size_t instag_triplane_backward_workspace_bytes(uint32_t N, uint32_t total_params) {
+  if (!instag::tp_fits_lds(total_params)) return 0;      // tables read and accumulated in place
   return (size_t)instag::tp_bwd_blocks(N) * 3 * total_params * sizeof(float);
 }
 
@@ -950,12 +1063,23 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
   INSTAG_REQUIRE(grad && xyz && table_xy && table_yz && table_xz && offsets && dtable_xy && dtable_yz && dtable_xz,
                  "triplane_backward: NULL tensor");
   INSTAG_REQUIRE(L >= 1 && L <= TP_MAX_L, "triplane: L must be in [1,16]");
-  INSTAG_REQUIRE((size_t)12 * total_params <= 156 * 1024,
-                 "triplane: a plane's table (4 B / entry) and its gradient (8 B / entry) must fit 156 KB of LDS");
   hipStream_t s = (hipStream_t)stream;
   if (N == 0) {
     for (float* d : {dtable_xy, dtable_yz, dtable_xz})
       INSTAG_CHECK_HIP(hipMemsetAsync(d, 0, (size_t)total_params * sizeof(float), s));
+    return INSTAG_OK;
+  }
+  if (!tp_fits_lds(total_params)) {
+    INSTAG_REQUIRE(shift == nullptr || shift_stride >= 3, "triplane: shift needs at least 3 columns");
+    INSTAG_REQUIRE(dshift == nullptr || (shift != nullptr && dxyz != nullptr), "triplane_backward: dshift needs shift and dxyz");
+    TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound, shift, shift_stride, shift_scale};
+    ProfScope p(K_GRID_BWD, s);
+    triplane_zero_kernel<<<div_up<uint32_t>(total_params, 256), 256, 0, s>>>(dtable_xy, dtable_yz, dtable_xz, total_params);
+    INSTAG_CHECK_LAUNCH();
+    const uint32_t waves = div_up<uint32_t>(N, TPG_PTS_PER_WAVE);
+    triplane_global_backward_kernel<<<div_up<uint32_t>(waves, TPG_BLOCK / 64), TPG_BLOCK, 0, s>>>(
+        a, grad, dxyz, dshift, dtable_xy, dtable_yz, dtable_xz, dxyz_add, dshift_add);
+    INSTAG_CHECK_LAUNCH();
     return INSTAG_OK;
   }
   const unsigned blocks = tp_bwd_blocks(N);

@@ -380,8 +380,8 @@ class PersonalizedMotionNetwork(_TriPlaneField):
 
 class MouthMotionNetwork(nn.Module):
     """Motion field of the mouth branch (scene/motion_net.py:346-478): tri-plane encoders with base resolution 64
-    (46,600 entries per plane: too large for the one-pass LDS tri-plane kernel, so the three generic
-    ``GridEncoder`` calls run), sigma_net 71->32->32->7 on the concatenation of position code, audio code and the
+    (46,600 entries per plane: too large for LDS, so the tri-plane kernels read the tables in place --
+    csrc/grid.hip triplane_global_*), sigma_net 71->32->32->7 on the concatenation of position code, audio code and the
     3-element jaw-movement feature, scaler_net 39->16->16->1 gating the displacement."""
 
     def __init__(self, audio_dim=32, ind_dim=0, args=None, encoder_cls=None):

@@ -323,9 +323,12 @@ def test_grid_renderer_constructs_runs_and_stays_out_of_adam():
     assert with_state == ["xyz", "f_dc", "f_rest", "identity", "opacity", "scaling", "rotation"]
 
 
-def test_tri_plane_kernels_against_the_numpy_oracle():
+@pytest.mark.parametrize("cfg", ["face", "mouth"])
+def test_tri_plane_kernels_against_the_numpy_oracle(cfg):
     """The fused tri-plane forward / backward kernels (the ones on the train step's path) directly against
-    oracle/grid_ref.py, plane by plane: features, table gradients and d/dxyz -- not via the per-plane HIP encoder."""
+    oracle/grid_ref.py, plane by plane: features, table gradients and d/dxyz -- not via the per-plane HIP encoder.
+    "face": tables staged in LDS; "mouth": 46,600 entries per plane, read and accumulated in place."""
+    FACE = {"face": globals()["FACE"], "mouth": MOUTH}[cfg]
     from instag_amd.gridencoder import GridEncoder, tri_plane_encode
     from oracle import grid_ref
     from oracle.grid_ref import GridEncoderRef
@@ -363,9 +366,11 @@ def test_tri_plane_kernels_against_the_numpy_oracle():
     assert np.quantile(rel, 0.995) <= 2e-4 and (rel > 2e-4).mean() < 5e-3
 
 
-def test_tri_plane_passthrough_sums_the_other_consumers_gradients():
+@pytest.mark.parametrize("cfg", ["face", "mouth"])
+def test_tri_plane_passthrough_sums_the_other_consumers_gradients(cfg):
     """gridencoder.passthrough: the position (and the shift) handed on by the encode carry their other consumers'
     gradients back into the encoder's backward kernel (dxyz_add / dshift_add) -- same sums as autograd's own adds."""
+    FACE = {"face": globals()["FACE"], "mouth": MOUTH}[cfg]
     from instag_amd import gridencoder as ge
     from instag_amd.gridencoder import GridEncoder, tri_plane_encode
     torch.manual_seed(1)
@@ -398,4 +403,7 @@ def test_tri_plane_passthrough_sums_the_other_consumers_gradients():
     assert float((gx_a - gx_b).abs().max()) <= 1e-6 * float(gx_a.abs().max())
     assert float((gp_a - gp_b).abs().max()) <= 1e-6 * float(gp_a.abs().max())
     for a, b in zip(gt_a, gt_b):
-        assert torch.equal(a, b)
+        if cfg == "face":
+            assert torch.equal(a, b)                      # fixed-order sums: bitwise reproducible
+        else:
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())     # float atomics: order varies
