@@ -29,72 +29,125 @@ constexpr int MLP_BLOCK = 256;
 __device__ __forceinline__ constexpr int feat(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---- layout-L tile load / store (rows on lanes) -------------------------------------------------
-__device__ __forceinline__ void load_block(const float* __restrict__ X, size_t row, bool valid, int K, int b, int h,
+// Branch-free: every load is issued unconditionally from a clamped address and the value selected afterwards.  (With
+// the loads inside `if (in range)` regions writing registers that were zero-initialised first, the compiler put an
+// s_waitcnt vmcnt(1) behind every 8-byte load of the K = 74 path -- twenty serialised round trips per tile.)
+// KC > 0: the row length is known at compile time (every alignment and range test folds).
+template <int KC = 0>
+__device__ __forceinline__ void load_block(const float* __restrict__ X, size_t row, bool valid, int Krt, int b, int h,
                                            f32x16& v) {
+  const int K = KC > 0 ? KC : Krt;
+  const float* __restrict__ base = X + (valid ? row * (size_t)K : 0);
+  if ((K & 3) == 0) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int f0 = 32 * b + 8 * q + 4 * h;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid && f0 < K) {
-      const float* p = X + row * (size_t)K + f0;
-      if ((K & 3) == 0) {
-        t = *reinterpret_cast<const float4*>(p);
-      } else if ((K & 1) == 0) {
-        const float2 a = *reinterpret_cast<const float2*>(p);
-        t.x = a.x; t.y = a.y;
-        if (f0 + 2 < K) { const float2 c = *reinterpret_cast<const float2*>(p + 2); t.z = c.x; t.w = c.y; }
-      } else {
-        t.x = p[0];
-        if (f0 + 1 < K) t.y = p[1];
-        if (f0 + 2 < K) t.z = p[2];
-        if (f0 + 3 < K) t.w = p[3];
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int f0 = 32 * b + 8 * q + 4 * h;
+      const bool ok = valid && f0 < K;
+      const float4 t = *reinterpret_cast<const float4*>(base + (ok ? f0 : 0));
+      v[4 * q + 0] = ok ? t.x : 0.f; v[4 * q + 1] = ok ? t.y : 0.f;
+      v[4 * q + 2] = ok ? t.z : 0.f; v[4 * q + 3] = ok ? t.w : 0.f;
     }
-    v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  } else if ((K & 1) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f0 = 32 * b + 8 * q + 4 * h;
+      const bool ok0 = valid && f0 < K, ok1 = valid && f0 + 2 < K;
+      const float2 a = *reinterpret_cast<const float2*>(base + (ok0 ? f0 : 0));
+      const float2 c = *reinterpret_cast<const float2*>(base + (ok1 ? f0 + 2 : 0));
+      v[4 * q + 0] = ok0 ? a.x : 0.f; v[4 * q + 1] = ok0 ? a.y : 0.f;
+      v[4 * q + 2] = ok1 ? c.x : 0.f; v[4 * q + 3] = ok1 ? c.y : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 32 * b + 8 * q + 4 * h + i;
+        const bool ok = valid && f < K;
+        const float t = base[ok ? f : 0];
+        v[4 * q + i] = ok ? t : 0.f;
+      }
   }
 }
 
-__device__ __forceinline__ void store_block(float* __restrict__ Y, size_t row, bool valid, int K, int b, int h,
+// The alignment case is chosen once per block (not per group of four features): per-slot scalar branches cost more
+// than the stores they guard.
+template <int KC = 0>
+__device__ __forceinline__ void store_block(float* __restrict__ Y, size_t row, bool valid, int Krt, int b, int h,
                                             const f32x16& v) {
-  if (!valid) return;
+  const int K = KC > 0 ? KC : Krt;
+  float* __restrict__ base = Y + row * (size_t)K;
+  if ((K & 3) == 0) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int f0 = 32 * b + 8 * q + 4 * h;
-    if (f0 >= K) continue;
-    float* p = Y + row * (size_t)K + f0;
-    if ((K & 3) == 0) {
-      *reinterpret_cast<float4*>(p) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    } else if ((K & 1) == 0) {
-      *reinterpret_cast<float2*>(p) = make_float2(v[4 * q], v[4 * q + 1]);
-      if (f0 + 2 < K) *reinterpret_cast<float2*>(p + 2) = make_float2(v[4 * q + 2], v[4 * q + 3]);
-    } else {
-      p[0] = v[4 * q];
-      if (f0 + 1 < K) p[1] = v[4 * q + 1];
-      if (f0 + 2 < K) p[2] = v[4 * q + 2];
-      if (f0 + 3 < K) p[3] = v[4 * q + 3];
+    for (int q = 0; q < 4; ++q) {
+      const int f0 = 32 * b + 8 * q + 4 * h;
+      if (valid && f0 < K)
+        *reinterpret_cast<float4*>(base + f0) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
+  } else if ((K & 1) == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f0 = 32 * b + 8 * q + 4 * h;
+      if (valid && f0 < K) *reinterpret_cast<float2*>(base + f0) = make_float2(v[4 * q], v[4 * q + 1]);
+      if (valid && f0 + 2 < K) *reinterpret_cast<float2*>(base + f0 + 2) = make_float2(v[4 * q + 2], v[4 * q + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 32 * b + 8 * q + 4 * h + i;
+        if (valid && f < K) base[f] = v[4 * q + i];
+      }
+  }
+}
+
+// NB blocks of a tile whose row length is most likely KC (the hidden widths 16 / 32 / 64 = 8 * HQ): one uniform test,
+// then straight-line code
+template <int NB, int KC>
+__device__ __forceinline__ void load_blocks(const float* __restrict__ X, size_t row, bool valid, int K, int h,
+                                            f32x16 (&v)[NB]) {
+  if (K == KC) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) load_block<KC>(X, row, valid, K, b, h, v[b]);
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) load_block<0>(X, row, valid, K, b, h, v[b]);
+  }
+}
+
+template <int NB, int KC>
+__device__ __forceinline__ void store_blocks(float* __restrict__ Y, size_t row, bool valid, int K, int h,
+                                             const f32x16 (&v)[NB]) {
+  if (K == KC) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) store_block<KC>(Y, row, valid, K, b, h, v[b]);
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) store_block<0>(Y, row, valid, K, b, h, v[b]);
   }
 }
 
 // ---- weights: global [O][K] row-major -> LDS [OP][32*KB+1], zero padded ------------------------------
 // 8 rows x 32 consecutive columns per pass: coalesced, division-free, fully unrolled (every load of a thread is
 // issued before the first wait).  The pad column (index 32*KB) is never read.
-template <int OP, int KB>
+template <int OP, int KB, int THREADS = 256>
 __device__ __forceinline__ void stage_weights(float* __restrict__ lds, const float* __restrict__ W, int O, int K) {
-  constexpr int KS = KB * 32 + 1;
+  constexpr int KS = KB * 32 + 1, RO = THREADS / 32;      // RO rows per pass
+  static_assert(OP % RO == 0, "stage_weights: rows per pass must divide the padded row count");
   const int ro = threadIdx.x >> 5, kk = threadIdx.x & 31;
-  float v[OP / 8][KB];
+  float v[OP / RO][KB];
 #pragma unroll
-  for (int i = 0; i < OP / 8; ++i)
+  for (int i = 0; i < OP / RO; ++i)
 #pragma unroll
     for (int b = 0; b < KB; ++b) {
-      const int o = ro + 8 * i, k = 32 * b + kk;
+      const int o = ro + RO * i, k = 32 * b + kk;
       v[i][b] = (o < O && k < K) ? W[o * K + k] : 0.f;
     }
 #pragma unroll
-  for (int i = 0; i < OP / 8; ++i)
+  for (int i = 0; i < OP / RO; ++i)
 #pragma unroll
-    for (int b = 0; b < KB; ++b) lds[(ro + 8 * i) * KS + 32 * b + kk] = v[i][b];
+    for (int b = 0; b < KB; ++b) lds[(ro + RO * i) * KS + 32 * b + kk] = v[i][b];
 }
 
 // Z^T = W X^T for one layer: in[KB] (layout L) -> acc[OB] (layout L).  KQ = number of 8-feature groups of the
@@ -195,10 +248,67 @@ mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restri
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int ntiles = (d.N + 31) / 32;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+  const int tstride = gridDim.x * 4;
+  // The next tile's input is fetched BEFORE this tile's products and stores are issued: memory operations retire in
+  // order, so a fetch issued after the stores could only be consumed once those had drained (measured at 100k rows:
+  // every round of tiles paid the fetch latency plus the store drain on top of its MFMA time).
+  f32x16 raw[KB0];
+  // GLUE: per-frame multipliers of this lane's feature slots (1 for the position code), loop invariant
+  f32x16 mul[GLUE ? KB0 : 1];
+  if (GLUE) {
+#pragma unroll
+    for (int b = 0; b < KB0; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int f = 32 * b + 8 * q + 4 * h + i;
+          float m = 1.f;
+          if (f >= GLUE_KX && f < GLUE_KX + GLUE_KA) m = gf.enc_a[f - GLUE_KX];
+          else if (f >= GLUE_KX + GLUE_KA && f < GLUE_KX + GLUE_KA + GLUE_KE) m = gf.enc_e[f - GLUE_KX - GLUE_KA];
+          mul[b][4 * q + i] = m;
+        }
+  }
+  auto fetch = [&](int tile) {
+    const size_t row = (size_t)tile * 32 + l31;
+    const bool valid = row < (size_t)d.N;
+    if (GLUE) {
+#pragma unroll
+      for (int b = 0; b < KB0; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f0 = 32 * b + 8 * q + 4 * h;
+          float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (valid) {
+            if (f0 + 4 <= GLUE_KX) {
+              t = *reinterpret_cast<const float4*>(gf.enc_x + row * GLUE_KX + f0);
+            } else if (f0 >= GLUE_KX && f0 + 4 <= GLUE_KX + GLUE_KA) {
+              t = *reinterpret_cast<const float4*>(gf.aud + row * GLUE_KA + (f0 - GLUE_KX));
+            } else if (f0 >= GLUE_KX + GLUE_KA && f0 < GLUE_KX + GLUE_KA + GLUE_KE) {
+              const int k = f0 - GLUE_KX - GLUE_KA;
+              const float* e = gf.eye_pre + row * GLUE_KE + k;
+              t.x = e[0];
+              if (k + 1 < GLUE_KE) t.y = e[1];
+              if (k + 2 < GLUE_KE) t.z = e[2];
+              if (k + 3 < GLUE_KE) t.w = e[3];
+            }
+          }
+          raw[b][4 * q] = t.x; raw[b][4 * q + 1] = t.y; raw[b][4 * q + 2] = t.z; raw[b][4 * q + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+      for (int b = 0; b < KB0; ++b) load_block(X, row, valid, d.K0, b, h, raw[b]);
+    }
+  };
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tstride) {
     const size_t row = (size_t)tile * 32 + l31;
     const bool valid = row < (size_t)d.N;
     f32x16 in0[KB0];
+#pragma unroll
+    for (int b = 0; b < KB0; ++b) in0[b] = raw[b];
+    if (tile + tstride < ntiles) fetch(tile + tstride);
     if (GLUE) {
       constexpr int K0 = GLUE_KX + GLUE_KA + GLUE_KE;
       float sa = 0.f, se = 0.f;
@@ -207,48 +317,36 @@ mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int f0 = 32 * b + 8 * q + 4 * h;
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          if (valid) {
-            if (f0 + 4 <= GLUE_KX) {
-              const float4 t = *reinterpret_cast<const float4*>(gf.enc_x + row * GLUE_KX + f0);
-              v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-            } else if (f0 >= GLUE_KX && f0 + 4 <= GLUE_KX + GLUE_KA) {
-              const int k = f0 - GLUE_KX;
-              const float4 a = *reinterpret_cast<const float4*>(gf.aud + row * GLUE_KA + k);
-              const float4 ea = *reinterpret_cast<const float4*>(gf.enc_a + k);
-              v[0] = ea.x * a.x; v[1] = ea.y * a.y; v[2] = ea.z * a.z; v[3] = ea.w * a.w;
-              sa += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
-            } else if (f0 >= GLUE_KX + GLUE_KA && f0 < K0) {
-              const int k = f0 - GLUE_KX - GLUE_KA;
+          float v[4] = {in0[b][4 * q], in0[b][4 * q + 1], in0[b][4 * q + 2], in0[b][4 * q + 3]};
+          if (f0 >= GLUE_KX && f0 + 4 <= GLUE_KX + GLUE_KA) {
+            sa += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (k + i < GLUE_KE) {
-                  const float act = fmaxf(gf.eye_pre[row * GLUE_KE + k + i], 0.f);
-                  v[i] = gf.enc_e[k + i] * act;
-                  se += act * act;
-                }
-            }
-            if (f0 < K0) {                   // (K0 = 74 is even: 8-byte stores)
-              float* hp = gf.h_in + row * K0 + f0;
-              *reinterpret_cast<float2*>(hp) = make_float2(v[0], v[1]);
-              if (f0 + 2 < K0) *reinterpret_cast<float2*>(hp + 2) = make_float2(v[2], v[3]);
-            }
+            for (int i = 0; i < 4; ++i) v[i] *= mul[b][4 * q + i];
+          } else if (f0 >= GLUE_KX + GLUE_KA && f0 < K0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (f0 + i < K0) {
+                const float act = fmaxf(v[i], 0.f);
+                se += act * act;
+                v[i] = mul[b][4 * q + i] * act;
+              }
+          }
+          if (valid && f0 < K0) {            // (K0 = 74 is even: 8-byte stores)
+            float* hp = gf.h_in + row * K0 + f0;
+            *reinterpret_cast<float2*>(hp) = make_float2(v[0], v[1]);
+            if (f0 + 2 < K0) *reinterpret_cast<float2*>(hp + 2) = make_float2(v[2], v[3]);
           }
           in0[b][4 * q] = v[0]; in0[b][4 * q + 1] = v[1]; in0[b][4 * q + 2] = v[2]; in0[b][4 * q + 3] = v[3];
         }
       sa += __shfl_xor(sa, 32);            // the other half wave holds the row's other feature groups
       se += __shfl_xor(se, 32);
       if (valid && h == 0) { gf.amb[3 * row] = sqrtf(sa); gf.amb[3 * row + 1] = sqrtf(se); gf.amb[3 * row + 2] = 0.f; }
-    } else {
-#pragma unroll
-      for (int b = 0; b < KB0; ++b) load_block(X, row, valid, d.K0, b, h, in0[b]);
     }
     f32x16 h1[HB];
     layer_forward<KQ0, KB0, HB>(w1, in0, h1, l31, h);
     relu_blocks<HB>(h1);
     if (A1) {
-#pragma unroll
-      for (int b = 0; b < HB; ++b) store_block(A1, row, valid, d.H, b, h, h1[b]);
+      store_blocks<HB, 8 * HQ>(A1, row, valid, d.H, h, h1);
     }
     f32x16 out[1];
     if (NL == 3) {
@@ -256,8 +354,7 @@ mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restri
       layer_forward<HQ, HB, HB>(w2, h1, h2, l31, h);
       relu_blocks<HB>(h2);
       if (A2) {
-#pragma unroll
-        for (int b = 0; b < HB; ++b) store_block(A2, row, valid, d.H, b, h, h2[b]);
+        store_blocks<HB, 8 * HQ>(A2, row, valid, d.H, h, h2);
       }
       layer_forward<HQ, HB, 1>(w3, h2, out, l31, h);
     } else {
@@ -278,7 +375,7 @@ struct GlueBwd {
 };
 
 template <int KQ0, int HQ, int OQ, int NL, bool GLUE = false>
-__global__ void __launch_bounds__(MLP_BLOCK)
+__global__ void __launch_bounds__(MLP_BLOCK) __attribute__((amdgpu_waves_per_eu(2)))
 mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __restrict__ A1,
                     const float* __restrict__ A2, const float* __restrict__ W1, const float* __restrict__ W2,
                     const float* __restrict__ W3, float* __restrict__ dZ1, float* __restrict__ dZ2,
@@ -307,32 +404,43 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const int ntiles = (d.N + 31) / 32;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+  const int tstride = gridDim.x * 4;
+  // next tile's dY and activations fetched before this tile's products and stores are issued (see mlp_forward_kernel)
+  f32x16 ndy, nact2[NL == 3 ? HB : 1], nact1[HB];
+  auto fetch = [&](int tile) {
     const size_t row = (size_t)tile * 32 + l31;
     const bool valid = row < (size_t)d.N;
-    f32x16 dy[1];
-    load_block(dY, row, valid, d.O, 0, h, dy[0]);
+    load_block(dY, row, valid, d.O, 0, h, ndy);
+    if constexpr (NL == 3) {
+      load_blocks<HB, 8 * HQ>(A2, row, valid, d.H, h, nact2);
+    }
+    load_blocks<HB, 8 * HQ>(A1, row, valid, d.H, h, nact1);
+  };
+  int tile = blockIdx.x * 4 + wave;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tstride) {
+    const size_t row = (size_t)tile * 32 + l31;
+    const bool valid = row < (size_t)d.N;
+    f32x16 dy[1], act2[NL == 3 ? HB : 1], act1[HB];
+    dy[0] = ndy;
+#pragma unroll
+    for (int b = 0; b < HB; ++b) {
+      act1[b] = nact1[b];
+      if constexpr (NL == 3) act2[b] = nact2[b];
+    }
+    if (tile + tstride < ntiles) fetch(tile + tstride);
     f32x16 g1[HB];
-    if (NL == 3) {
-      f32x16 g2[HB], act[HB];
+    if constexpr (NL == 3) {
+      f32x16 g2[HB];
       layer_backward<OQ, 1, HB>(w3, dy, g2, l31, h);
-#pragma unroll
-      for (int b = 0; b < HB; ++b) load_block(A2, row, valid, d.H, b, h, act[b]);
-      mask_blocks<HB>(g2, act);
-#pragma unroll
-      for (int b = 0; b < HB; ++b) store_block(dZ2, row, valid, d.H, b, h, g2[b]);
+      mask_blocks<HB>(g2, act2);
+      store_blocks<HB, 8 * HQ>(dZ2, row, valid, d.H, h, g2);
       layer_backward<HQ, HB, HB>(w2, g2, g1, l31, h);
     } else {
       layer_backward<OQ, 1, HB>(w2, dy, g1, l31, h);
     }
-    {
-      f32x16 act[HB];
-#pragma unroll
-      for (int b = 0; b < HB; ++b) load_block(A1, row, valid, d.H, b, h, act[b]);
-      mask_blocks<HB>(g1, act);
-    }
-#pragma unroll
-    for (int b = 0; b < HB; ++b) store_block(dZ1, row, valid, d.H, b, h, g1[b]);
+    mask_blocks<HB>(g1, act1);
+    store_blocks<HB, 8 * HQ>(dZ1, row, valid, d.H, h, g1);
     if (GLUE) {
       f32x16 gx[KB0];
       layer_backward<HQ, HB, KB0>(w1, g1, gx, l31, h);
@@ -458,8 +566,7 @@ mlp2_forward_kernel(Mlp2Dims d, const float* __restrict__ X, const float* __rest
       f32x16 h1[HBA], out[1];
       layer_forward<KQ0, KB0, HBA>(wa1, in0, h1, l31, h);
       relu_blocks<HBA>(h1);
-#pragma unroll
-      for (int b = 0; b < HBA; ++b) store_block(A1A, row, valid, d.HA, b, h, h1[b]);
+      store_blocks<HBA, 8 * HQA>(A1A, row, valid, d.HA, h, h1);
       layer_forward<HQA, HBA, 1>(wa2, h1, out, l31, h);
       store_block(YA, row, valid, d.OA, 0, h, out[0]);
     }
@@ -467,8 +574,7 @@ mlp2_forward_kernel(Mlp2Dims d, const float* __restrict__ X, const float* __rest
       f32x16 h1[HBB], out[1];
       layer_forward<KQ0, KB0, HBB>(wb1, in0, h1, l31, h);
       relu_blocks<HBB>(h1);
-#pragma unroll
-      for (int b = 0; b < HBB; ++b) store_block(A1B, row, valid, d.HB, b, h, h1[b]);
+      store_blocks<HBB, 8 * HQB>(A1B, row, valid, d.HB, h, h1);
       layer_forward<HQB, HBB, 1>(wb2, h1, out, l31, h);
       store_block(YB, row, valid, d.OB, 0, h, out[0]);
     }
@@ -507,22 +613,18 @@ mlp2_backward_kernel(Mlp2Dims d, const float* __restrict__ dYA, const float* __r
       f32x16 dy[1], g1[HBA], act[HBA];
       load_block(dYA, row, valid, d.OA, 0, h, dy[0]);
       layer_backward<OQA, 1, HBA>(wa2, dy, g1, l31, h);
-#pragma unroll
-      for (int b = 0; b < HBA; ++b) load_block(A1A, row, valid, d.HA, b, h, act[b]);
+      load_blocks<HBA, 8 * HQA>(A1A, row, valid, d.HA, h, act);
       mask_blocks<HBA>(g1, act);
-#pragma unroll
-      for (int b = 0; b < HBA; ++b) store_block(dZ1A, row, valid, d.HA, b, h, g1[b]);
+      store_blocks<HBA, 8 * HQA>(dZ1A, row, valid, d.HA, h, g1);
       if (dX) layer_backward<HQA, HBA, KB0>(wa1, g1, gx, l31, h);
     }
     {
       f32x16 dy[1], g1[HBB], act[HBB], gb[KB0];
       load_block(dYB, row, valid, d.OB, 0, h, dy[0]);
       layer_backward<OQB, 1, HBB>(wb2, dy, g1, l31, h);
-#pragma unroll
-      for (int b = 0; b < HBB; ++b) load_block(A1B, row, valid, d.HB, b, h, act[b]);
+      load_blocks<HBB, 8 * HQB>(A1B, row, valid, d.HB, h, act);
       mask_blocks<HBB>(g1, act);
-#pragma unroll
-      for (int b = 0; b < HBB; ++b) store_block(dZ1B, row, valid, d.HB, b, h, g1[b]);
+      store_blocks<HBB, 8 * HQB>(dZ1B, row, valid, d.HB, h, g1);
       if (dX) {
         layer_backward<HQB, HBB, KB0>(wb1, g1, gb, l31, h);
 #pragma unroll
@@ -682,6 +784,13 @@ inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256))
 
 // Two workgroups per CU, each staging the weights once and walking a strided list of 32-row tiles.  (768 and 1024
 // workgroups -- one tile per wave at 100k rows -- measured the same or slower: sigma_net forward 44.9 / 44.6 / 47.8 us.)
+// Where the sigma-net forward's 39 us at 100k rows go (scripts/mlp_probe.py, scripts/probes/mfma_rate_probe.hip):
+// one v_mfma_f32_32x32x2_f32 per 64 cycles and SIMD at ~2.1 GHz = 5.35 us per tile; 3125 tiles on 1024 SIMDs are 3.05
+// per SIMD but some SIMD runs 4 (100,000 rows cost what 131,072 do); with the global loads and stores compiled out
+// the kernel takes 28.7 us (6 us fixed + 4 x 5.5), with them 38-39: the 85 MB it moves would take ~15 us at the
+// achievable HBM rate, as long as the MFMA work itself, and the two overlap only partly.  One 512-thread workgroup per
+// CU drawing tiles from an LDS counter, with the second wave of each SIMD at lower issue priority (s_setprio), measured
+// the same (38.4 us) and was slower for 32k rows (22 vs 16 us): not kept.
 inline int mlp_blocks(int ntiles) {
   return std::max(1, std::min(512, (ntiles + 3) / 4));
 }
