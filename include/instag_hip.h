@@ -68,10 +68,10 @@ int instag_grid_total_variation(const float* inputs, const float* embeddings, fl
  * [total_params,1] with shared `offsets` [L+1], every level dense.  backward: grad [N,3L] -> dxyz [N,3] (written, may
  * be NULL) and the three table gradients (written, not accumulated).  workspace:
  * instag_triplane_backward_workspace_bytes(N, total_params) bytes of scratch.
- * Tables of up to 13,312 entries per plane (the face fields) are staged in LDS and their gradient is summed in a
- * fixed order (bitwise reproducible); larger tables (the mouth field, 46,600 entries) are read in place and their
- * gradient is scattered with global float atomics (summation order not fixed, as in gridencoder.cu:300-330); the
- * workspace size is then 0.
+ * Tables of up to 13,312 entries per plane (the face fields) are staged in LDS whole; larger tables (the mouth field,
+ * 46,600 entries) are read in place and their gradient is accumulated level by level in LDS.  Either way the sums are
+ * 64-bit fixed point, added up in a fixed order: bitwise reproducible.  Only a single level of more than 16,384 cells
+ * falls back to global float atomics (summation order not fixed, as in gridencoder.cu:300-330).
  * shift (optional, [N, shift_stride >= 3]): the encoders are evaluated at xyz + shift_scale * shift[:, :3] (the universal
  * field sits behind the personalised alignment, gaussian_renderer/__init__.py:196-197); backward then also writes
  * dshift [N, shift_stride] = (shift_scale * d/dpoint, 0, ...) when it is non-NULL (needs dxyz).

@@ -223,7 +223,7 @@ def tri_plane_supported(enc_xy, enc_yz, enc_xz) -> bool:
                and e.gridtype_id == 0 and not e.align_corners and e.interp_id == 0
                and e.embeddings.shape == e0.embeddings.shape and e.embeddings.is_cuda for e in encs)
     # (tables of up to 13,312 entries per plane are staged in LDS; larger ones -- the mouth field's 46,600 -- are read
-    # in place by the triplane_global_* kernels behind the same two entry points)
+    # in place by the triplane_global_* / triplane_level_* kernels behind the same two entry points)
     if not (same and e0.num_levels <= 16):
         return False
     # the fused kernels index every level densely (x + y*(res+1)): no level may be hashed

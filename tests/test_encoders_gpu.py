@@ -403,7 +403,4 @@ def test_tri_plane_passthrough_sums_the_other_consumers_gradients(cfg):
     assert float((gx_a - gx_b).abs().max()) <= 1e-6 * float(gx_a.abs().max())
     assert float((gp_a - gp_b).abs().max()) <= 1e-6 * float(gp_a.abs().max())
     for a, b in zip(gt_a, gt_b):
-        if cfg == "face":
-            assert torch.equal(a, b)                      # fixed-order sums: bitwise reproducible
-        else:
-            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())     # float atomics: order varies
+        assert torch.equal(a, b)                          # fixed-point LDS sums, fixed-order reduce: reproducible
