@@ -352,6 +352,19 @@ int instag_deform_activate_backward(const float* scaling, const float* rotation,
                                     const float* g_rots, const float* g_opac, float* d_xyz, float* d_scaling,
                                     float* d_rotation, float* d_opacity, float* d_h, float* d_p, const float* g_reg,
                                     float reg_weight, int32_t N, instag_stream_t stream);
+/* mouth_activate (gaussian_renderer/__init__.py:404-420 with scene/motion_net.py:446-452): h [N,7] = the mouth field's
+ * sigma_net output, hs [N,1] = its scaler_net output, (sx, sy, sz) = the per-axis displacement scale (1e-2/5, 1e-2,
+ * 1e-2/5) -> means3D = xyz + ((h[:, :3] * s) * sigmoid(hs)) * 2, scales = softplus(scaling), rotations =
+ * normalize(rotation), opacity = sigmoid(opacity).  backward writes d_h[:, 3:7] = 0 (the mouth render does not apply
+ * the predicted rotation). */
+int instag_mouth_activate_forward(const float* xyz, const float* scaling, const float* rotation, const float* opacity,
+                                  const float* h, const float* hs, float sx, float sy, float sz, float* means3D,
+                                  float* scales, float* rotations, float* opac, int32_t N, instag_stream_t stream);
+int instag_mouth_activate_backward(const float* scaling, const float* rotation, const float* opacity, const float* h,
+                                   const float* hs, float sx, float sy, float sz, const float* g_means,
+                                   const float* g_scales, const float* g_rots, const float* g_opac, float* d_xyz,
+                                   float* d_scaling, float* d_rotation, float* d_opacity, float* d_h, float* d_hs,
+                                   int32_t N, instag_stream_t stream);
 int instag_motion_l1_reg_num_partials(int32_t N);
 int instag_motion_l1_reg_forward(const float* h, const float* p, float* partial, int32_t N,
                                  instag_stream_t stream);

@@ -148,6 +148,8 @@ _PROTOS = {
     "instag_deform_activate_num_reg_partials": (C.c_int, [i32]),
     "instag_deform_activate_forward": (C.c_int, [vp] * 11 + [f32, i32, vp]),
     "instag_deform_activate_backward": (C.c_int, [vp] * 16 + [f32, i32, vp]),
+    "instag_mouth_activate_forward": (C.c_int, [vp] * 6 + [f32] * 3 + [vp] * 4 + [i32, vp]),
+    "instag_mouth_activate_backward": (C.c_int, [vp] * 5 + [f32] * 3 + [vp] * 10 + [i32, vp]),
     "instag_motion_l1_reg_num_partials": (C.c_int, [i32]),
     "instag_motion_l1_reg_forward": (C.c_int, [vp, vp, vp, i32, vp]),
     "instag_motion_l1_reg_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),

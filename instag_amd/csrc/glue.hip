@@ -204,6 +204,77 @@ deform_activate_forward_kernel(int N, const float* __restrict__ xyz, const float
   }
 }
 
+// ---- mouth branch: displacement gate + activations (gaussian_renderer/__init__.py:404-420, scene/motion_net.py:446-452)
+// means3D = xyz + ((h[:, :3] * (sx, sy, sz)) * sigmoid(hs)) * 2, scales = softplus(scaling), rotations = normalize(rotation),
+// opacity = sigmoid(opacity): eleven elementwise launches forward and twenty-eight backward otherwise.
+__global__ void __launch_bounds__(GB)
+mouth_activate_forward_kernel(int N, const float* __restrict__ xyz, const float* __restrict__ scaling,
+                              const float* __restrict__ rotation, const float* __restrict__ opacity,
+                              const float* __restrict__ h /*[N,7]*/, const float* __restrict__ hs /*[N,1]*/, float sx,
+                              float sy, float sz, float* __restrict__ means3D, float* __restrict__ scales,
+                              float* __restrict__ rots, float* __restrict__ opac) {
+  const int r = blockIdx.x * GB + threadIdx.x;
+  if (r >= N) return;
+  const float sg = sigmoid_f(hs[r]);
+  const float xs[3] = {sx, sy, sz};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    means3D[3 * r + k] = xyz[3 * r + k] + ((h[(size_t)r * 7 + k] * xs[k]) * sg) * 2.0f;
+    scales[3 * r + k] = softplus_f(scaling[3 * r + k]);
+  }
+  float q[4], n2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { q[k] = rotation[4 * r + k]; n2 += q[k] * q[k]; }
+  const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rots[4 * r + k] = q[k] * inv;
+  opac[r] = sigmoid_f(opacity[r]);
+}
+
+__global__ void __launch_bounds__(GB)
+mouth_activate_backward_kernel(int N, const float* __restrict__ scaling, const float* __restrict__ rotation,
+                               const float* __restrict__ opacity, const float* __restrict__ h,
+                               const float* __restrict__ hs, float sx, float sy, float sz,
+                               const float* __restrict__ g_means, const float* __restrict__ g_scales,
+                               const float* __restrict__ g_rots, const float* __restrict__ g_opac,
+                               float* __restrict__ d_xyz, float* __restrict__ d_scaling, float* __restrict__ d_rotation,
+                               float* __restrict__ d_opacity, float* __restrict__ d_h /*[N,7]*/,
+                               float* __restrict__ d_hs /*[N,1]*/) {
+  const int r = blockIdx.x * GB + threadIdx.x;
+  if (r >= N) return;
+  const float sg = sigmoid_f(hs[r]);
+  const float xs[3] = {sx, sy, sz};
+  float dgate = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float gm = g_means ? g_means[3 * r + k] : 0.f;
+    d_xyz[3 * r + k] = gm;
+    d_h[(size_t)r * 7 + k] = gm * 2.0f * sg * xs[k];
+    dgate += gm * 2.0f * (h[(size_t)r * 7 + k] * xs[k]);
+    const float gs = g_scales ? g_scales[3 * r + k] : 0.f;
+    d_scaling[3 * r + k] = gs * sigmoid_f(scaling[3 * r + k]);           // d softplus = sigmoid
+  }
+#pragma unroll
+  for (int k = 3; k < 7; ++k) d_h[(size_t)r * 7 + k] = 0.f;            // d_rot is not applied by the mouth render
+  d_hs[r] = dgate * sg * (1.f - sg);
+  float q[4], n2 = 0.f, dot = 0.f, gr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    q[k] = rotation[4 * r + k];
+    n2 += q[k] * q[k];
+    gr[k] = g_rots ? g_rots[4 * r + k] : 0.f;
+  }
+  const float nrm = sqrtf(n2);
+  const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) dot += gr[k] * q[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    d_rotation[4 * r + k] = nrm > 1e-12f ? (gr[k] - q[k] * inv * dot * inv) * inv : gr[k] * inv;
+  const float so = sigmoid_f(opacity[r]);
+  d_opacity[r] = (g_opac ? g_opac[r] : 0.f) * so * (1.f - so);
+}
+
 __global__ void __launch_bounds__(GB)
 deform_activate_backward_kernel(int N, const float* __restrict__ scaling, const float* __restrict__ rotation,
                                 const float* __restrict__ opacity, const float* __restrict__ h,
@@ -419,6 +490,35 @@ int instag_deform_activate_backward(const float* scaling, const float* rotation,
 }
 
 int instag_deform_activate_num_reg_partials(int32_t N) { return (N + GB - 1) / GB; }
+
+int instag_mouth_activate_forward(const float* xyz, const float* scaling, const float* rotation, const float* opacity,
+                                  const float* h, const float* hs, float sx, float sy, float sz, float* means3D,
+                                  float* scales, float* rotations, float* opac, int32_t N, instag_stream_t stream) {
+  INSTAG_REQUIRE(xyz && scaling && rotation && opacity && h && hs && means3D && scales && rotations && opac,
+                 "mouth_activate_forward: NULL tensor");
+  if (N <= 0) return INSTAG_OK;
+  mouth_activate_forward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(
+      N, xyz, scaling, rotation, opacity, h, hs, sx, sy, sz, means3D, scales, rotations, opac);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_mouth_activate_backward(const float* scaling, const float* rotation, const float* opacity, const float* h,
+                                   const float* hs, float sx, float sy, float sz, const float* g_means,
+                                   const float* g_scales, const float* g_rots, const float* g_opac, float* d_xyz,
+                                   float* d_scaling, float* d_rotation, float* d_opacity, float* d_h, float* d_hs,
+                                   int32_t N, instag_stream_t stream) {
+  INSTAG_REQUIRE(scaling && rotation && opacity && h && hs && d_xyz && d_scaling && d_rotation && d_opacity && d_h && d_hs,
+                 "mouth_activate_backward: NULL tensor");
+  if (N <= 0) return INSTAG_OK;
+  mouth_activate_backward_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(
+      N, scaling, rotation, opacity, h, hs, sx, sy, sz, g_means, g_scales, g_rots, g_opac, d_xyz, d_scaling, d_rotation,
+      d_opacity, d_h, d_hs);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+
 
 int instag_motion_l1_reg_num_partials(int32_t N) { return std::max(1, std::min(256, (N + GB - 1) / GB)); }
 

@@ -238,6 +238,51 @@ def deform_activate(xyz, scaling, rotation, opacity, h, p, reg_weight=None):
     return _DeformActivate.apply(xyz, scaling, rotation, opacity, h, p, reg_weight)
 
 
+class _MouthActivate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, opacity, h, hs, xyz_scale):
+        L = _lib.lib()
+        ctx.set_materialize_grads(False)
+        xyz, scaling, rotation, opacity, h, hs = (_c(t) for t in (xyz, scaling, rotation, opacity, h, hs))
+        N, dev = xyz.shape[0], xyz.device
+        means3D = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        scales = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        rots = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        opac = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        sx, sy, sz = xyz_scale
+        check(L.instag_mouth_activate_forward(ptr(xyz), ptr(scaling), ptr(rotation), ptr(opacity), ptr(h), ptr(hs), sx, sy,
+                                              sz, ptr(means3D), ptr(scales), ptr(rots), ptr(opac), N,
+                                              _lib.current_stream()), "mouth_activate_forward")
+        ctx.save_for_backward(scaling, rotation, opacity, h, hs)
+        ctx.xyz_scale = (sx, sy, sz)
+        return means3D, scales, rots, opac
+
+    @staticmethod
+    def backward(ctx, g_means, g_scales, g_rots, g_opac):
+        L = _lib.lib()
+        scaling, rotation, opacity, h, hs = ctx.saved_tensors
+        N, dev = scaling.shape[0], scaling.device
+        gs = [None if g is None else _c(g) for g in (g_means, g_scales, g_rots, g_opac)]
+        d_xyz = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        d_scaling = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        d_rot = torch.empty(N, 4, dtype=torch.float32, device=dev)
+        d_op = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        d_h = torch.empty(N, 7, dtype=torch.float32, device=dev)
+        d_hs = torch.empty(N, 1, dtype=torch.float32, device=dev)
+        sx, sy, sz = ctx.xyz_scale
+        check(L.instag_mouth_activate_backward(ptr(scaling), ptr(rotation), ptr(opacity), ptr(h), ptr(hs), sx, sy, sz,
+                                               ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(d_xyz), ptr(d_scaling),
+                                               ptr(d_rot), ptr(d_op), ptr(d_h), ptr(d_hs), N, _lib.current_stream()),
+              "mouth_activate_backward")
+        return d_xyz, d_scaling, d_rot, d_op, d_h, d_hs, None
+
+
+def mouth_activate(xyz, scaling, rotation, opacity, h, hs, xyz_scale=(1e-2 / 5, 1e-2, 1e-2 / 5)):
+    """means3D, scales, rotations, opacity of the mouth render (gaussian_renderer/__init__.py:404-420): the mouth
+    field's gated displacement (scene/motion_net.py:446-452) added to the positions, and the three activations."""
+    return _MouthActivate.apply(xyz, scaling, rotation, opacity, h, hs, tuple(float(v) for v in xyz_scale))
+
+
 class _MotionL1Reg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, p):

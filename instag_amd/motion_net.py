@@ -384,6 +384,8 @@ class MouthMotionNetwork(nn.Module):
     csrc/grid.hip triplane_global_*), sigma_net 71->32->32->7 on the concatenation of position code, audio code and the
     3-element jaw-movement feature, scaler_net 39->16->16->1 gating the displacement."""
 
+    XYZ_SCALE = (1e-2 / 5, 1e-2, 1e-2 / 5)      # per-axis displacement scale (scene/motion_net.py:446-450)
+
     def __init__(self, audio_dim=32, ind_dim=0, args=None, encoder_cls=None):
         super().__init__()
         encoder_cls = encoder_cls or _default_encoder_cls()
@@ -409,7 +411,7 @@ class MouthMotionNetwork(nn.Module):
         self.scaler_net = MLP(self.in_dim + self.move_dim, 1, 16, 3)
         self.aud_ch_att_net = MLP(self.in_dim, audio_dim, 32, 2)     # present in the reference, unused in forward
         # d_xyz = h[:, :3] * 1e-2 with x and z divided by 5 (motion_net.py:446-450); not part of the state_dict
-        self.register_buffer("_xyz_scale", torch.tensor([1e-2 / 5, 1e-2, 1e-2 / 5]), persistent=False)
+        self.register_buffer("_xyz_scale", torch.tensor(self.XYZ_SCALE), persistent=False)
 
     encode_x = _TriPlaneField.encode_x
 
@@ -429,8 +431,10 @@ class MouthMotionNetwork(nn.Module):
         move = move.repeat(n, 1)
         h = self.sigma_net(torch.cat([enc_x, enc_a.repeat(n, 1), move], dim=-1))
         h_s = self.scaler_net(torch.cat([enc_x, move], dim=-1))
-        d_xyz = h[..., :3] * self._xyz_scale           # the reference's in-place edits as one multiply
-        return {"d_xyz": d_xyz * torch.sigmoid(h_s) * 2, "d_rot": h[..., 3:]}
+        # d_xyz = h[:, :3] * scale (the reference's in-place edits as one multiply) gated by sigmoid(h_s) * 2; the fused
+        # render path consumes the raw head outputs (glue.mouth_activate), the dictionary entries are built on access
+        return LazyOutputs({"d_xyz": lambda: (h[..., :3] * self._xyz_scale) * torch.sigmoid(h_s) * 2,
+                            "d_rot": lambda: h[..., 3:], "_h": h, "_hs": h_s})
 
     def get_params(self, lr, lr_net, wd=0):
         params = [

@@ -320,15 +320,24 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
             motion_max, motion_min = top[-1], bottom[-1]
         move_feat = torch.stack([motion_max, motion_min, motion_max - motion_min]).reshape(1, 3) * 1e2
     motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
-    d_xyz = motion_preds["d_xyz"]
-    if personalized:
-        d_xyz = d_xyz + p_motion_preds["d_xyz"]
-    means3D = pc.get_xyz + d_xyz
-    opacity = pc.get_opacity
+    h_raw, hs_raw = dict.get(motion_preds, "_h"), dict.get(motion_preds, "_hs")
+    if (not personalized and torch.is_tensor(h_raw) and torch.is_tensor(hs_raw) and h_raw.is_cuda
+            and h_raw.shape[-1] == 7):
+        # gated displacement + softplus / normalize / sigmoid in one HIP kernel per pass (instag_amd/glue.py)
+        from .glue import mouth_activate
+        means3D, scales, rotations, opacity = mouth_activate(pc.get_xyz, pc._scaling, pc._rotation, pc._opacity, h_raw,
+                                                             hs_raw, getattr(motion_net, "XYZ_SCALE",
+                                                                             (1e-2 / 5, 1e-2, 1e-2 / 5)))
+    else:
+        d_xyz = motion_preds["d_xyz"]
+        if personalized:
+            d_xyz = d_xyz + p_motion_preds["d_xyz"]
+        means3D = pc.get_xyz + d_xyz
+        opacity = pc.get_opacity
+        scales, rotations = pc.get_scaling, pc.rotation_activation(pc._rotation)
     image, depth, normal, alpha, radii, extra = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
-        scales=pc.get_scaling, rotations=pc.rotation_activation(pc._rotation), cov3Ds_precomp=None,
-        extra_attrs=_ones(opacity))
+        scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=_ones(opacity))
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "depth": depth,
             "alpha": alpha, "radii": radii, "motion": motion_preds,
             "p_motion": p_motion_preds if personalized or align else None}

@@ -492,3 +492,36 @@ def test_extreme_values_match_topk(n, k):
     kk = min(k, n)
     assert torch.equal(top.cpu(), v.topk(kk, largest=True, sorted=True).values)
     assert torch.equal(bottom.cpu(), v.topk(kk, largest=False, sorted=True).values)
+
+
+def test_mouth_activate_matches_plain_torch():
+    """glue.mouth_activate = the mouth render's elementwise tail (gaussian_renderer/__init__.py:404-420 with
+    scene/motion_net.py:446-452) -- values and all six gradients against the torch expressions."""
+    from instag_amd.glue import mouth_activate
+    torch.manual_seed(3)
+    n = 3001
+    mk = lambda *s: torch.randn(*s, device="cuda").requires_grad_(True)
+    xyz, scaling, rotation, opacity, h, hs = mk(n, 3), mk(n, 3), mk(n, 4), mk(n, 1), mk(n, 7), mk(n, 1)
+    w = [torch.randn(n, c, device="cuda") for c in (3, 3, 4, 1)]
+    scale = (1e-2 / 5, 1e-2, 1e-2 / 5)
+
+    def plain():
+        d = (h[..., :3] * torch.tensor(scale, device="cuda")) * torch.sigmoid(hs) * 2
+        return (xyz + d, torch.nn.functional.softplus(scaling), torch.nn.functional.normalize(rotation),
+                torch.sigmoid(opacity))
+
+    leaves = (xyz, scaling, rotation, opacity, h, hs)
+    grads = []
+    outs = []
+    for fn in (plain, lambda: mouth_activate(xyz, scaling, rotation, opacity, h, hs, scale)):
+        for t in leaves:
+            t.grad = None
+        o = fn()
+        sum((a * b).sum() for a, b in zip(o, w)).backward()
+        outs.append([t.detach().clone() for t in o])
+        grads.append([t.grad.clone() for t in leaves])
+    for a, b in zip(outs[0], outs[1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+    for a, b in zip(grads[0], grads[1]):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+    assert float(grads[1][4][:, 3:].abs().max()) == 0.0          # the predicted rotation is not applied
