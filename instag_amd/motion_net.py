@@ -424,9 +424,32 @@ class MouthMotionNetwork(nn.Module):
                 return _audio.frame_codes(self, a, None)[0]       # AudioNet + AudioAttNet in one workgroup
         return self.audio_att_net(self.audio_net(a).unsqueeze(0))
 
+    def start_audio(self, a, stream_index=0):
+        """As _TriPlaneField.start_audio: the next forward(x, a, move) with the same `a` runs the audio branch on side
+        stream `stream_index` behind an event recorded here."""
+        from . import _lib
+        if not (a.is_cuda and CONCURRENT_AUDIO and _lib.may_fork(a.device)):
+            return
+        ev = self.__dict__.get("_audio_event")
+        if ev is None:
+            ev = self.__dict__["_audio_event"] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(a.device))
+        self._audio_pending = (a, ev, _side_stream(a.device, stream_index))
+
     def forward(self, x, a, move):
+        pending = self.__dict__.pop("_audio_pending", None)
         enc_x = self.encode_x(x, bound=self.bound)
-        enc_a = self.encode_audio(a)
+        if pending is not None and pending[0] is a:
+            # the audio branch depends on the frame only: on its own stream from the point the caller announced it
+            main_stream, side = torch.cuda.current_stream(a.device), pending[2]
+            side.wait_event(pending[1])
+            with torch.cuda.stream(side):
+                enc_a = self.encode_audio(a)
+            main_stream.wait_stream(side)
+            from . import _keepalive
+            _keepalive.cross_stream(enc_a, main_stream)
+        else:
+            enc_a = self.encode_audio(a)
         n = enc_x.shape[0]
         move = move.repeat(n, 1)
         h = self.sigma_net(torch.cat([enc_x, enc_a.repeat(n, 1), move], dim=-1))

@@ -295,13 +295,22 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
     dev = pc.get_xyz.device
     audio_feat = viewpoint_camera.talking_dict["auds"].to(dev, non_blocking=True)
     xyz = pc.get_xyz
+    exp_feat = None
+    if xyz.is_cuda:
+        # the per-frame branches of both fields depend on the frame only: announce them now, each on its own side stream
+        if hasattr(motion_net, "start_audio"):
+            motion_net.start_audio(audio_feat, 2)
+        if not inference and hasattr(motion_net_face, "start_audio"):
+            exp_feat = torch.zeros_like(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
+            motion_net_face.start_audio(audio_feat, 1, exp_feat)
     p_motion_preds = None
     if personalized or align:
         p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat)
     if align:
         xyz = xyz + p_motion_preds["p_xyz"]
     if not inference:
-        exp_feat = torch.zeros_like(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
+        if exp_feat is None:
+            exp_feat = torch.zeros_like(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
         motion_preds_face = motion_net_face(pc_face.get_xyz, audio_feat, exp_feat)
     else:
         motion_preds_face = motion_net_face.cache
