@@ -365,6 +365,24 @@ int instag_mouth_activate_backward(const float* scaling, const float* rotation, 
                                    const float* g_scales, const float* g_rots, const float* g_opac, float* d_xyz,
                                    float* d_scaling, float* d_rotation, float* d_opacity, float* d_h, float* d_hs,
                                    int32_t N, instag_stream_t stream);
+/* abs_mean (train_mouth.py:203, `p_xyz.abs().mean()`): mean |x[:, :ncols] * scale| over the N rows of x [N, stride] as
+ * instag_abs_mean_num_partials(N) per-workgroup partial sums (to be added up by the consumer, e.g. the `extra` array of
+ * instag_face_loss_forward); backward: g = upstream gradient of that sum (device scalar) -> dx [N, stride], zero in the
+ * columns beyond ncols. */
+int instag_abs_mean_num_partials(int32_t N);
+int instag_abs_mean_forward(const float* x, int32_t N, int32_t stride, int32_t ncols, float scale, float* partials,
+                            instag_stream_t stream);
+int instag_abs_mean_backward(const float* x, const float* g, int32_t N, int32_t stride, int32_t ncols, float scale,
+                             float* dx, instag_stream_t stream);
+/* mouth_glue (scene/motion_net.py:437-444): in_sigma [N, KX+KA+KM] = [enc_x | enc_a | move], in_scaler [N, KX+KM] =
+ * [enc_x | move]; enc_a [KA <= 32] and move [KM] are per-frame vectors.  backward: d_enc_x [N,KX] = the enc_x columns
+ * of both gradients added (either may be NULL), col_partials [instag_mouth_glue_backward_num_partials(N)][KA] =
+ * per-workgroup column sums of d_in_sigma's enc_a block, to be summed by the caller in order. */
+int instag_mouth_glue_forward(const float* enc_x, const float* enc_a, const float* move, float* in_sigma,
+                              float* in_scaler, int32_t N, int32_t KX, int32_t KA, int32_t KM, instag_stream_t stream);
+int instag_mouth_glue_backward_num_partials(int32_t N);
+int instag_mouth_glue_backward(const float* d_sigma, const float* d_scaler, float* d_enc_x, float* col_partials,
+                               int32_t N, int32_t KX, int32_t KA, int32_t KM, instag_stream_t stream);
 int instag_motion_l1_reg_num_partials(int32_t N);
 int instag_motion_l1_reg_forward(const float* h, const float* p, float* partial, int32_t N,
                                  instag_stream_t stream);
@@ -381,6 +399,14 @@ int instag_densify_stats(const float* viewspace_grad, const int32_t* radii, floa
 size_t instag_extreme_values_workspace_bytes(int32_t N, int32_t k);
 int instag_extreme_values(const float* v, int32_t N, int32_t k, float* largest, float* smallest, void* workspace,
                           size_t workspace_bytes, instag_stream_t stream);
+/* The mouth field's jaw-movement feature (gaussian_renderer/__init__.py:341-349): out[3] = [max, min, max - min] * 1e2,
+ * max / min = scale * the k-th largest / smallest of v[i * stride + offset], i < N (a column of the face field's head
+ * output).  kmax <= min(64, N) candidates per side; k (1-based, clamped to [1, kmax]) is read from k_dev (int64 on the
+ * device) or, when that is NULL, k_host.  workspace: instag_jaw_feature_workspace_bytes(N, kmax). */
+size_t instag_jaw_feature_workspace_bytes(int32_t N, int32_t kmax);
+int instag_jaw_feature(const float* v, int32_t N, int32_t stride, int32_t offset, float scale, int32_t kmax,
+                       const int64_t* k_dev, int32_t k_host, float* out, void* workspace, size_t workspace_bytes,
+                       instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * `simple_knn._C.distCUDA2` provider (scene/gaussian_model.py:20,246; the package itself is an absent third-party

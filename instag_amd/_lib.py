@@ -137,6 +137,8 @@ _PROTOS = {
     "instag_mlp_forward_glue": (C.c_int, [vp] * 13 + [i32] * 3 + [vp]),
     "instag_extreme_values_workspace_bytes": (sz, [i32, i32]),
     "instag_extreme_values": (C.c_int, [vp, i32, i32, vp, vp, vp, sz, vp]),
+    "instag_jaw_feature_workspace_bytes": (sz, [i32, i32]),
+    "instag_jaw_feature": (C.c_int, [vp, i32, i32, i32, f32, i32, vp, i32, vp, vp, sz, vp]),
     "instag_mlp2_supported": (C.c_int, [i32] * 5),
     "instag_mlp2_forward": (C.c_int, [vp] * 9 + [i32] * 6 + [vp]),
     "instag_mlp2_backward": (C.c_int, [vp] * 12 + [i32] * 6 + [vp]),
@@ -148,6 +150,12 @@ _PROTOS = {
     "instag_deform_activate_num_reg_partials": (C.c_int, [i32]),
     "instag_deform_activate_forward": (C.c_int, [vp] * 11 + [f32, i32, vp]),
     "instag_deform_activate_backward": (C.c_int, [vp] * 16 + [f32, i32, vp]),
+    "instag_abs_mean_num_partials": (C.c_int, [i32]),
+    "instag_abs_mean_forward": (C.c_int, [vp, i32, i32, i32, f32, vp, vp]),
+    "instag_abs_mean_backward": (C.c_int, [vp, vp, i32, i32, i32, f32, vp, vp]),
+    "instag_mouth_glue_forward": (C.c_int, [vp] * 5 + [i32] * 4 + [vp]),
+    "instag_mouth_glue_backward_num_partials": (C.c_int, [i32]),
+    "instag_mouth_glue_backward": (C.c_int, [vp] * 4 + [i32] * 4 + [vp]),
     "instag_mouth_activate_forward": (C.c_int, [vp] * 6 + [f32] * 3 + [vp] * 4 + [i32, vp]),
     "instag_mouth_activate_backward": (C.c_int, [vp] * 5 + [f32] * 3 + [vp] * 10 + [i32, vp]),
     "instag_motion_l1_reg_num_partials": (C.c_int, [i32]),

@@ -275,6 +275,84 @@ mouth_activate_backward_kernel(int N, const float* __restrict__ scaling, const f
   d_opacity[r] = (g_opac ? g_opac[r] : 0.f) * so * (1.f - so);
 }
 
+// ---- mean |x[:, :ncols] * scale| as per-workgroup partial sums (train_mouth.py:203 `p_xyz.abs().mean()` on the raw
+// alignment head output p [N,6], p_xyz = p[:, :3] * 1e-2); backward writes the whole [N, stride] gradient ------------
+constexpr int AM_MAX_PARTIALS = 64;
+
+__global__ void __launch_bounds__(GB)
+abs_mean_forward_kernel(int N, int stride, int ncols, float scale, const float* __restrict__ x,
+                        float* __restrict__ partials) {
+  __shared__ float s_red[GB / 64];
+  const float w = 1.0f / ((float)N * (float)ncols);
+  float acc = 0.f;
+  for (int r = blockIdx.x * GB + threadIdx.x; r < N; r += gridDim.x * GB)
+    for (int c = 0; c < ncols; ++c) acc += fabsf(x[(size_t)r * stride + c] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = w * (((s_red[0] + s_red[1]) + s_red[2]) + s_red[3]);
+}
+
+__global__ void __launch_bounds__(GB)
+abs_mean_backward_kernel(int N, int stride, int ncols, float scale, const float* __restrict__ x,
+                         const float* __restrict__ g /*device scalar*/, float* __restrict__ dx) {
+  const int i = blockIdx.x * GB + threadIdx.x;
+  if (i >= N * stride) return;
+  const int c = i % stride;
+  const float w = g[0] * scale / ((float)N * (float)ncols);
+  dx[i] = c < ncols ? w * sgn(x[i] * scale) : 0.f;
+}
+
+// ---- mouth field input assembly (scene/motion_net.py:437-444): in_sigma = [enc_x | enc_a | move], in_scaler =
+// [enc_x | move] with the per-frame vectors enc_a [KA], move [KM] repeated over the rows; backward: d_enc_x = the two
+// gradients' enc_x columns added, per-workgroup column sums of the enc_a columns (move carries no gradient) ------------
+__global__ void __launch_bounds__(GB)
+mouth_glue_forward_kernel(int N, int KX, int KA, int KM, const float* __restrict__ enc_x,
+                          const float* __restrict__ enc_a, const float* __restrict__ move,
+                          float* __restrict__ in_sigma, float* __restrict__ in_scaler) {
+  const int K1 = KX + KA + KM, K2 = KX + KM;
+  const size_t total = (size_t)N * (K1 + K2);
+  for (size_t i = (size_t)blockIdx.x * GB + threadIdx.x; i < total; i += (size_t)gridDim.x * GB) {
+    if (i < (size_t)N * K1) {
+      const int r = (int)(i / K1), c = (int)(i - (size_t)r * K1);
+      in_sigma[i] = c < KX ? enc_x[(size_t)r * KX + c] : (c < KX + KA ? enc_a[c - KX] : move[c - KX - KA]);
+    } else {
+      const size_t j = i - (size_t)N * K1;
+      const int r = (int)(j / K2), c = (int)(j - (size_t)r * K2);
+      in_scaler[j] = c < KX ? enc_x[(size_t)r * KX + c] : move[c - KX];
+    }
+  }
+}
+
+constexpr int MG_MAX_PARTIALS = 64;
+
+__global__ void __launch_bounds__(GB)
+mouth_glue_backward_kernel(int N, int KX, int KA, int KM, const float* __restrict__ d_sigma /*[N,KX+KA+KM] or null*/,
+                           const float* __restrict__ d_scaler /*[N,KX+KM] or null*/, float* __restrict__ d_enc_x,
+                           float* __restrict__ col_partials /*[gridDim.x][KA]*/) {
+  __shared__ float s_col[GB / 64][32];
+  const int K1 = KX + KA + KM, K2 = KX + KM;
+  const int rows_per = (N + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = min(N, r0 + rows_per);
+  // d_enc_x: thread per element of this workgroup's rows
+  for (int i = threadIdx.x; i < (r1 - r0) * KX; i += GB) {
+    const int r = r0 + i / KX, c = i % KX;
+    d_enc_x[(size_t)r * KX + c] = (d_sigma ? d_sigma[(size_t)r * K1 + c] : 0.f) + (d_scaler ? d_scaler[(size_t)r * K2 + c] : 0.f);
+  }
+  // column sums of the enc_a block: lane = column (KA <= 32), the 8 half-waves of the workgroup take rows in turn
+  const int col = threadIdx.x & 31, part = threadIdx.x >> 5;
+  float acc = 0.f;
+  if (d_sigma && col < KA)
+    for (int r = r0 + part; r < r1; r += GB / 32) acc += d_sigma[(size_t)r * K1 + KX + col];
+  acc += __shfl_xor(acc, 32);
+  if ((threadIdx.x & 63) < 32) s_col[threadIdx.x >> 6][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < KA)
+    col_partials[(size_t)blockIdx.x * KA + threadIdx.x] =
+        ((s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + s_col[2][threadIdx.x]) + s_col[3][threadIdx.x];
+}
+
 __global__ void __launch_bounds__(GB)
 deform_activate_backward_kernel(int N, const float* __restrict__ scaling, const float* __restrict__ rotation,
                                 const float* __restrict__ opacity, const float* __restrict__ h,
@@ -490,6 +568,54 @@ int instag_deform_activate_backward(const float* scaling, const float* rotation,
 }
 
 int instag_deform_activate_num_reg_partials(int32_t N) { return (N + GB - 1) / GB; }
+
+int instag_abs_mean_num_partials(int32_t N) { return std::max(1, std::min(AM_MAX_PARTIALS, (N + GB - 1) / GB)); }
+
+int instag_abs_mean_forward(const float* x, int32_t N, int32_t stride, int32_t ncols, float scale, float* partials,
+                            instag_stream_t stream) {
+  INSTAG_REQUIRE(x && partials, "abs_mean_forward: NULL tensor");
+  INSTAG_REQUIRE(N >= 1 && ncols >= 1 && ncols <= stride, "abs_mean: need N >= 1 and 1 <= ncols <= stride");
+  abs_mean_forward_kernel<<<instag_abs_mean_num_partials(N), GB, 0, (hipStream_t)stream>>>(N, stride, ncols, scale, x, partials);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_abs_mean_backward(const float* x, const float* g, int32_t N, int32_t stride, int32_t ncols, float scale,
+                             float* dx, instag_stream_t stream) {
+  INSTAG_REQUIRE(x && g && dx, "abs_mean_backward: NULL tensor");
+  INSTAG_REQUIRE(N >= 1 && ncols >= 1 && ncols <= stride, "abs_mean: need N >= 1 and 1 <= ncols <= stride");
+  INSTAG_REQUIRE((long long)N * stride <= 0x7fffffffll, "abs_mean: tensor too large");
+  abs_mean_backward_kernel<<<(N * stride + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, stride, ncols, scale, x, g, dx);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_mouth_glue_forward(const float* enc_x, const float* enc_a, const float* move, float* in_sigma,
+                              float* in_scaler, int32_t N, int32_t KX, int32_t KA, int32_t KM, instag_stream_t stream) {
+  INSTAG_REQUIRE(enc_x && enc_a && move && in_sigma && in_scaler, "mouth_glue_forward: NULL tensor");
+  INSTAG_REQUIRE(KX >= 1 && KA >= 1 && KA <= 32 && KM >= 1, "mouth_glue: need KX >= 1, 1 <= KA <= 32, KM >= 1");
+  if (N <= 0) return INSTAG_OK;
+  const long long total = (long long)N * (2 * KX + KA + 2 * KM);
+  const int blocks = (int)std::max(1ll, std::min(2048ll, (total + GB - 1) / GB));
+  mouth_glue_forward_kernel<<<blocks, GB, 0, (hipStream_t)stream>>>(N, KX, KA, KM, enc_x, enc_a, move, in_sigma, in_scaler);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_mouth_glue_backward_num_partials(int32_t N) { return std::max(1, std::min(MG_MAX_PARTIALS, (N + GB - 1) / GB)); }
+
+int instag_mouth_glue_backward(const float* d_sigma, const float* d_scaler, float* d_enc_x, float* col_partials,
+                               int32_t N, int32_t KX, int32_t KA, int32_t KM, instag_stream_t stream) {
+  INSTAG_REQUIRE(d_enc_x && col_partials, "mouth_glue_backward: NULL tensor");
+  INSTAG_REQUIRE(KX >= 1 && KA >= 1 && KA <= 32 && KM >= 1, "mouth_glue: need KX >= 1, 1 <= KA <= 32, KM >= 1");
+  INSTAG_REQUIRE(N >= 1, "mouth_glue_backward: N must be >= 1");
+  mouth_glue_backward_kernel<<<instag_mouth_glue_backward_num_partials(N), GB, 0, (hipStream_t)stream>>>(
+      N, KX, KA, KM, d_sigma, d_scaler, d_enc_x, col_partials);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+
 
 int instag_mouth_activate_forward(const float* xyz, const float* scaling, const float* rotation, const float* opacity,
                                   const float* h, const float* hs, float sx, float sy, float sz, float* means3D,

@@ -283,6 +283,80 @@ def mouth_activate(xyz, scaling, rotation, opacity, h, hs, xyz_scale=(1e-2 / 5, 
     return _MouthActivate.apply(xyz, scaling, rotation, opacity, h, hs, tuple(float(v) for v in xyz_scale))
 
 
+class _AbsMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ncols, scale):
+        L = _lib.lib()
+        x = _c(x)
+        N, stride = x.shape
+        part = torch.empty(L.instag_abs_mean_num_partials(N), dtype=torch.float32, device=x.device)
+        check(L.instag_abs_mean_forward(ptr(x), N, stride, int(ncols), float(scale), ptr(part), _lib.current_stream()),
+              "abs_mean_forward")
+        ctx.save_for_backward(x)
+        ctx.meta = (int(ncols), float(scale))
+        return part
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        (x,) = ctx.saved_tensors
+        ncols, scale = ctx.meta
+        N, stride = x.shape
+        # every partial sum feeds the same scalar: its upstream gradient is one number
+        g1 = g.reshape(-1)[:1].contiguous().float()
+        dx = torch.empty_like(x)
+        check(L.instag_abs_mean_backward(ptr(x), ptr(g1), N, stride, ncols, scale, ptr(dx), _lib.current_stream()),
+              "abs_mean_backward")
+        return dx, None, None
+
+
+def abs_mean_partials(x, ncols, scale=1.0):
+    """Partial sums of mean|x[:, :ncols] * scale| (x [N, C] on the device): sum them, or hand them to
+    ``losses.face_loss / mouth_loss_fused`` as the ``extra`` array (train_mouth.py:203 with x = the alignment head's raw
+    output and scale = 1e-2)."""
+    return _AbsMean.apply(x, ncols, scale)
+
+
+class _MouthGlue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc_x, enc_a, move):
+        L = _lib.lib()
+        enc_x, enc_a, move = _c(enc_x), _c(enc_a).reshape(-1), _c(move).reshape(-1)
+        N, KX = enc_x.shape
+        KA, KM = enc_a.numel(), move.numel()
+        in_sigma = torch.empty(N, KX + KA + KM, dtype=torch.float32, device=enc_x.device)
+        in_scaler = torch.empty(N, KX + KM, dtype=torch.float32, device=enc_x.device)
+        check(L.instag_mouth_glue_forward(ptr(enc_x), ptr(enc_a), ptr(move), ptr(in_sigma), ptr(in_scaler), N, KX, KA, KM,
+                                          _lib.current_stream()), "mouth_glue_forward")
+        ctx.dims = (N, KX, KA, KM)
+        return in_sigma, in_scaler
+
+    @staticmethod
+    def backward(ctx, d_sigma, d_scaler):
+        L = _lib.lib()
+        N, KX, KA, KM = ctx.dims
+        dev = (d_sigma if d_sigma is not None else d_scaler).device
+        d_sigma = None if d_sigma is None else _c(d_sigma)
+        d_scaler = None if d_scaler is None else _c(d_scaler)
+        d_enc_x = torch.empty(N, KX, dtype=torch.float32, device=dev)
+        parts = torch.empty(L.instag_mouth_glue_backward_num_partials(N), KA, dtype=torch.float32, device=dev)
+        check(L.instag_mouth_glue_backward(ptr(d_sigma), ptr(d_scaler), ptr(d_enc_x), ptr(parts), N, KX, KA, KM,
+                                           _lib.current_stream()), "mouth_glue_backward")
+        d_enc_a = parts.sum(0, keepdim=True) if ctx.needs_input_grad[1] else None
+        return d_enc_x, d_enc_a, None
+
+
+def mouth_glue(enc_x, enc_a, move):
+    """(in_sigma, in_scaler) = (cat[enc_x, enc_a.repeat, move.repeat], cat[enc_x, move.repeat]) of the mouth field
+    (scene/motion_net.py:437-444) in one launch per pass; enc_a [1,KA<=32], move [1,KM] (no gradient)."""
+    return _MouthGlue.apply(enc_x, enc_a, move)
+
+
+def mouth_glue_supported(enc_x, enc_a, move) -> bool:
+    return (enc_x.is_cuda and enc_x.dim() == 2 and enc_x.dtype == torch.float32 and enc_a.numel() <= 32
+            and enc_a.dtype == torch.float32 and move.dtype == torch.float32 and not move.requires_grad)
+
+
 class _MotionL1Reg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, p):

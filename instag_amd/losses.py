@@ -289,13 +289,19 @@ def face_loss(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None, attn=
     return _FusedFaceLoss.apply(image, alpha, attn, extra, gt, face_mask, hair_mask, mouth_mask, bg, lips_rect, cfg)
 
 
-def mouth_loss_fused(image, alpha, gt, mouth_mask, lips_rect, bg, p_xyz=None, warm=True, lambda_dssim=0.2):
+def mouth_loss_fused(image, alpha, gt, mouth_mask, lips_rect, bg, p_xyz=None, warm=True, lambda_dssim=0.2, p_raw=None):
     """Loss block of the mouth branch (train_mouth.py:186-221) on the device -> (loss, Ll1): the face branch's fused
     kernels in their mouth mode (csrc/ssim.hip F_MOUTH) -- two launches forward, one backward, instead of ~45 elementwise
-    / reduce launches.  ``lips_rect`` = int32 [4] (row0, row1, col0, col1) on the device."""
+    / reduce launches.  ``lips_rect`` = int32 [4] (row0, row1, col0, col1) on the device.  ``p_raw`` (optional): the
+    alignment head's raw output [N, >=3] that ``p_xyz`` = p_raw[:, :3] * 1e-2 was made of (used instead of p_xyz)."""
     flags = FLAG_MOUTH | (FLAG_ALPHA if warm else 0)
     extra = None
-    if warm and p_xyz is not None:
+    if warm and p_raw is not None and p_raw.is_cuda and p_raw.dim() == 2 and p_raw.shape[1] >= 3:
+        # mean|p_xyz| with p_xyz = p[:, :3] * 1e-2 as partial sums the loss kernel adds up: one launch per pass instead
+        # of the slice / scale / abs / mean chain and its five backward launches
+        from .glue import abs_mean_partials
+        extra = abs_mean_partials(p_raw, 3, 1e-2)
+    elif warm and p_xyz is not None:
         extra = p_xyz.abs().mean().reshape(1)
     cfg = (flags, float(lambda_dssim), 1e-3, 0.0, 0.0, 1e-5)
     return _FusedFaceLoss.apply(image, alpha if warm else None, None, extra, gt, None, None, mouth_mask, bg,

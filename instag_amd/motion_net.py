@@ -436,9 +436,11 @@ class MouthMotionNetwork(nn.Module):
         ev.record(torch.cuda.current_stream(a.device))
         self._audio_pending = (a, ev, _side_stream(a.device, stream_index))
 
-    def forward(self, x, a, move):
+    def forward(self, x, a, move, x_shift=None):
+        """Reference signature (x, a, move).  Extension: ``x_shift`` = (tensor, scale) evaluates the field at
+        x + scale * tensor[:, :3] without materialising the sum (the mouth render's xyz + p_xyz)."""
         pending = self.__dict__.pop("_audio_pending", None)
-        enc_x = self.encode_x(x, bound=self.bound)
+        enc_x = self.encode_x(x, bound=self.bound, shift=x_shift)
         if pending is not None and pending[0] is a:
             # the audio branch depends on the frame only: on its own stream from the point the caller announced it
             main_stream, side = torch.cuda.current_stream(a.device), pending[2]
@@ -451,9 +453,15 @@ class MouthMotionNetwork(nn.Module):
         else:
             enc_a = self.encode_audio(a)
         n = enc_x.shape[0]
-        move = move.repeat(n, 1)
-        h = self.sigma_net(torch.cat([enc_x, enc_a.repeat(n, 1), move], dim=-1))
-        h_s = self.scaler_net(torch.cat([enc_x, move], dim=-1))
+        from . import glue as _glue
+        if enc_x.is_cuda and _glue.mouth_glue_supported(enc_x, enc_a, move):
+            in_sigma, in_scaler = _glue.mouth_glue(enc_x, enc_a, move)        # both inputs in one launch per pass
+        else:
+            move = move.repeat(n, 1)
+            in_sigma = torch.cat([enc_x, enc_a.repeat(n, 1), move], dim=-1)
+            in_scaler = torch.cat([enc_x, move], dim=-1)
+        h = self.sigma_net(in_sigma)
+        h_s = self.scaler_net(in_scaler)
         # d_xyz = h[:, :3] * scale (the reference's in-place edits as one multiply) gated by sigmoid(h_s) * 2; the fused
         # render path consumes the raw head outputs (glue.mouth_activate), the dictionary entries are built on access
         return LazyOutputs({"d_xyz": lambda: (h[..., :3] * self._xyz_scale) * torch.sigmoid(h_s) * 2,

@@ -283,6 +283,22 @@ def _extreme_values(v, k):
     return _top_values(v, k, True), _top_values(v, k, False)
 
 
+def _jaw_feature(h, column, scale, k):
+    """[1,3] = [max, min, max - min] * 1e2 of the k-th largest / smallest value of scale * h[:, column] in one operator
+    (csrc/select.hip instag_jaw_feature).  ``k``: int, or int64 tensor on the device (clamped to [1, 50])."""
+    from . import _lib
+    L = _lib.lib()
+    N, stride = h.shape[0], h.shape[1]
+    dev_k = torch.is_tensor(k)
+    kmax = min(50, N) if dev_k else min(int(k), N)
+    out = torch.empty(1, 3, dtype=torch.float32, device=h.device)
+    ws = torch.empty(L.instag_jaw_feature_workspace_bytes(N, kmax), dtype=torch.uint8, device=h.device)
+    _lib.check(L.instag_jaw_feature(_lib.ptr(h), N, stride, column, float(scale), kmax, _lib.ptr(k) if dev_k else None,
+                                    0 if dev_k else kmax, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.current_stream()),
+               "jaw_feature")
+    return out
+
+
 def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_net_face, pipe=None, bg_color=None,
                             scaling_modifier=1.0, frame_idx=None, return_attn=False, personalized=False, align=False,
                             k=10, inference=False):
@@ -306,29 +322,45 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
     p_motion_preds = None
     if personalized or align:
         p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat)
+    x_shift = None
     if align:
-        xyz = xyz + p_motion_preds["p_xyz"]
+        p_raw = dict.get(p_motion_preds, "_p")
+        if torch.is_tensor(p_raw) and xyz.is_cuda and getattr(motion_net, "XYZ_SCALE", None) is not None:
+            x_shift = (p_raw, 1e-2)           # xyz + p_xyz (= p[:, :3] * 1e-2) is formed inside the tri-plane kernel
+        else:
+            xyz = xyz + p_motion_preds["p_xyz"]
     if not inference:
         if exp_feat is None:
             exp_feat = torch.zeros_like(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
         motion_preds_face = motion_net_face(pc_face.get_xyz, audio_feat, exp_feat)
     else:
         motion_preds_face = motion_net_face.cache
-    with torch.no_grad():
-        dy = motion_preds_face["d_xyz"][..., 1]
-        if torch.is_tensor(k):
-            # k on the device (int64 [1], 1 <= k <= 50): a captured step draws a new k per replay without a host
-            # round trip -- the 50 largest / smallest once, the k-th of them by index
-            kmax = min(50, dy.shape[0])
-            kidx = (k.reshape(1) - 1).clamp(0, kmax - 1)
-            top, bottom = _extreme_values(dy, kmax)
-            motion_max = top.gather(0, kidx)[0]
-            motion_min = bottom.gather(0, kidx)[0]
-        else:
-            top, bottom = _extreme_values(dy, k)
-            motion_max, motion_min = top[-1], bottom[-1]
-        move_feat = torch.stack([motion_max, motion_min, motion_max - motion_min]).reshape(1, 3) * 1e2
-    motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
+    h_face = None if inference else dict.get(motion_preds_face, "_h")
+    if (torch.is_tensor(h_face) and h_face.is_cuda and h_face.dim() == 2 and h_face.is_contiguous()
+            and h_face.dtype == torch.float32 and h_face.shape[0] >= 1 and (torch.is_tensor(k) or 1 <= int(k) <= 64)
+            and (not torch.is_tensor(k) or (k.is_cuda and k.dtype == torch.int64))):
+        # d_xyz[:, 1] = h[:, 1] * 1e-2 (scene/motion_net.py:330): selection, gather and the three products in one operator
+        with torch.no_grad():
+            move_feat = _jaw_feature(h_face.detach(), 1, 1e-2, k)
+    else:
+        with torch.no_grad():
+            dy = motion_preds_face["d_xyz"][..., 1]
+            if torch.is_tensor(k):
+                # k on the device (int64 [1], 1 <= k <= 50): a captured step draws a new k per replay without a host
+                # round trip -- the 50 largest / smallest once, the k-th of them by index
+                kmax = min(50, dy.shape[0])
+                kidx = (k.reshape(1) - 1).clamp(0, kmax - 1)
+                top, bottom = _extreme_values(dy, kmax)
+                motion_max = top.gather(0, kidx)[0]
+                motion_min = bottom.gather(0, kidx)[0]
+            else:
+                top, bottom = _extreme_values(dy, k)
+                motion_max, motion_min = top[-1], bottom[-1]
+            move_feat = torch.stack([motion_max, motion_min, motion_max - motion_min]).reshape(1, 3) * 1e2
+    if x_shift is not None:
+        motion_preds = motion_net(xyz, audio_feat, move_feat.detach(), x_shift=x_shift)
+    else:
+        motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
     h_raw, hs_raw = dict.get(motion_preds, "_h"), dict.get(motion_preds, "_hs")
     if (not personalized and torch.is_tensor(h_raw) and torch.is_tensor(hs_raw) and h_raw.is_cuda
             and h_raw.shape[-1] == 7):

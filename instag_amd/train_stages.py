@@ -232,13 +232,16 @@ class MouthTrainer:
         td = frame.talking_dict
         dev = self.device
         mouth = td["mouth_mask"].to(dev)
-        p_xyz = pkg["p_motion"]["p_xyz"] if (phase.warm and pkg["p_motion"] is not None) else None
+        want_p = phase.warm and pkg["p_motion"] is not None
         if self.on_gpu and torch.is_tensor(td["lips_rect"]) and pkg["render"].shape[0] == 3:
             from .losses import mouth_loss_fused
+            p_raw = dict.get(pkg["p_motion"], "_p") if want_p else None
+            p_xyz = pkg["p_motion"]["p_xyz"] if (want_p and p_raw is None) else None
             loss, Ll1 = mouth_loss_fused(pkg["render"], pkg["alpha"], frame.original_image.to(dev), mouth,
                                          td["lips_rect"].to(dev), bg, p_xyz, warm=phase.warm,
-                                         lambda_dssim=self.opt.lambda_dssim)
+                                         lambda_dssim=self.opt.lambda_dssim, p_raw=p_raw)
             return pkg, loss, Ll1
+        p_xyz = pkg["p_motion"]["p_xyz"] if want_p else None
         lips = _lips_mask(mouth, td["lips_rect"])
         loss, Ll1 = mouth_loss(pkg["render"], pkg["alpha"], frame.original_image.to(dev), mouth, lips, bg, p_xyz,
                                warm=phase.warm, lambda_dssim=self.opt.lambda_dssim)

@@ -525,3 +525,58 @@ def test_mouth_activate_matches_plain_torch():
     for a, b in zip(grads[0], grads[1]):
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
     assert float(grads[1][4][:, 3:].abs().max()) == 0.0          # the predicted rotation is not applied
+
+
+def test_abs_mean_partials_match_torch():
+    from instag_amd.glue import abs_mean_partials
+    torch.manual_seed(5)
+    p = torch.randn(20011, 6, device="cuda")
+    p[7, 1] = 0.0                                                   # sign(0) = 0
+    p.requires_grad_(True)
+    want = (p[:, :3] * 1e-2).abs().mean()
+    (want * 3.0).backward()
+    g_want = p.grad.clone()
+    p.grad = None
+    got = abs_mean_partials(p, 3, 1e-2).sum()
+    (got * 3.0).backward()
+    assert abs(float(got) - float(want)) <= 2e-6 * float(want)
+    assert float((p.grad - g_want).abs().max()) <= 1e-12 + 1e-6 * float(g_want.abs().max())
+    assert float(p.grad[:, 3:].abs().max()) == 0.0
+
+
+def test_mouth_glue_matches_cat_and_repeat():
+    from instag_amd.glue import mouth_glue
+    torch.manual_seed(6)
+    n = 20003
+    enc_x = torch.randn(n, 36, device="cuda").requires_grad_(True)
+    enc_a = torch.randn(1, 32, device="cuda").requires_grad_(True)
+    move = torch.randn(1, 3, device="cuda")
+    w1, w2 = torch.randn(n, 71, device="cuda"), torch.randn(n, 39, device="cuda")
+
+    def plain():
+        m = move.repeat(n, 1)
+        return torch.cat([enc_x, enc_a.repeat(n, 1), m], -1), torch.cat([enc_x, m], -1)
+
+    res = []
+    for fn in (plain, lambda: mouth_glue(enc_x, enc_a, move)):
+        enc_x.grad = enc_a.grad = None
+        a, b = fn()
+        ((a * w1).sum() + (b * w2).sum()).backward()
+        res.append((a.detach().clone(), b.detach().clone(), enc_x.grad.clone(), enc_a.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float((res[0][2] - res[1][2]).abs().max()) <= 1e-6 * float(res[0][2].abs().max())
+    assert float((res[0][3] - res[1][3]).abs().max()) <= 2e-5 * float(res[0][3].abs().max())
+
+
+@pytest.mark.parametrize("n", [900, 100000])
+def test_jaw_feature_matches_topk(n):
+    from instag_amd.renderer import _jaw_feature
+    torch.manual_seed(8)
+    h = torch.randn(n, 11, device="cuda")
+    dy = h[:, 1] * 1e-2
+    for k in (1, 10, 50):
+        mx, mn = dy.topk(k).values[-1], dy.topk(k, largest=False).values[-1]
+        want = torch.stack([mx, mn, mx - mn]).reshape(1, 3) * 1e2
+        assert torch.equal(_jaw_feature(h, 1, 1e-2, k), want)
+        kd = torch.tensor([k], dtype=torch.int64, device="cuda")
+        assert torch.equal(_jaw_feature(h, 1, 1e-2, kd), want)
