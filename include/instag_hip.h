@@ -383,6 +383,16 @@ int instag_mouth_glue_forward(const float* enc_x, const float* enc_a, const floa
 int instag_mouth_glue_backward_num_partials(int32_t N);
 int instag_mouth_glue_backward(const float* d_sigma, const float* d_scaler, float* d_enc_x, float* col_partials,
                                int32_t N, int32_t KX, int32_t KA, int32_t KM, instag_stream_t stream);
+/* fuse_compose (train_fuse_con.py:102-121): face, mouth [3,H,W] rendered over bg [3], a_face, a_mouth [1,H,W], scene
+ * [3,H,W] or NULL (= black) -> mouth_image = mouth - bg (1 - a_mouth) + scene (1 - a_mouth), image = face - bg (1 - a_face)
+ * + mouth_image (1 - a_face).  backward: g_image / g_mouth_image (either may be NULL) -> gradients of the four inputs. */
+int instag_fuse_compose_forward(const float* face, const float* a_face, const float* mouth, const float* a_mouth,
+                                const float* bg, const float* scene, float* image, float* mouth_image, int32_t H,
+                                int32_t W, instag_stream_t stream);
+int instag_fuse_compose_backward(const float* g_image, const float* g_mouth_image, const float* a_face,
+                                 const float* mouth_image, const float* bg, const float* scene, float* d_face,
+                                 float* d_a_face, float* d_mouth, float* d_a_mouth, int32_t H, int32_t W,
+                                 instag_stream_t stream);
 int instag_motion_l1_reg_num_partials(int32_t N);
 int instag_motion_l1_reg_forward(const float* h, const float* p, float* partial, int32_t N,
                                  instag_stream_t stream);

@@ -156,6 +156,8 @@ _PROTOS = {
     "instag_mouth_glue_forward": (C.c_int, [vp] * 5 + [i32] * 4 + [vp]),
     "instag_mouth_glue_backward_num_partials": (C.c_int, [i32]),
     "instag_mouth_glue_backward": (C.c_int, [vp] * 4 + [i32] * 4 + [vp]),
+    "instag_fuse_compose_forward": (C.c_int, [vp] * 8 + [i32, i32, vp]),
+    "instag_fuse_compose_backward": (C.c_int, [vp] * 10 + [i32, i32, vp]),
     "instag_mouth_activate_forward": (C.c_int, [vp] * 6 + [f32] * 3 + [vp] * 4 + [i32, vp]),
     "instag_mouth_activate_backward": (C.c_int, [vp] * 5 + [f32] * 3 + [vp] * 10 + [i32, vp]),
     "instag_motion_l1_reg_num_partials": (C.c_int, [i32]),

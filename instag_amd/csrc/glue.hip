@@ -353,6 +353,51 @@ mouth_glue_backward_kernel(int N, int KX, int KA, int KM, const float* __restric
         ((s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + s_col[2][threadIdx.x]) + s_col[3][threadIdx.x];
 }
 
+// ---- fuse stage composition (train_fuse_con.py:102-121): both passes were rendered over bg; bg is taken out again and
+// the mouth shows through the face, the scene background through both --------------------------------------------------
+//   mouth_image = mouth - bg (1 - a_m) + scene (1 - a_m);   image = face - bg (1 - a_f) + mouth_image (1 - a_f)
+__global__ void __launch_bounds__(GB)
+fuse_compose_forward_kernel(int HW, const float* __restrict__ face, const float* __restrict__ a_face,
+                            const float* __restrict__ mouth, const float* __restrict__ a_mouth,
+                            const float* __restrict__ bg /*[3]*/, const float* __restrict__ scene /*[3,HW] or null*/,
+                            float* __restrict__ image, float* __restrict__ mouth_image) {
+  const int i = blockIdx.x * GB + threadIdx.x;
+  if (i >= HW) return;
+  const float tf = 1.0f - a_face[i], tm = 1.0f - a_mouth[i];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float sc = scene ? scene[c * HW + i] : 0.f;
+    const float mi = (mouth[c * HW + i] - bg[c] * tm) + sc * tm;
+    mouth_image[c * HW + i] = mi;
+    image[c * HW + i] = (face[c * HW + i] - bg[c] * tf) + mi * tf;
+  }
+}
+
+__global__ void __launch_bounds__(GB)
+fuse_compose_backward_kernel(int HW, const float* __restrict__ g_image /*[3,HW] or null*/,
+                             const float* __restrict__ g_mouth_image /*[3,HW] or null*/,
+                             const float* __restrict__ a_face, const float* __restrict__ mouth_image,
+                             const float* __restrict__ bg, const float* __restrict__ scene,
+                             float* __restrict__ d_face, float* __restrict__ d_a_face, float* __restrict__ d_mouth,
+                             float* __restrict__ d_a_mouth) {
+  const int i = blockIdx.x * GB + threadIdx.x;
+  if (i >= HW) return;
+  const float tf = 1.0f - a_face[i];
+  float da_f = 0.f, da_m = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float g = g_image ? g_image[c * HW + i] : 0.f;
+    const float sc = scene ? scene[c * HW + i] : 0.f;
+    d_face[c * HW + i] = g;
+    da_f += g * (bg[c] - mouth_image[c * HW + i]);           // d/d a_f of -bg (1 - a_f) + mouth_image (1 - a_f)
+    const float dmi = g * tf + (g_mouth_image ? g_mouth_image[c * HW + i] : 0.f);
+    d_mouth[c * HW + i] = dmi;
+    da_m += dmi * (bg[c] - sc);
+  }
+  d_a_face[i] = da_f;
+  d_a_mouth[i] = da_m;
+}
+
 __global__ void __launch_bounds__(GB)
 deform_activate_backward_kernel(int N, const float* __restrict__ scaling, const float* __restrict__ rotation,
                                 const float* __restrict__ opacity, const float* __restrict__ h,
@@ -568,6 +613,34 @@ int instag_deform_activate_backward(const float* scaling, const float* rotation,
 }
 
 int instag_deform_activate_num_reg_partials(int32_t N) { return (N + GB - 1) / GB; }
+
+int instag_fuse_compose_forward(const float* face, const float* a_face, const float* mouth, const float* a_mouth,
+                                const float* bg, const float* scene, float* image, float* mouth_image, int32_t H,
+                                int32_t W, instag_stream_t stream) {
+  INSTAG_REQUIRE(face && a_face && mouth && a_mouth && bg && image && mouth_image, "fuse_compose_forward: NULL tensor");
+  INSTAG_REQUIRE(H >= 1 && W >= 1, "fuse_compose: empty image");
+  const int HW = H * W;
+  fuse_compose_forward_kernel<<<(HW + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(HW, face, a_face, mouth, a_mouth, bg,
+                                                                                 scene, image, mouth_image);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_fuse_compose_backward(const float* g_image, const float* g_mouth_image, const float* a_face,
+                                 const float* mouth_image, const float* bg, const float* scene, float* d_face,
+                                 float* d_a_face, float* d_mouth, float* d_a_mouth, int32_t H, int32_t W,
+                                 instag_stream_t stream) {
+  INSTAG_REQUIRE(a_face && mouth_image && bg && d_face && d_a_face && d_mouth && d_a_mouth,
+                 "fuse_compose_backward: NULL tensor");
+  INSTAG_REQUIRE(H >= 1 && W >= 1, "fuse_compose: empty image");
+  const int HW = H * W;
+  fuse_compose_backward_kernel<<<(HW + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(
+      HW, g_image, g_mouth_image, a_face, mouth_image, bg, scene, d_face, d_a_face, d_mouth, d_a_mouth);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+
 
 int instag_abs_mean_num_partials(int32_t N) { return std::max(1, std::min(AM_MAX_PARTIALS, (N + GB - 1) / GB)); }
 

@@ -357,6 +357,46 @@ def mouth_glue_supported(enc_x, enc_a, move) -> bool:
             and enc_a.dtype == torch.float32 and move.dtype == torch.float32 and not move.requires_grad)
 
 
+class _FuseCompose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, face, a_face, mouth, a_mouth, bg, scene):
+        L = _lib.lib()
+        ctx.set_materialize_grads(False)
+        face, a_face, mouth, a_mouth, bg = (_c(t) for t in (face, a_face, mouth, a_mouth, bg))
+        scene = None if scene is None else _c(scene)
+        _, H, W = face.shape
+        image, mouth_image = torch.empty_like(face), torch.empty_like(face)
+        check(L.instag_fuse_compose_forward(ptr(face), ptr(a_face), ptr(mouth), ptr(a_mouth), ptr(bg), ptr(scene),
+                                            ptr(image), ptr(mouth_image), H, W, _lib.current_stream()),
+              "fuse_compose_forward")
+        ctx.save_for_backward(a_face, mouth_image, bg, *([scene] if scene is not None else []))
+        ctx.shapes = (tuple(a_face.shape), tuple(a_mouth.shape))
+        return image, mouth_image
+
+    @staticmethod
+    def backward(ctx, g_image, g_mouth_image):
+        L = _lib.lib()
+        saved = ctx.saved_tensors
+        a_face, mouth_image, bg = saved[:3]
+        scene = saved[3] if len(saved) > 3 else None
+        _, H, W = mouth_image.shape
+        g_image = None if g_image is None else _c(g_image)
+        g_mouth_image = None if g_mouth_image is None else _c(g_mouth_image)
+        d_face, d_mouth = torch.empty_like(mouth_image), torch.empty_like(mouth_image)
+        d_af = torch.empty(ctx.shapes[0], dtype=torch.float32, device=mouth_image.device)
+        d_am = torch.empty(ctx.shapes[1], dtype=torch.float32, device=mouth_image.device)
+        check(L.instag_fuse_compose_backward(ptr(g_image), ptr(g_mouth_image), ptr(a_face), ptr(mouth_image), ptr(bg),
+                                             ptr(scene), ptr(d_face), ptr(d_af), ptr(d_mouth), ptr(d_am), H, W,
+                                             _lib.current_stream()), "fuse_compose_backward")
+        return d_face, d_af, d_mouth, d_am, None, None
+
+
+def fuse_compose(face, a_face, mouth, a_mouth, bg, scene=None):
+    """(image, mouth_image) of the fuse stage (train_fuse_con.py:102-121) in one launch per pass; face / mouth [3,H,W],
+    the alphas [1,H,W], bg [3], scene [3,H,W] or None (black)."""
+    return _FuseCompose.apply(face, a_face, mouth, a_mouth, bg, scene)
+
+
 class _MotionL1Reg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, p):

@@ -580,3 +580,32 @@ def test_jaw_feature_matches_topk(n):
         assert torch.equal(_jaw_feature(h, 1, 1e-2, k), want)
         kd = torch.tensor([k], dtype=torch.int64, device="cuda")
         assert torch.equal(_jaw_feature(h, 1, 1e-2, kd), want)
+
+
+@pytest.mark.parametrize("with_scene", [False, True])
+def test_fuse_compose_matches_plain_torch(with_scene):
+    from instag_amd.glue import fuse_compose
+    torch.manual_seed(9)
+    H, W = 67, 131
+    mk = lambda *s: torch.rand(*s, device="cuda").requires_grad_(True)
+    face, mouth, af, am = mk(3, H, W), mk(3, H, W), mk(1, H, W), mk(1, H, W)
+    bg = torch.tensor([0.0, 1.0, 0.0], device="cuda")
+    scene = torch.rand(3, H, W, device="cuda") if with_scene else None
+    w1, w2 = torch.randn(3, H, W, device="cuda"), torch.randn(3, H, W, device="cuda")
+
+    def plain():
+        bg3 = bg[:, None, None]
+        sb = scene if scene is not None else torch.zeros_like(face)
+        mi = mouth - bg3 * (1.0 - am) + sb * (1.0 - am)
+        return face - bg3 * (1.0 - af) + mi * (1.0 - af), mi
+
+    res = []
+    for fn in (plain, lambda: fuse_compose(face, af, mouth, am, bg, scene)):
+        for t in (face, mouth, af, am):
+            t.grad = None
+        img, mi = fn()
+        ((img * w1).sum() + (mi * w2).sum()).backward()
+        res.append([img.detach().clone(), mi.detach().clone()] + [t.grad.clone() for t in (face, mouth, af, am)])
+    for a, b in zip(res[0], res[1]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
