@@ -17,6 +17,7 @@ from .motion_net import MotionNetwork as _MotionNetwork
 
 CONCURRENT_PASSES = True      # fork the attention raster pass(es) onto a second stream
 SHARED_ATTN_PASS = True       # attention map as an auxiliary colour set of the main raster pass
+CONCURRENT_FUSE_PASSES = True  # fuse stage (training): the mouth pass on a second stream beside the face pass
 
 
 _SIDE_STREAMS = {}
@@ -24,8 +25,12 @@ _SIDE_STREAMS = {}
 
 def _side_stream(device):
     """Second HIP stream per device: independent work (the attention raster pass) is forked onto it so that it
-    overlaps the main pass -- both blend kernels are bound by their longest tile and leave most CUs idle."""
-    key = (device.type, device.index)
+    overlaps the main pass -- both blend kernels are bound by their longest tile and leave most CUs idle.
+    ``device`` may be a (device, tag) pair: a separate stream per purpose."""
+    tag = None
+    if isinstance(device, tuple):
+        device, tag = device
+    key = (device.type, device.index, tag)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
@@ -390,9 +395,26 @@ def render_fuse(viewpoint_camera, pc, motion_net, pc_mouth, motion_net_mouth, pi
     and were rendered over ``bg_color``, which is taken out again) / synthesize_fuse.py:46-66 (inference: the mouth
     field reads the face field's cached motion).  ``scene_background`` [3,H,W] in [0,1] is what shows through both.
     -> dict(image, face=<render_motion pkg>, mouth=<render_motion_mouth_con pkg>)."""
-    face = render_motion(viewpoint_camera, pc, motion_net, pipe, bg_color, personalized=personalized, align=True)
-    mouth = render_motion_mouth_con(viewpoint_camera, pc_mouth, motion_net_mouth, pc, motion_net, pipe, bg_color,
-                                    personalized=personalized, align=True, k=k, inference=inference)
+    from . import _lib
+    dev = pc.get_xyz.device
+    if CONCURRENT_FUSE_PASSES and dev.type == "cuda" and not inference and _lib.may_fork(dev):
+        # In training the mouth pass re-evaluates the face field with a neutral expression (it does not read the face
+        # pass's cache): the two passes share nothing but parameters, so the mouth pass -- forward here, and with it
+        # its whole backward -- runs on a second stream beside the face pass.  Each pass alone is a chain of short
+        # kernels that leaves most of the chip idle.
+        main, side = torch.cuda.current_stream(dev), _side_stream((dev, "fuse"))
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            mouth = render_motion_mouth_con(viewpoint_camera, pc_mouth, motion_net_mouth, pc, motion_net, pipe, bg_color,
+                                            personalized=personalized, align=True, k=k, inference=False)
+        face = render_motion(viewpoint_camera, pc, motion_net, pipe, bg_color, personalized=personalized, align=True)
+        main.wait_stream(side)
+        for t in (mouth["render"], mouth["alpha"], mouth["depth"], mouth["radii"]):
+            _keepalive.cross_stream(t, main)
+    else:
+        face = render_motion(viewpoint_camera, pc, motion_net, pipe, bg_color, personalized=personalized, align=True)
+        mouth = render_motion_mouth_con(viewpoint_camera, pc_mouth, motion_net_mouth, pc, motion_net, pipe, bg_color,
+                                        personalized=personalized, align=True, k=k, inference=inference)
     alpha, alpha_mouth = face["alpha"], mouth["alpha"]
     fr, mr = face["render"], mouth["render"]
     if (fr.is_cuda and fr.dim() == 3 and fr.shape[0] == 3 and fr.dtype == torch.float32 and mr.shape == fr.shape
