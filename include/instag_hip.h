@@ -498,6 +498,7 @@ int instag_l1_ssim_backward(const float* img1, const float* img2, const float* m
  * [lips_rect[0], lips_rect[1]) x columns [lips_rect[2], lips_rect[3]); face_mask / hair_mask may be NULL, lips_rect is
  * required, none of the three face-branch flags may be set */
 #define INSTAG_FACE_LOSS_MOUTH 16
+#define INSTAG_FACE_LOSS_PLAIN 32     /* whole-frame L1 + DSSIM of image against gt (train_fuse_con.py:176-181): no masks, bg or rectangle */
 typedef struct {
   int32_t H, W, flags;
   float w_dssim, w_alpha, w_attn_hair, w_attn_lips, w_extra;

@@ -167,6 +167,9 @@ constexpr int F_HAIR_BG = 1, F_ALPHA = 2, F_HAIR_ATTN = 4, F_LIPS = 8;
 //   image_green = (lips ^ mouth) ? bg : image,  gt_green = mouth ? gt : bg,  alpha terms over the lips rectangle
 // (lips = rows [lips[0], lips[1]) x columns [lips[2], lips[3]) of the image); face / hair masks are not read.
 constexpr int F_MOUTH = 16;
+// F_PLAIN: whole-frame L1 + DSSIM of image against gt (the fuse stage, train_fuse_con.py:176-181): no mask, background
+// or rectangle is read
+constexpr int F_PLAIN = 32;
 
 struct FaceIn {
   const float* image; const float* gt; const uint8_t* face; const uint8_t* hair; const uint8_t* mouth;
@@ -179,6 +182,11 @@ __device__ __forceinline__ bool in_lips(const FaceIn& in, int gy, int gx) {
 
 __device__ __forceinline__ void face_pixel(const FaceCfg& cfg, const FaceIn& in, int c, size_t plane, size_t pix,
                                            float& x, float& y) {
+  if (cfg.flags & F_PLAIN) {
+    x = in.image[c * plane + pix];
+    y = in.gt[c * plane + pix];
+    return;
+  }
   const float bgc = in.bg[c];
   if (cfg.flags & F_MOUTH) {
     const int gy = (int)(pix / (size_t)cfg.W), gx = (int)(pix - (size_t)gy * cfg.W);
@@ -250,9 +258,9 @@ face_loss_forward_kernel(FaceCfg cfg, FaceIn in, float* __restrict__ maps, float
     v[0] = ssim_v;
     v[1] = fabsf(s_x[ty + RAD][tx + RAD] - s_y[ty + RAD][tx + RAD]);
     if (c == 0) {
-      const bool mouth_mode = (cfg.flags & F_MOUTH) != 0;
-      const bool hair = !mouth_mode && in.hair[pix] != 0;
-      const bool head = mouth_mode ? in_lips(in, gy, gx) : (hair || in.face[pix] != 0);
+      const bool mouth_mode = (cfg.flags & F_MOUTH) != 0, plain = (cfg.flags & F_PLAIN) != 0;
+      const bool hair = !mouth_mode && !plain && in.hair[pix] != 0;
+      const bool head = plain ? false : (mouth_mode ? in_lips(in, gy, gx) : (hair || in.face[pix] != 0));
       if (cfg.flags & F_ALPHA) {
         const float a = in.alpha[pix];
         v[2] = head ? 1.f - a : 0.f;
@@ -376,13 +384,14 @@ face_loss_backward_kernel(FaceCfg cfg, FaceIn in, const float* __restrict__ maps
   const float gs = -cfg.w_dssim * g;
   const float diff = x - y;
   const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-  const bool mouth_mode = (cfg.flags & F_MOUTH) != 0;
-  const bool hair = !mouth_mode && in.hair[pix] != 0;
+  const bool mouth_mode = (cfg.flags & F_MOUTH) != 0, plain = (cfg.flags & F_PLAIN) != 0;
+  const bool hair = !mouth_mode && !plain && in.hair[pix] != 0;
   // pixel overwritten by the background: no gradient
-  const bool frozen = mouth_mode ? (in_lips(in, gy, gx) != (in.mouth[pix] != 0)) : ((cfg.flags & F_HAIR_BG) && hair);
+  const bool frozen = plain ? false
+                            : (mouth_mode ? (in_lips(in, gy, gx) != (in.mouth[pix] != 0)) : ((cfg.flags & F_HAIR_BG) && hair));
   d_image[c * plane + pix] = frozen ? 0.f : (1.f / (float)C3) * (gs * (fm + 2.f * x * f11 + y * f12) + gl * sgn);
   if (c == 0) {
-    const bool head = mouth_mode ? in_lips(in, gy, gx) : (hair || in.face[pix] != 0);
+    const bool head = plain ? false : (mouth_mode ? in_lips(in, gy, gx) : (hair || in.face[pix] != 0));
     if (d_alpha) d_alpha[pix] = (cfg.flags & F_ALPHA) ? g * cfg.w_alpha / (float)plane * (head ? -1.f : 1.f) : 0.f;
     if (d_attn) {
       const float gh = ((cfg.flags & F_HAIR_ATTN) && hair) ? g * cfg.w_hair * out[3] : 0.f;
@@ -449,8 +458,10 @@ int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image
   FaceCfg c;
   if (int rc = face_cfg(cfg, &c)) return rc;
   const bool mouth_mode = (c.flags & F_MOUTH) != 0;
-  INSTAG_REQUIRE(image && gt && mouth_mask && bg && maps && partials && out && (mouth_mode || (face_mask && hair_mask)),
-                 "face_loss_forward: NULL tensor");
+  const bool plain = (c.flags & F_PLAIN) != 0;
+  INSTAG_REQUIRE(image && gt && maps && partials && out, "face_loss_forward: NULL tensor");
+  INSTAG_REQUIRE(plain || (mouth_mask && bg && (mouth_mode || (face_mask && hair_mask))), "face_loss_forward: NULL mask");
+  INSTAG_REQUIRE(!plain || !(c.flags & ~F_PLAIN), "face_loss_forward: the plain mode takes no other term");
   INSTAG_REQUIRE(!mouth_mode || (lips_rect && !(c.flags & (F_HAIR_BG | F_HAIR_ATTN | F_LIPS))),
                  "face_loss_forward: the mouth mode needs lips_rect and none of the face-branch terms");
   INSTAG_REQUIRE(!(c.flags & F_ALPHA) || alpha, "face_loss_forward: alpha term without alpha");
@@ -478,8 +489,9 @@ int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* imag
   FaceCfg c;
   if (int rc = face_cfg(cfg, &c)) return rc;
   const bool mouth_mode = (c.flags & F_MOUTH) != 0;
-  INSTAG_REQUIRE(image && gt && mouth_mask && bg && maps && out && d_image && (mouth_mode || (face_mask && hair_mask)),
-                 "face_loss_backward: NULL tensor");
+  const bool plain = (c.flags & F_PLAIN) != 0;
+  INSTAG_REQUIRE(image && gt && maps && out && d_image, "face_loss_backward: NULL tensor");
+  INSTAG_REQUIRE(plain || (mouth_mask && bg && (mouth_mode || (face_mask && hair_mask))), "face_loss_backward: NULL mask");
   INSTAG_REQUIRE(!mouth_mode || lips_rect, "face_loss_backward: the mouth mode needs lips_rect");
   INSTAG_REQUIRE(!(c.flags & F_LIPS) || lips_rect, "face_loss_backward: lips term without lips_rect");
   const FaceIn in{image, gt, face_mask, hair_mask, mouth_mask, bg, nullptr, nullptr, lips_rect, nullptr};

@@ -178,7 +178,7 @@ def l1_and_ssim(img1, img2):
 
 
 # ---- the face branch's whole loss block ---------------------------------------------------------------------------
-FLAG_HAIR_TO_BG, FLAG_ALPHA, FLAG_HAIR_ATTN, FLAG_LIPS, FLAG_MOUTH = 1, 2, 4, 8, 16
+FLAG_HAIR_TO_BG, FLAG_ALPHA, FLAG_HAIR_ATTN, FLAG_LIPS, FLAG_MOUTH, FLAG_PLAIN = 1, 2, 4, 8, 16, 32
 
 
 def face_loss_torch(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None, attn=None, lips_rect=None,
@@ -228,7 +228,7 @@ class _FusedFaceLoss(torch.autograd.Function):
         as_u8 = lambda m: None if m is None else (m.contiguous().view(torch.uint8) if m.dtype == torch.bool
                                                   else m.contiguous().to(torch.uint8))
         face_mask, hair_mask, mouth_mask = as_u8(face_mask), as_u8(hair_mask), as_u8(mouth_mask)
-        gt, bg = gt.contiguous().float(), bg.contiguous().float()
+        gt, bg = gt.contiguous().float(), (None if bg is None else bg.contiguous().float())
         alpha = None if alpha is None else alpha.contiguous().float()
         attn = None if attn is None else attn.contiguous().float()
         extra_shape = None if extra is None else tuple(extra.shape)
@@ -287,6 +287,13 @@ def face_loss(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None, attn=
         lips_rect = torch.tensor(list(lips_rect), dtype=torch.int32, device=image.device)
     cfg = (flags, float(lambda_dssim), float(w_alpha), float(w_attn), float(w_attn), float(w_extra))
     return _FusedFaceLoss.apply(image, alpha, attn, extra, gt, face_mask, hair_mask, mouth_mask, bg, lips_rect, cfg)
+
+
+def plain_loss_fused(image, gt, lambda_dssim=0.2):
+    """(Ll1 + lambda_dssim * (1 - ssim), Ll1) of two [3,H,W] device images (train_fuse_con.py:176-181) with the face
+    branch's loss kernels in their plain mode: two launches forward, one backward, no scalar arithmetic launches."""
+    cfg = (FLAG_PLAIN, float(lambda_dssim), 0.0, 0.0, 0.0, 0.0)
+    return _FusedFaceLoss.apply(image, None, None, None, gt.detach(), None, None, None, None, None, cfg)
 
 
 def mouth_loss_fused(image, alpha, gt, mouth_mask, lips_rect, bg, p_xyz=None, warm=True, lambda_dssim=0.2, p_raw=None):

@@ -56,6 +56,9 @@ def mouth_loss(image, alpha, gt, mouth_mask, lips_mask, bg, p_xyz=None, warm=Tru
 
 def fuse_loss(image, gt, lambda_dssim=0.2):
     """train_fuse_con.py:176-181 (iteration >= bg_iter = 0, always): whole-frame L1 + DSSIM -> (loss, Ll1)."""
+    if image.is_cuda and image.dim() == 3 and image.shape[0] == 3:
+        from .losses import plain_loss_fused
+        return plain_loss_fused(image, gt, lambda_dssim)
     Ll1, s = l1_and_ssim(image, gt)
     return Ll1 + lambda_dssim * (1.0 - s), Ll1
 

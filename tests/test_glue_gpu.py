@@ -609,3 +609,21 @@ def test_fuse_compose_matches_plain_torch(with_scene):
     for a, b in zip(res[0], res[1]):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
+def test_plain_loss_fused_matches_torch():
+    """losses.plain_loss_fused (the fuse stage's whole-frame L1 + DSSIM, train_fuse_con.py:176-181) against the torch
+    formulation pinned by tests/golden/g3_losses.npz: values and the image gradient."""
+    from instag_amd.losses import l1_loss, plain_loss_fused, ssim
+    torch.manual_seed(10)
+    img = torch.rand(3, 96, 160, device="cuda").requires_grad_(True)
+    gt = torch.rand(3, 96, 160, device="cuda")
+    want_l1 = l1_loss(img, gt)
+    want = want_l1 + 0.2 * (1.0 - ssim(img, gt))
+    want.backward()
+    g_want = img.grad.clone()
+    img.grad = None
+    loss, l1 = plain_loss_fused(img, gt, 0.2)
+    loss.backward()
+    assert abs(float(loss) - float(want)) <= 2e-6 * float(want) and abs(float(l1) - float(want_l1)) <= 2e-6 * float(want_l1)
+    assert float((img.grad - g_want).abs().max()) <= 2e-5 * float(g_want.abs().max())
