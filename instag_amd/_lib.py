@@ -191,7 +191,7 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
-ABI_VERSION = 7     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
+ABI_VERSION = 8     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
 
 
 def lib():
