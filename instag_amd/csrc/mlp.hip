@@ -416,11 +416,14 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
     }
     load_blocks<HB, 8 * HQ>(A1, row, valid, d.H, h, nact1);
   };
+  // (the GLUE variant's epilogue needs the registers: with the prefetch it spills)
+  constexpr bool PREFETCH = !GLUE;
   int tile = blockIdx.x * 4 + wave;
-  if (tile < ntiles) fetch(tile);
+  if (PREFETCH && tile < ntiles) fetch(tile);
   for (; tile < ntiles; tile += tstride) {
     const size_t row = (size_t)tile * 32 + l31;
     const bool valid = row < (size_t)d.N;
+    if (!PREFETCH) fetch(tile);
     f32x16 dy[1], act2[NL == 3 ? HB : 1], act1[HB];
     dy[0] = ndy;
 #pragma unroll
@@ -428,7 +431,7 @@ mlp_backward_kernel(MlpDims d, const float* __restrict__ dY, const float* __rest
       act1[b] = nact1[b];
       if constexpr (NL == 3) act2[b] = nact2[b];
     }
-    if (tile + tstride < ntiles) fetch(tile + tstride);
+    if (PREFETCH && tile + tstride < ntiles) fetch(tile + tstride);
     f32x16 g1[HB];
     if constexpr (NL == 3) {
       f32x16 g2[HB];
