@@ -904,6 +904,134 @@ triplane_backward_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3L]
   }
 }
 
+// The same stage 1 for the common shape (LC levels known at compile time, at most one point per thread: N <= 256 x 512):
+// the thread's point and its 3 x LC gradient values are loaded ONCE (the values also give the fixed-point scale) and
+// stay in registers across the three plane phases, and the position gradient is assembled in registers and stored once.
+// The general kernel re-reads them per plane and level -- about fifteen dependent global round trips per thread in a
+// kernel whose LDS work takes ~30 us.  Same arithmetic, same summation order: identical bits.
+template <int LC>
+__global__ void __launch_bounds__(TP_BWD_BLOCK)
+triplane_backward_cached_kernel(TriPlaneArgs a, const float* __restrict__ grad /*[N,3LC]*/,
+                                float* __restrict__ dxyz /*[N,3] or null*/,
+                                float* __restrict__ dshift /*[N, shift_stride] or null*/,
+                                float* __restrict__ ws /*[gridDim.x][3T]*/, const float* __restrict__ dxyz_add,
+                                const float* __restrict__ dshift_add) {
+  extern __shared__ __align__(16) unsigned long long s_mem64[];      // [T] i64 gradient | [T] f32 table of the plane
+  __shared__ TpLevel s_lv[TP_MAX_L];
+  __shared__ float s_wmax[TP_BWD_BLOCK / 64];
+  const uint32_t per_block = (a.N + gridDim.x - 1) / gridDim.x;      // <= TP_BWD_BLOCK (host)
+  const uint32_t b0 = blockIdx.x * per_block, b1 = min(a.N, b0 + per_block);
+  const uint32_t T = (uint32_t)a.offsets[LC];
+  unsigned long long* s_acc = s_mem64;
+  float* s_tab = reinterpret_cast<float*>(s_mem64 + T);
+  const float inv2b = 1.0f / (2.0f * a.bound);
+  tp_levels(a, s_lv);
+  const uint32_t b = b0 + threadIdx.x;
+  const bool mine = threadIdx.x < per_block && b < b1;
+  float p[3] = {0.f, 0.f, 0.f};
+  float gc[3 * LC];
+  float gmax = 0.f;
+  if (mine) {
+    tp_point(a, b, p);
+    const float* __restrict__ g = grad + (size_t)b * 3 * LC;
+    if ((3 * LC) % 4 == 0 && (reinterpret_cast<uintptr_t>(grad) & 15) == 0) {
+#pragma unroll
+      for (int k = 0; k < 3 * LC / 4; ++k) {
+        const float4 t = reinterpret_cast<const float4*>(g)[k];
+        gc[4 * k] = t.x; gc[4 * k + 1] = t.y; gc[4 * k + 2] = t.z; gc[4 * k + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3 * LC; ++k) gc[k] = g[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3 * LC; ++k) gmax = fmaxf(gmax, fabsf(gc[k]));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3 * LC; ++k) gc[k] = 0.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = gmax;
+  __syncthreads();
+  gmax = s_wmax[0];
+#pragma unroll
+  for (int w = 1; w < TP_BWD_BLOCK / 64; ++w) gmax = fmaxf(gmax, s_wmax[w]);
+  const bool usable = gmax > 0.f && gmax < INFINITY;
+  int shift = 0;
+  if (usable) {
+    int npts_log2 = 1;
+    while ((1u << npts_log2) < per_block) ++npts_log2;
+    shift = 60 - (ilogbf(gmax) + 1) - npts_log2;
+  }
+  const double to_fixed = ldexp(1.0, shift), to_float = ldexp(1.0, -shift);
+  float* slice = ws + (size_t)blockIdx.x * 3 * T;
+  float dsum[3] = {0.f, 0.f, 0.f};                    // d/d point, in the general kernel's order of additions
+#pragma unroll
+  for (int plane = 0; plane < 3; ++plane) {
+    __syncthreads();                                   // previous plane's slice fully stored
+    tp_stage_table<TP_BWD_BLOCK, false>(s_tab, nullptr, a.tables[plane], T);
+#pragma unroll 8
+    for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK) s_acc[i] = 0ull;
+    __syncthreads();
+    if (mine) {
+      float xw[2];
+      plane_coords(plane, p, xw);
+      const float x0 = (xw[0] + a.bound) * inv2b, x1 = (xw[1] + a.bound) * inv2b;
+      float gx = 0.f, gy = 0.f;
+      if (!(x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f)) {
+#pragma unroll
+        for (int l = 0; l < LC; ++l) {
+          const TpLevel lv = s_lv[l];
+          const float gl = gc[plane * LC + l];
+          const float px = x0 * lv.scale + 0.5f, py = x1 * lv.scale + 0.5f;
+          const float flx = floorf(px), fly = floorf(py);
+          const float fx = px - flx, fy = py - fly;
+          const uint32_t i00 = lv.offset + (uint32_t)flx + (uint32_t)fly * lv.stride;
+          const uint32_t i10 = i00 + 1, i01 = i00 + lv.stride, i11 = i01 + 1;
+          if (usable) {
+            const double gs = (double)gl * to_fixed;
+            atomicAdd(&s_acc[i00], (unsigned long long)__double2ll_rn((double)((1.f - fx) * (1.f - fy)) * gs));
+            atomicAdd(&s_acc[i10], (unsigned long long)__double2ll_rn((double)(fx * (1.f - fy)) * gs));
+            atomicAdd(&s_acc[i01], (unsigned long long)__double2ll_rn((double)((1.f - fx) * fy) * gs));
+            atomicAdd(&s_acc[i11], (unsigned long long)__double2ll_rn((double)(fx * fy) * gs));
+          }
+          if (dxyz) {
+            const float v00 = s_tab[i00], v10 = s_tab[i10], v01 = s_tab[i01], v11 = s_tab[i11];
+            gx += gl * lv.scale * ((1.f - fy) * (v10 - v00) + fy * (v11 - v01));
+            gy += gl * lv.scale * ((1.f - fx) * (v01 - v00) + fx * (v11 - v10));
+          }
+        }
+      }
+      gx *= inv2b; gy *= inv2b;
+      // xy = (x,y), yz = (y,z), xz = (x,z): d[0] = gx0 + gx2, d[1] = gy0 + gx1, d[2] = gy1 + gy2
+      if (plane == 0) { dsum[0] = gx; dsum[1] = gy; dsum[2] = 0.f; }
+      else if (plane == 1) { dsum[1] += gx; dsum[2] += gy; }
+      else { dsum[0] += gx; dsum[2] += gy; }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (uint32_t i = threadIdx.x; i < T; i += TP_BWD_BLOCK)
+      slice[plane * T + i] = (float)((double)(long long)s_acc[i] * to_float);
+  }
+  if (mine && dxyz) {
+    float d0 = dsum[0], d1 = dsum[1], d2 = dsum[2];
+    if (dshift) {
+      float* ds = dshift + (size_t)b * a.shift_stride;
+      const float* da = dshift_add ? dshift_add + (size_t)b * a.shift_stride : nullptr;
+      ds[0] = a.shift_scale * d0 + (da ? da[0] : 0.f);
+      ds[1] = a.shift_scale * d1 + (da ? da[1] : 0.f);
+      ds[2] = a.shift_scale * d2 + (da ? da[2] : 0.f);
+      for (uint32_t k = 3; k < a.shift_stride; ++k) ds[k] = da ? da[k] : 0.f;
+    }
+    if (dxyz_add) {
+      d0 += dxyz_add[(size_t)b * 3]; d1 += dxyz_add[(size_t)b * 3 + 1]; d2 += dxyz_add[(size_t)b * 3 + 2];
+    }
+    float* d = dxyz + (size_t)b * 3;
+    d[0] = d0; d[1] = d1; d[2] = d2;
+  }
+}
+
 // stage 2: dtab[plane][i] = sum over workgroup slices, fixed order.  32 cells x 8 slice-groups per workgroup.
 __global__ void __launch_bounds__(256)
 triplane_reduce_kernel(const float* __restrict__ ws, uint32_t nslices, uint32_t T, float* __restrict__ dtab0,
@@ -1189,9 +1317,15 @@ int instag_triplane_backward(const float* grad, const float* xyz, const float* t
   INSTAG_REQUIRE(dshift == nullptr || (shift != nullptr && dxyz != nullptr), "triplane_backward: dshift needs shift and dxyz");
   TriPlaneArgs a{xyz, {table_xy, table_yz, table_xz}, offsets, N, L, H, S, bound, shift, shift_stride, shift_scale};
   ProfScope p(K_GRID_BWD, s);
-  triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)12 * total_params, s>>>(a, grad, dxyz, dshift,
-                                                                                    (float*)workspace, dxyz_add,
-                                                                                    dshift_add);
+  if (L == 12 && div_up<uint32_t>(N, blocks) <= (uint32_t)TP_BWD_BLOCK) {
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void*>(triplane_backward_cached_kernel<12>), 156 * 1024)) return rc;
+    triplane_backward_cached_kernel<12><<<blocks, TP_BWD_BLOCK, (size_t)12 * total_params, s>>>(
+        a, grad, dxyz, dshift, (float*)workspace, dxyz_add, dshift_add);
+  } else {
+    triplane_backward_kernel<<<blocks, TP_BWD_BLOCK, (size_t)12 * total_params, s>>>(a, grad, dxyz, dshift,
+                                                                                      (float*)workspace, dxyz_add,
+                                                                                      dshift_add);
+  }
   INSTAG_CHECK_LAUNCH();
   triplane_reduce_kernel<<<div_up<uint32_t>(3 * total_params, 32), 256, 0, s>>>((const float*)workspace, blocks,
                                                                               total_params, dtable_xy, dtable_yz,
