@@ -385,8 +385,10 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
         means3D = pc.get_xyz + d_xyz
         opacity = pc.get_opacity
         scales, rotations = pc.get_scaling, pc.rotation_activation(pc._rotation)
+    # (dc and rest coefficients as the pair the model stores: no concatenation, no slice copies in backward)
+    shs = pc.get_features_pair if (means3D.is_cuda and hasattr(pc, "get_features_pair")) else pc.get_features
     image, depth, normal, alpha, radii, extra = rasterizer(
-        means3D=means3D, means2D=screenspace_points, shs=pc.get_features, colors_precomp=None, opacities=opacity,
+        means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=_ones(opacity))
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "depth": depth,
             "alpha": alpha, "radii": radii, "motion": motion_preds,
