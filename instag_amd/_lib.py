@@ -88,9 +88,21 @@ def may_fork(device=None) -> bool:
     """May an operator fork work onto a second stream from the current stream?  Always outside a capture; inside one
     only from the capture's origin stream (a capture somebody else opened: origin unknown -> no)."""
     import torch
+    if _LEAF_STREAMS and any(torch.cuda.current_stream(device) == s for s in _LEAF_STREAMS):
+        return False
     if not torch.cuda.is_current_stream_capturing():
         return True
     return _CAPTURE_ORIGIN is not None and torch.cuda.current_stream(device) == _CAPTURE_ORIGIN
+
+
+# streams that carry a whole forked pass (renderer.render_fuse): operators running on them never fork further, eagerly
+# or captured, so that the pass is the same chain of launches in both modes
+_LEAF_STREAMS = []
+
+
+def leaf_stream(stream):
+    if all(stream != s for s in _LEAF_STREAMS):
+        _LEAF_STREAMS.append(stream)
 
 
 _PROTOS = {

@@ -17,10 +17,12 @@ from .motion_net import MotionNetwork as _MotionNetwork
 
 CONCURRENT_PASSES = True      # fork the attention raster pass(es) onto a second stream
 SHARED_ATTN_PASS = True       # attention map as an auxiliary colour set of the main raster pass
-# Fuse stage (training): the mouth pass on a second stream beside the face pass.  Measured 1.55 -> 1.35 ms per captured
-# step, but OFF: with it on, tests/test_glue_gpu.py + tests/test_stages_gpu.py in one process end in a segmentation fault
-# inside hipGraphLaunch of a LATER, unrelated face-step graph (test_face_schedule_replays_one_graph_per_phase), also
-# when only the eager steps ran the passes concurrently; cause not found.
+# Fuse stage (training): the mouth pass on a second stream beside the face pass.  Measured 1.45 -> 1.26 ms per captured
+# step, but OFF: with it on, a process that runs the stage tests ends in a segmentation fault inside hipGraphLaunch of a
+# LATER, unrelated face-step graph (test_face_schedule_replays_one_graph_per_phase).  Narrowed, not solved: the fault
+# also comes when only the EAGER steps ran the passes concurrently; with the rule that a forked pass never forks further
+# (_lib.leaf_stream) the suite passes in its default order (137 tests) but a soak that repeats the stage file four times
+# still faults in the same test, and the same soak with the switch off passes (207 tests).  DESIGN.md section 5.
 CONCURRENT_FUSE_PASSES = False
 
 
@@ -409,6 +411,7 @@ def render_fuse(viewpoint_camera, pc, motion_net, pc_mouth, motion_net_mouth, pi
         # its whole backward -- runs on a second stream beside the face pass.  Each pass alone is a chain of short
         # kernels that leaves most of the chip idle.
         main, side = torch.cuda.current_stream(dev), _side_stream((dev, "fuse"))
+        _lib.leaf_stream(side)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             mouth = render_motion_mouth_con(viewpoint_camera, pc_mouth, motion_net_mouth, pc, motion_net, pipe, bg_color,
