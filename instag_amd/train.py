@@ -517,7 +517,10 @@ class GraphedStep:
         for _ in range(max(1, warmup_steps)):
             t.iteration += 1
             t._set_learning_rates(t.iteration)
-            pkg, _, _ = t._forward_backward(self.static, phase)
+            # (only the package is kept, and only for the statistics: a live loss tensor would keep this step's autograd
+            # graph -- and with it every parameter's gradient accumulator, bound to THIS stream -- alive into the capture,
+            # whose backward would then hop to this stream for every AccumulateGrad)
+            pkg = t._forward_backward(self.static, phase)[0]
             t._stats_and_optimizers(pkg, self.distributed)
             t._zero_grad()
             del pkg        # a live autograd graph keeps grad accumulators bound to this (non-capture) stream
@@ -534,7 +537,7 @@ class GraphedStep:
                 t.iteration += 1
                 t._set_learning_rates(t.iteration)
                 self.plan.begin_step()
-                pkg, _, _ = t._forward_backward(self.static, phase)
+                pkg = t._forward_backward(self.static, phase)[0]
                 t._stats_and_optimizers(pkg, self.distributed)
                 t._zero_grad()
                 del pkg
