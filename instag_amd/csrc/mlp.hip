@@ -672,7 +672,7 @@ __device__ __forceinline__ void weight_grad_body(const float* __restrict__ dZ, c
   for (int t = 0; t < OB; ++t) oin[t] = 32 * t + l31 < O;
 #pragma unroll
   for (int b = 0; b < KB; ++b) kin[b] = 32 * b + l31 < K;
-  constexpr int UNROLL = 4;
+  constexpr int UNROLL = 8;
   for (long r0 = w0; r0 < w1; r0 += 2 * UNROLL) {
     float a[UNROLL][OB], bb[UNROLL][KB];
 #pragma unroll
