@@ -749,11 +749,9 @@ triplane_forward_all_kernel(TriPlaneArgs a, float* __restrict__ out /*[N,3L]*/) 
   const uint32_t T = (uint32_t)a.offsets[a.L];
   const float inv2b = 1.0f / (2.0f * a.bound);
   tp_levels(a, s_lv);
+  // (16-byte loads, several in flight per thread: tp_stage_table)
 #pragma unroll
-  for (int plane = 0; plane < 3; ++plane) {
-    const float* __restrict__ src = a.tables[plane];
-    for (uint32_t i = threadIdx.x; i < T; i += TPF_BLOCK) s_tab[plane * T + i] = src[i];
-  }
+  for (int plane = 0; plane < 3; ++plane) tp_stage_table<TPF_BLOCK, false>(s_tab + plane * T, nullptr, a.tables[plane], T);
   __syncthreads();
   if (b0 >= b1) return;
   const uint32_t items = 3u * (b1 - b0);
