@@ -549,6 +549,12 @@ int instag_adam_grads_max(void);
 int instag_adam_step_grads(const void* tensors, const void* host_grads, int32_t n_tensors, const void* groups,
                            const float* lrs, const int32_t* chunks, int32_t n_chunks, float* step,
                            instag_stream_t stream);
+/* The same in ONE launch (no counter launch in front): tickets = int32[n_tensors] in device memory, zero before the first
+ * call and left zero by every call; the workgroup of each tensor that finishes last stores the tensor's new step count.
+ * chunks must list every chunk of every tensor exactly once. */
+int instag_adam_step_grads_ticketed(const void* tensors, const void* host_grads, int32_t n_tensors, const void* groups,
+                                    const float* lrs, const int32_t* chunks, int32_t n_chunks, float* step,
+                                    int32_t* tickets, instag_stream_t stream);
 int instag_adam_step(const void* tensors, int32_t n_tensors, const void* groups, const float* lrs,
                      const int32_t* chunks, int32_t n_chunks, float* step, instag_stream_t stream);
 

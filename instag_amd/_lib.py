@@ -195,6 +195,7 @@ _PROTOS = {
     "instag_adam_step": (C.c_int, [vp, i32, vp, vp, vp, i32, vp, vp]),
     "instag_adam_grads_max": (C.c_int, []),
     "instag_adam_step_grads": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, vp, vp]),
+    "instag_adam_step_grads_ticketed": (C.c_int, [vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
     "instag_prof_enable": (C.c_int, [C.c_int]),
     "instag_prof_reset": (C.c_int, []),
     "instag_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -76,16 +76,22 @@ __global__ void adam_tick_grads_kernel(AdamGrads gr, int n, float* __restrict__ 
   if (i < n && gr.g[i] != nullptr) steps[i] += 1.0f;
 }
 
+// TICKET: no separate counter launch.  Every workgroup reads the tensor's counter of COMPLETED steps, uses counter + 1,
+// and draws a ticket when it is done; the workgroup that draws the tensor's last ticket stores the new count and
+// clears the tickets.  All reads of the counter precede the store (each workgroup reads before it draws), and the
+// next launch is ordered behind this one by the stream.
+template <bool TICKET>
 __global__ void __launch_bounds__(ADAM_BLOCK)
 adam_step_grads_kernel(const AdamTensor* __restrict__ tensors, AdamGrads grads, const AdamGroup* __restrict__ groups,
-                       const float* __restrict__ lrs, const int2* __restrict__ chunks, const float* __restrict__ step) {
+                       const float* __restrict__ lrs, const int2* __restrict__ chunks, float* step,
+                       int32_t* __restrict__ tickets) {
   const int2 ch = chunks[blockIdx.x];            // (tensor index, chunk index)
   const float* __restrict__ tg = grads.g[ch.x];
   if (tg == nullptr) return;
   const AdamTensor t = tensors[ch.x];
   const AdamGroup gr = groups[t.group];
   const float lr = lrs[t.group];
-  const float tstep = step[ch.x];
+  const float tstep = TICKET ? step[ch.x] + 1.0f : step[ch.x];
   const float bc1 = 1.0f - powf(gr.beta1, tstep);
   const float bc2_sqrt = sqrtf(1.0f - powf(gr.beta2, tstep));
   const float step_size = lr / bc1;
@@ -100,6 +106,16 @@ adam_step_grads_kernel(const AdamTensor* __restrict__ tensors, AdamGrads grads, 
     const float denom = sqrtf(v) / bc2_sqrt + gr.eps;
     p -= step_size * (m / denom);
     t.p[i] = p; t.m[i] = m; t.v[i] = v;
+  }
+  if (TICKET) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nchunks = (int)((t.n + ADAM_CHUNK - 1) / ADAM_CHUNK);
+      if (atomicAdd(&tickets[ch.x], 1) == nchunks - 1) {
+        tickets[ch.x] = 0;
+        step[ch.x] = tstep;
+      }
+    }
   }
 }
 
@@ -147,8 +163,27 @@ int instag_adam_step_grads(const void* tensors, const void* host_grads, int32_t 
   memcpy(gr.g, host_grads, (size_t)n_tensors * sizeof(const float*));
   adam_tick_grads_kernel<<<(n_tensors + 63) / 64, 64, 0, s>>>(gr, n_tensors, step);
   INSTAG_CHECK_LAUNCH();
-  adam_step_grads_kernel<<<n_chunks, ADAM_BLOCK, 0, s>>>((const AdamTensor*)tensors, gr, (const AdamGroup*)groups, lrs,
-                                                         (const int2*)chunks, step);
+  adam_step_grads_kernel<false><<<n_chunks, ADAM_BLOCK, 0, s>>>((const AdamTensor*)tensors, gr, (const AdamGroup*)groups,
+                                                                lrs, (const int2*)chunks, step, nullptr);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+/* As instag_adam_step_grads in ONE launch: `tickets` = int32[n_tensors] in device memory, zero before the first call
+ * and left zero by every call; the step counters are incremented by the kernel itself (by the workgroup of each tensor
+ * that finishes last).  `chunks` must list every chunk of every tensor exactly once. */
+int instag_adam_step_grads_ticketed(const void* tensors, const void* host_grads, int32_t n_tensors, const void* groups,
+                                    const float* lrs, const int32_t* chunks, int32_t n_chunks, float* step,
+                                    int32_t* tickets, instag_stream_t stream) {
+  INSTAG_REQUIRE(tensors && host_grads && groups && lrs && chunks && step && tickets, "adam_step: NULL argument");
+  INSTAG_REQUIRE(n_tensors <= ADAM_GRADS_MAX, "adam_step_grads: more tensors than instag_adam_grads_max()");
+  if (n_chunks <= 0 || n_tensors <= 0) return INSTAG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  AdamGrads gr;
+  memset(&gr, 0, sizeof(gr));
+  memcpy(gr.g, host_grads, (size_t)n_tensors * sizeof(const float*));
+  adam_step_grads_kernel<true><<<n_chunks, ADAM_BLOCK, 0, s>>>((const AdamTensor*)tensors, gr, (const AdamGroup*)groups,
+                                                               lrs, (const int2*)chunks, step, tickets);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }

@@ -113,6 +113,7 @@ class MultiTensorAdam:
                 if prev is not None:
                     steps[i:i + 1].copy_(prev.reshape(1))
             self._step = steps
+            self._tickets = torch.zeros(len(tensors), dtype=torch.int32, device=dev)   # adam.hip: TICKET
             for i, t in enumerate(tensors):
                 self._state_of(t[0])["step"] = steps[i:i + 1]
             self._dev, self._layout_key = dev, key
@@ -130,9 +131,11 @@ class MultiTensorAdam:
             gh = self._grads_host
             for i, t in enumerate(tensors):
                 gh[i] = 0 if t[1] is None else t[1].data_ptr()
-            check(L.instag_adam_step_grads(ptr(self._tensors_dev), gh.ctypes.data, len(tensors), ptr(self._groups_dev),
-                                           ptr(self._lr_dev), ptr(self._chunks), self._chunks.shape[0],
-                                           ptr(self._step), _lib.current_stream()), "adam_step")
+            # (one launch: the kernel counts the steps itself)
+            check(L.instag_adam_step_grads_ticketed(ptr(self._tensors_dev), gh.ctypes.data, len(tensors),
+                                                    ptr(self._groups_dev), ptr(self._lr_dev), ptr(self._chunks),
+                                                    self._chunks.shape[0], ptr(self._step), ptr(self._tickets),
+                                                    _lib.current_stream()), "adam_step")
             return
         tarr = self._tensors_host.numpy().view(_TENSOR_DT)
         for i, (p, grad, m, v, gi) in enumerate(tensors):
