@@ -403,6 +403,10 @@ int instag_motion_l1_reg_backward(const float* h, const float* p, const float* g
  * denom += 1.  viewspace_grad [N,3], radii int32 [N], the three statistics float [N]. */
 int instag_densify_stats(const float* viewspace_grad, const int32_t* radii, float* max_radii2D, float* grad_accum,
                          float* denom, int32_t N, instag_stream_t stream);
+/* As instag_densify_stats with a second producer's share of the screen-space gradient: viewspace_grad += grad_add
+ * ([N,3], may be NULL) for every Gaussian first (the sum is written back), then the statistics from the sum. */
+int instag_densify_stats_add(float* viewspace_grad, const float* grad_add, const int32_t* radii, float* max_radii2D,
+                             float* grad_accum, float* denom, int32_t N, instag_stream_t stream);
 
 /* The k largest (descending) and k smallest (ascending) VALUES of v [N], 1 <= k <= 64 (csrc/select.hip): the two
  * torch.topk selections behind the mouth branch's jaw-movement feature, gaussian_renderer/__init__.py:341-349. */

@@ -177,6 +177,7 @@ _PROTOS = {
     "instag_motion_l1_reg_backward": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
     "instag_knn3_mean_dist2": (C.c_int, [vp, vp, i32, vp]),
     "instag_densify_stats": (C.c_int, [vp, vp, vp, vp, vp, i32, vp]),
+    "instag_densify_stats_add": (C.c_int, [vp] * 6 + [i32, vp]),
     "instag_frame_code_saved_floats": (C.c_int64, [i32, i32, i32]),
     "instag_frame_code_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "instag_frame_code_backward_workspace_bytes": (sz, [i32, i32, i32]),

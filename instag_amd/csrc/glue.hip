@@ -517,14 +517,21 @@ motion_l1_reg_backward_kernel(int N, const float* __restrict__ h, const float* _
 //   max_radii2D[vis] = max(max_radii2D[vis], radii[vis]); xyz_gradient_accum[vis] += ||viewspace_grad[vis, :2]||;
 //   denom[vis] += 1          with vis = radii > 0
 __global__ void __launch_bounds__(GB)
-densify_stats_kernel(int N, const float* __restrict__ vs_grad, const int32_t* __restrict__ radii,
-                     float* __restrict__ max_radii2D, float* __restrict__ grad_accum, float* __restrict__ denom) {
+densify_stats_kernel(int N, float* __restrict__ vs_grad, const float* __restrict__ vs_add /*[N,3] or null*/,
+                     const int32_t* __restrict__ radii, float* __restrict__ max_radii2D, float* __restrict__ grad_accum,
+                     float* __restrict__ denom) {
   const int i = blockIdx.x * GB + threadIdx.x;
   if (i >= N) return;
+  float gx = vs_grad[3 * i], gy = vs_grad[3 * i + 1];
+  if (vs_add) {
+    // a second producer's share of the screen-space gradient (the auxiliary image's backward) is added HERE and the
+    // sum written back, instead of by an elementwise launch on the tail of the step
+    gx += vs_add[3 * i]; gy += vs_add[3 * i + 1];
+    vs_grad[3 * i] = gx; vs_grad[3 * i + 1] = gy; vs_grad[3 * i + 2] += vs_add[3 * i + 2];
+  }
   const int r = radii[i];
   if (r <= 0) return;
   max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
-  const float gx = vs_grad[3 * i], gy = vs_grad[3 * i + 1];
   grad_accum[i] += sqrtf(gx * gx + gy * gy);
   denom[i] += 1.f;
 }
@@ -742,7 +749,18 @@ int instag_densify_stats(const float* viewspace_grad, const int32_t* radii, floa
                          float* denom, int32_t N, instag_stream_t stream) {
   INSTAG_REQUIRE(viewspace_grad && radii && max_radii2D && grad_accum && denom, "densify_stats: NULL tensor");
   if (N == 0) return INSTAG_OK;
-  densify_stats_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, viewspace_grad, radii, max_radii2D,
+  densify_stats_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, const_cast<float*>(viewspace_grad), nullptr,
+                                                                         radii, max_radii2D, grad_accum, denom);
+  INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int instag_densify_stats_add(float* viewspace_grad, const float* grad_add, const int32_t* radii, float* max_radii2D,
+                             float* grad_accum, float* denom, int32_t N, instag_stream_t stream) {
+  INSTAG_REQUIRE(viewspace_grad && radii && max_radii2D && grad_accum && denom, "densify_stats: NULL tensor");
+  INSTAG_REQUIRE(grad_add != viewspace_grad, "densify_stats_add: grad_add must not alias viewspace_grad");
+  if (N == 0) return INSTAG_OK;
+  densify_stats_kernel<<<(N + GB - 1) / GB, GB, 0, (hipStream_t)stream>>>(N, viewspace_grad, grad_add, radii, max_radii2D,
                                                                          grad_accum, denom);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;

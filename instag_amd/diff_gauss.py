@@ -233,7 +233,30 @@ def join_pending_aux(final: bool = False):
         while _PENDING_AUX:
             entry = _PENDING_AUX.pop()
             leaf, m2d_aux = entry["leaf"], entry["m2d_aux"]
-            leaf.grad = m2d_aux if leaf.grad is None else leaf.grad.add_(m2d_aux)
+            if FOLD_AUX_M2D and leaf.grad is not None:
+                _FOLDED.append((leaf, m2d_aux))          # the caller adds it (take_folded_aux)
+            else:
+                leaf.grad = m2d_aux if leaf.grad is None else leaf.grad.add_(m2d_aux)
+
+
+# A trainer whose next launch after backward reads means2D.grad anyway (the densification statistics) may take the aux
+# image's share from here and add it in that launch (glue.densify_stats(grad_add=...)) instead of paying an elementwise
+# launch on the tail of the step: set FOLD_AUX_M2D around backward, call take_folded_aux(leaf) right after it.
+FOLD_AUX_M2D = False
+_FOLDED = []
+
+
+def take_folded_aux(leaf):
+    """The aux image's means2D share that join_pending_aux(final=True) left un-added for ``leaf`` (or None).  Shares of
+    other leaves are added to their gradients now."""
+    mine = None
+    while _FOLDED:
+        lf, m2d_aux = _FOLDED.pop()
+        if lf is leaf and mine is None:
+            mine = m2d_aux
+        else:
+            lf.grad = m2d_aux if lf.grad is None else lf.grad.add_(m2d_aux)
+    return mine
 
 
 def rasterize_aux_backward(st: "_State", g_aux, want_colors=True, want_means2D=True, stream=None):

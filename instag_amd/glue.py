@@ -427,11 +427,18 @@ def motion_l1_reg(h, p):
 
 
 @torch.no_grad()
-def densify_stats(viewspace_grad, radii, max_radii2D, xyz_gradient_accum, denom):
-    """In-place densification statistics of one step (train_face.py:626-629) as one launch."""
+def densify_stats(viewspace_grad, radii, max_radii2D, xyz_gradient_accum, denom, grad_add=None):
+    """In-place densification statistics of one step (train_face.py:626-629) as one launch.  ``grad_add`` [N,3]: a
+    second producer's share of the screen-space gradient, added into ``viewspace_grad`` by the same launch first."""
     N = radii.shape[0]
     assert viewspace_grad.is_contiguous() and max_radii2D.is_contiguous() and xyz_gradient_accum.is_contiguous() \
         and denom.is_contiguous() and radii.dtype == torch.int32 and max_radii2D.dtype == torch.float32
+    if grad_add is not None:
+        assert grad_add.is_contiguous() and grad_add.shape == viewspace_grad.shape and grad_add.dtype == torch.float32
+        check(_lib.lib().instag_densify_stats_add(ptr(viewspace_grad), ptr(grad_add), ptr(radii.contiguous()),
+                                                  ptr(max_radii2D), ptr(xyz_gradient_accum), ptr(denom), N,
+                                                  _lib.current_stream()), "densify_stats_add")
+        return
     check(_lib.lib().instag_densify_stats(ptr(viewspace_grad), ptr(radii.contiguous()), ptr(max_radii2D),
                                           ptr(xyz_gradient_accum), ptr(denom), N, _lib.current_stream()),
           "densify_stats")

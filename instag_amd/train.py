@@ -279,13 +279,17 @@ class FaceTrainer:
         return loss, Ll1
 
     # ---- one step ---------------------------------------------------------------------------------------------
-    def _forward_backward(self, frame: Frame, phase: FacePhase = C3_PHASE):
+    def _forward_backward(self, frame: Frame, phase: FacePhase = C3_PHASE, fold_aux: bool = False):
         from .renderer import render_motion
         pkg = render_motion(frame, self.g, self.motion_net, None, self.bg, return_attn=True, personalized=False,
                             align=phase.align, motion_reg_weight=1e-5 if phase.warm else None)
         loss, Ll1 = self.loss_fn(frame, pkg, warm=phase.warm, hair_mask_iter=phase.hair_mask_iter,
                                  priors=phase.priors, prior_depth=phase.prior_depth)
         from .deferred import deferred_grads
+        from . import diff_gauss
+        # fold_aux (only callers that run _stats_and_optimizers(pkg) next): the auxiliary image's share of the screen-space
+        # gradient is added by the statistics kernel instead of by a launch of its own at the end of backward
+        diff_gauss.FOLD_AUX_M2D = bool(fold_aux and self.on_gpu)
         with deferred_grads(self.device if self.on_gpu else None):
             # the MLPs' weight gradients are batched into one launch at the end (deferred.py); the root gradient is
             # a cached constant (no fill launch per step)
@@ -295,10 +299,13 @@ class FaceTrainer:
                 loss.backward(gradient=self._one)
             else:
                 loss.backward()
+        if diff_gauss.FOLD_AUX_M2D:
+            diff_gauss.FOLD_AUX_M2D = False
+            pkg["_m2d_aux"] = diff_gauss.take_folded_aux(pkg["viewspace_points"])
         return pkg, loss, Ll1
 
     @torch.no_grad()
-    def _update_stats(self, vs_grad, radii):
+    def _update_stats(self, vs_grad, radii, grad_add=None):
         """Densification statistics of this rank's frame (train_face.py:670-671; scene/gaussian_model.py:683-685).
         With several ranks they stay LOCAL sums / maxima and are exchanged once, when a densification reads them
         (sync_densification_stats): sum and max commute with the per-step accumulation."""
@@ -306,8 +313,10 @@ class FaceTrainer:
         if vs_grad.is_cuda and g.max_radii2D.dtype == torch.float32 and radii.dtype == torch.int32 \
                 and vs_grad.is_contiguous():
             from .glue import densify_stats
-            densify_stats(vs_grad, radii, g.max_radii2D, g.xyz_gradient_accum, g.denom)
+            densify_stats(vs_grad, radii, g.max_radii2D, g.xyz_gradient_accum, g.denom, grad_add)
             return
+        if grad_add is not None:
+            vs_grad.add_(grad_add)
         vis = radii > 0
         rmax = torch.where(vis, radii.to(g.max_radii2D.dtype), torch.zeros_like(g.max_radii2D))
         g.max_radii2D.copy_(torch.max(g.max_radii2D, rmax))
@@ -331,7 +340,7 @@ class FaceTrainer:
     def _stats_and_optimizers(self, pkg, distributed: bool, it: Optional[int] = None, frame: Optional[Frame] = None):
         """Everything of an iteration behind loss.backward(), in the reference's order (train_face.py:667-788):
         statistics -> [gradient exchange] -> [densify / prune / opacity reset] -> optimizers."""
-        self._update_stats(pkg["viewspace_points"].grad, pkg["radii"])
+        self._update_stats(pkg["viewspace_points"].grad, pkg["radii"], dict.get(pkg, "_m2d_aux"))
         if distributed:
             allreduce_gradients(self._all_params())
         if it is not None:
@@ -424,7 +433,7 @@ class FaceTrainer:
             from . import diff_gauss
             if diff_gauss._CAPACITY_PLAN is not None:
                 diff_gauss._CAPACITY_PLAN.begin_step()
-            pkg, loss, Ll1 = self._forward_backward(frame, phase)
+            pkg, loss, Ll1 = self._forward_backward(frame, phase, fold_aux=True)
             self._stats_and_optimizers(pkg, distributed, it, frame)
             self._zero_grad()
         self.last = dict(loss=loss.detach(), l1=Ll1.detach(), num_points=self.g.num_points, phase=phase)
@@ -520,7 +529,7 @@ class GraphedStep:
             # (only the package is kept, and only for the statistics: a live loss tensor would keep this step's autograd
             # graph -- and with it every parameter's gradient accumulator, bound to THIS stream -- alive into the capture,
             # whose backward would then hop to this stream for every AccumulateGrad)
-            pkg = t._forward_backward(self.static, phase)[0]
+            pkg = t._forward_backward(self.static, phase, fold_aux=True)[0]
             t._stats_and_optimizers(pkg, self.distributed)
             t._zero_grad()
             del pkg        # a live autograd graph keeps grad accumulators bound to this (non-capture) stream
@@ -537,7 +546,7 @@ class GraphedStep:
                 t.iteration += 1
                 t._set_learning_rates(t.iteration)
                 self.plan.begin_step()
-                pkg = t._forward_backward(self.static, phase)[0]
+                pkg = t._forward_backward(self.static, phase, fold_aux=True)[0]
                 t._stats_and_optimizers(pkg, self.distributed)
                 t._zero_grad()
                 del pkg
@@ -555,7 +564,7 @@ class GraphedStep:
         self.plan.begin_step()
         if not self.split:
             with _no_gc(), _lib.graph_capture(self.graph_a, **mode):
-                pkg, loss, l1 = t._forward_backward(self.static, phase)
+                pkg, loss, l1 = t._forward_backward(self.static, phase, fold_aux=True)
                 t._stats_and_optimizers(pkg, False)
                 t._zero_grad()
             # nothing captured is released before the capture has ended (ROCm 7.2: frees inside the capture
