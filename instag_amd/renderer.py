@@ -392,9 +392,11 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
     image, depth, normal, alpha, radii, extra = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=_ones(opacity))
-    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "depth": depth,
-            "alpha": alpha, "radii": radii, "motion": motion_preds,
-            "p_motion": p_motion_preds if personalized or align else None}
+    from .motion_net import LazyOutputs
+    return LazyOutputs({"render": image, "viewspace_points": screenspace_points,
+                        "visibility_filter": lambda: radii > 0,          # built on first access
+                        "depth": depth, "alpha": alpha, "radii": radii, "motion": motion_preds,
+                        "p_motion": p_motion_preds if personalized or align else None})
 
 
 def render_fuse(viewpoint_camera, pc, motion_net, pc_mouth, motion_net_mouth, pipe=None, bg_color=None,
