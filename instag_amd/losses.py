@@ -307,7 +307,12 @@ def mouth_loss_fused(image, alpha, gt, mouth_mask, lips_rect, bg, p_xyz=None, wa
         # mean|p_xyz| with p_xyz = p[:, :3] * 1e-2 as partial sums the loss kernel adds up: one launch per pass instead
         # of the slice / scale / abs / mean chain and its five backward launches
         from .glue import abs_mean_partials
-        extra = abs_mean_partials(p_raw, 3, 1e-2)
+        # (the term's weight rides in the scale -- |x * 1e-2| * 1e-5 = |x * 1e-7| -- so the loss kernel's w_extra is 1
+        # and the gradient of the partial sums is the loss gradient itself: no scaling launch in backward)
+        extra = abs_mean_partials(p_raw, 3, 1e-2 * 1e-5)
+        cfg = (flags, float(lambda_dssim), 1e-3, 0.0, 0.0, 1.0)
+        return _FusedFaceLoss.apply(image, alpha if warm else None, None, extra, gt, None, None, mouth_mask, bg,
+                                    lips_rect.to(torch.int32), cfg)
     elif warm and p_xyz is not None:
         extra = p_xyz.abs().mean().reshape(1)
     cfg = (flags, float(lambda_dssim), 1e-3, 0.0, 0.0, 1e-5)

@@ -74,6 +74,21 @@ def render(viewpoint_camera, pc, pipe=None, bg_color=None, scaling_modifier=1.0,
 _ONES = {}
 
 
+_ZEROS = {}
+
+
+def _zeros_const(like):
+    """Read-only zero tensor of ``like``'s shape (the neutral expression the mouth branch feeds the face field), created
+    once per (device, shape, dtype) outside any graph capture."""
+    key = (like.device, tuple(like.shape), like.dtype)
+    t = _ZEROS.get(key)
+    if t is None:
+        if like.is_cuda and torch.cuda.is_current_stream_capturing():
+            return torch.zeros_like(like)
+        t = _ZEROS[key] = torch.zeros_like(like)
+    return t
+
+
 def _ones(like):
     """Constant extra_attrs column, created once per (device, N) outside any graph capture."""
     key = (like.device, tuple(like.shape))
@@ -328,7 +343,7 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
         if hasattr(motion_net, "start_audio"):
             motion_net.start_audio(audio_feat, 2)
         if not inference and hasattr(motion_net_face, "start_audio"):
-            exp_feat = torch.zeros_like(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
+            exp_feat = _zeros_const(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
             motion_net_face.start_audio(audio_feat, 1, exp_feat)
     p_motion_preds = None
     if personalized or align:
@@ -342,7 +357,7 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
             xyz = xyz + p_motion_preds["p_xyz"]
     if not inference:
         if exp_feat is None:
-            exp_feat = torch.zeros_like(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
+            exp_feat = _zeros_const(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
         motion_preds_face = motion_net_face(pc_face.get_xyz, audio_feat, exp_feat)
     else:
         motion_preds_face = motion_net_face.cache

@@ -174,11 +174,25 @@ class GraphedStage:
         return bool(self.plan.poll_overflow())        # asynchronous: the answer of the previous poll, no device wait
 
 
+_ONE = {}
+
+
 def _backward(loss, device):
-    """loss.backward() with the MLPs' weight-gradient GEMMs batched into one launch behind it (instag_amd/deferred.py)."""
+    """loss.backward() with the MLPs' weight-gradient GEMMs batched into one launch behind it (instag_amd/deferred.py);
+    on the device the root gradient is a cached constant (no fill launch per step)."""
     from .deferred import deferred_grads
     with deferred_grads(device if device.type == "cuda" else None):
-        loss.backward()
+        if device.type == "cuda" and loss.dim() == 0:
+            key = (loss.device, loss.dtype)
+            one = _ONE.get(key)
+            if one is None:
+                if torch.cuda.is_current_stream_capturing():
+                    one = torch.ones((), dtype=loss.dtype, device=loss.device)
+                else:
+                    one = _ONE[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+            loss.backward(gradient=one)
+        else:
+            loss.backward()
 
 
 def _drop_graph(trainer):
