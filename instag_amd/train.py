@@ -112,20 +112,27 @@ def make_frame(cam, frame_data) -> Frame:
     return f.packed() if frame_data["gt_image"].is_cuda else f
 
 
+def with_grad(params: List[torch.Tensor]) -> List[torch.Tensor]:
+    """The parameters that received a gradient this step.  Which ones do depends on the step's phase only (e.g. the
+    personalised field's deformation head is never evaluated with personalized=False), so every rank gets the same
+    list; a parameter without gradient is not exchanged and -- as on one GPU -- not stepped."""
+    return [p for p in params if p.grad is not None]
+
+
 def flat_grad_bucket(params: List[torch.Tensor]) -> torch.Tensor:
-    """Concatenate gradients (zeros where .grad is None) into one contiguous fp32 bucket."""
-    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    """Concatenate the gradients of ``params`` (all of which have one, see with_grad) into one contiguous fp32 bucket."""
+    return torch.cat([p.grad.reshape(-1) for p in params])
 
 
 def scatter_grad_bucket(params: List[torch.Tensor], bucket: torch.Tensor):
+    """Hand the reduced gradients back as VIEWS of the bucket (no copy: ~45 parameter tensors would be ~45 launches per
+    step, a third of a captured step's time).  The bucket must stay alive and untouched until the optimizers have read
+    it -- it does: the next step's gradients are concatenated into a fresh tensor (eager) / the captured step rewrites
+    it only in its first graph, the optimizers run in the second."""
     o = 0
     for p in params:
         n = p.numel()
-        g = bucket[o:o + n].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+        p.grad = bucket[o:o + n].view_as(p)
         o += n
 
 
@@ -135,6 +142,7 @@ def allreduce_gradients(params: List[torch.Tensor], extras: Optional[List[torch.
         return
     world = dist.get_world_size()
     extras = extras or []
+    params = with_grad(params)
     g = flat_grad_bucket(params)
     n_g = g.numel()
     bucket = torch.cat([g] + [e.reshape(-1).to(g.dtype) for e in extras])
@@ -574,7 +582,7 @@ class GraphedStep:
             with _no_gc(), _lib.graph_capture(self.graph_a, **mode):
                 pkg, loss, l1 = t._forward_backward(self.static, phase)
                 self._vs_grad, self._radii = pkg["viewspace_points"].grad, pkg["radii"]
-                self._params = t._all_params()
+                self._params = with_grad(t._all_params())
                 self._bucket = flat_grad_bucket(self._params)
             del pkg
             self.graph_b = torch.cuda.CUDAGraph()

@@ -83,37 +83,42 @@ def _dp_worker(rank, world, port, results):
         stat = torch.full((50, 1), float(rank + 1))
         cnt = torch.ones(50, 1)
         allreduce_gradients(params, extras=[stat, cnt])
-        results[rank] = dict(g0=params[0].grad.clone(), g1=params[1].grad.clone(), g2=params[2].grad.clone(),
+        results[rank] = dict(g0=params[0].grad.clone(), g1=params[1].grad.clone(), g2_none=params[2].grad is None,
                              stat=stat.clone(), cnt=cnt.clone(), p1=params[1].detach().clone())
     finally:
         dist.destroy_process_group()
 
 
 def test_dp_fused_bucket_allreduce_gloo_world2():
-    """Gradients become the mean over ranks (== accumulation over the ranks' frames), statistics the sum,
-    parameters without gradient are zero-filled consistently; both ranks end up identical."""
+    """Gradients become the mean over ranks (== accumulation over the ranks' frames), statistics the sum, a parameter
+    without gradient is not exchanged and keeps none (as on one GPU: not stepped); both ranks end up identical."""
     world = 2
     mgr = mp.Manager()
     results = mgr.dict()
     port = 29500 + os.getpid() % 2000
     mp.spawn(_dp_worker, args=(world, port, results), nprocs=world, join=True)
     r0, r1 = results[0], results[1]
-    for k in ("g0", "g1", "g2", "stat", "cnt"):
+    for k in ("g0", "g1", "stat", "cnt"):
         assert torch.equal(r0[k], r1[k]), k
     assert torch.allclose(r0["g0"], torch.full((50, 3), 1.5))            # mean of 1 and 2
     assert torch.allclose(r0["g1"], 2 * r0["p1"] * 1.5)
-    assert float(r0["g2"].abs().max()) == 0.0
+    assert r0["g2_none"] and r1["g2_none"]
     assert torch.allclose(r0["stat"], torch.full((50, 1), 3.0)) and torch.allclose(r0["cnt"], torch.full((50, 1), 2.0))
 
 
 def test_grad_bucket_roundtrip():
-    from instag_amd.train import flat_grad_bucket, scatter_grad_bucket
-    ps = [torch.nn.Parameter(torch.randn(5, 2)), torch.nn.Parameter(torch.randn(3))]
+    from instag_amd.train import flat_grad_bucket, scatter_grad_bucket, with_grad
+    ps = [torch.nn.Parameter(torch.randn(5, 2)), torch.nn.Parameter(torch.randn(3)), torch.nn.Parameter(torch.randn(4))]
     ps[0].grad = torch.arange(10.0).view(5, 2)
-    b = flat_grad_bucket(ps)
-    assert b.shape == (13,) and float(b[10:].abs().max()) == 0
-    scatter_grad_bucket(ps, b * 2)
-    assert torch.equal(ps[0].grad, torch.arange(10.0).view(5, 2) * 2) and ps[1].grad is not None
+    ps[2].grad = torch.ones(4)
+    have = with_grad(ps)
+    assert [p is q for p, q in zip(have, (ps[0], ps[2]))] == [True, True]
+    b = flat_grad_bucket(have)
+    assert b.shape == (14,)
+    b2 = b * 2
+    scatter_grad_bucket(have, b2)
+    assert torch.equal(ps[0].grad, torch.arange(10.0).view(5, 2) * 2) and ps[1].grad is None
+    assert ps[2].grad.data_ptr() == b2[10:].data_ptr()                   # views of the bucket, no copies
 
 
 def test_ply_roundtrip_and_reference_layout(tmp_path):
