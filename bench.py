@@ -32,8 +32,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 KERNEL_IDS = {"preprocess": 0, "duplicate": 1, "sort": 2, "ranges": 3, "blend_fwd": 4, "blend_bwd": 5,
-              "preprocess_bwd": 6, "grid_fwd": 7, "grid_bwd": 8, "mlp_fwd": 11, "mlp_bwd": 12, "mlp_wgrad": 13}
+              "preprocess_bwd": 6, "grid_fwd": 7, "grid_bwd": 8, "mlp_fwd": 11, "mlp_bwd": 12, "mlp_wgrad": 13,
+              "blend_bwd_mean": 16}
 NON_RASTER = ("grid_fwd", "grid_bwd", "mlp_fwd", "mlp_bwd", "mlp_wgrad")
+# the blend launches of the C3 step, each a kernel of its own (template variant) with its own byte count:
+#   blend_fwd       image + attention map, all channels                     60 R + 44 P   
+#   blend_bwd       colour pass, aux colours' gradient in idle GEMM columns  124 R + 44 P  
+#   blend_bwd_mean  the attention map's d/dmean pass: reads id 4 + xy 8 + conic, opacity 16 + aux colour 12, writes the
+#                   8-byte mean gradient per entry; per pixel dL/daux 12 + n_contrib 4 + final_T 4   48 R + 20 P
+BLEND_VARIANTS = {"blend_fwd": ("blend_forward_kernel<true>", 60, 44),
+                  "blend_bwd": ("blend_backward_kernel<false, 2, false>", 124, 44),
+                  "blend_bwd_mean": ("blend_backward_kernel<false, 0, true>", 48, 20)}
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA (32x32x2 / 16x16x4), 64 FLOP/clk/SIMD
 SIMDS, CLOCK_GHZ = 1024, 2.4
@@ -42,7 +51,7 @@ SIMDS, CLOCK_GHZ = 1024, 2.4
 # VALU instruction occupies its SIMD-32 for 2 cycles (transcendental: 4), v_mfma_f32_16x16x4_f32 for 32; ONE wave
 # alone issues one instruction of any class per ~4 cycles (8 for a transcendental).
 VALU_CYC, TRANS_CYC, MFMA_16x16x4_CYC, LONE_WAVE_CYC = 2, 4, 32, 4
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
 
 
 def algorithmic_bytes(kernel, N, M, R, P, grid_points=0):
@@ -54,6 +63,7 @@ def algorithmic_bytes(kernel, N, M, R, P, grid_points=0):
         "ranges": 8 * R,
         "blend_fwd": 60 * R + 44 * P,
         "blend_bwd": 124 * R + 44 * P,
+        "blend_bwd_mean": 48 * R + 20 * P,
         "preprocess_bwd": 64 * R + N * (128 + 24 * M),
         "grid_fwd": grid_points * 156,      # tri-plane launch: xyz 12 B + 3 planes x 12 levels x 4 B out
         "grid_bwd": grid_points * 168,      # + 12 B gradient to xyz
@@ -61,27 +71,26 @@ def algorithmic_bytes(kernel, N, M, R, P, grid_points=0):
 
 
 PMC_KERNEL = {"preprocess": "preprocess_kernel", "duplicate": "duplicate_kernel", "ranges": "ranges_kernel",
-              "blend_fwd": "blend_forward_kernel", "blend_bwd": "blend_backward_kernel",
-              "preprocess_bwd": "preprocess_backward_kernel"}
+              "blend_fwd": BLEND_VARIANTS["blend_fwd"][0], "blend_bwd": BLEND_VARIANTS["blend_bwd"][0],
+              "blend_bwd_mean": BLEND_VARIANTS["blend_bwd_mean"][0], "preprocess_bwd": "preprocess_backward_kernel"}
 
 
 def pmc_traffic(kernel, n_gaussians, size):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of THIS workload committed under profiles/
-    (written by scripts/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE; the counters cannot be read from inside the run),
-    newest round first; None for any other workload."""
+    """HBM bytes per launch of `kernel` (one template variant, never an average over variants) from the rocprofv3 PMC
+    passes of THIS workload committed under profiles/ (written by scripts/pmc_summary.py: 2*FETCH_SIZE + WRITE_SIZE; the
+    counters cannot be read from inside the run), newest round first; None for any other workload."""
     if (n_gaussians, size) != (100000, 512) or kernel not in PMC_KERNEL:
         return None, None
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG, "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_traffic_c3.json")
         try:
             table = json.load(open(path))
         except (OSError, ValueError):
             continue
-        rows = [v for k, v in table.items() if k.startswith(PMC_KERNEL[kernel])]
-        if not rows:
+        row = table.get(PMC_KERNEL[kernel])
+        if row is None:
             continue
-        launches = sum(r["launches"] for r in rows)
-        return int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / max(1, launches)), os.path.basename(path)
+        return int(row["hbm_bytes_per_launch"]), os.path.basename(path)
     return None, None
 
 
@@ -108,7 +117,7 @@ def traversed_entries(state):
 def roofline_valu(kernel, variants, entries, avg_us, launches_per_step):
     """VALU / MFMA issue floor of a blend kernel: `entries` list entries x 4 waves per tile = (Gaussian, wave) pairs."""
     table = None
-    for tag in (PROFILE_TAG, "r01"):
+    for tag in (PROFILE_TAG, "r02", "r01"):
         try:
             table = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_blend_isa_counts.json")))
             src = f"{tag}_blend_isa_counts.json"
@@ -224,6 +233,14 @@ def main():
     ap.add_argument("--no-stable-targets", action="store_true", help="skip the second workload (rendered targets)")
     ap.add_argument("--no-graph", action="store_true", help="launch every operator eagerly instead of replaying a hipGraph")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
+    ap.add_argument("--no-host-frames", action="store_true",
+                    help="skip the PCIe-inclusive workload (frames in pinned host memory, uploaded one step ahead)")
+    ap.add_argument("--no-schedule", action="store_true",
+                    help="skip the reference_schedule workload (700 iterations across density-control events)")
+    ap.add_argument("--schedule-iterations", type=int, default=700)
+    ap.add_argument("--allow-eager-fallback", action="store_true",
+                    help="several ranks: if the step cannot be captured next to the collective library, time eager "
+                         "launches instead of failing (the line then says so in config.execution)")
     args = ap.parse_args()
 
     t_start = time.perf_counter()
@@ -314,6 +331,10 @@ def main():
                 log(f"step captured into a hipGraph (instance capacity {graph.capacity})")
             except Exception as exc:       # e.g. a collective library that cannot coexist with stream capture
                 why = f"{type(exc).__name__}: {exc}"
+                if world > 1 and not args.allow_eager_fallback:
+                    # a scaling line must never silently be an eager number
+                    raise SystemExit(f"rank {rank}: graph capture failed with {world} ranks ({why}); "
+                                     "pass --allow-eager-fallback to time eager launches instead")
                 log(f"graph capture failed ({why}); running the same HIP operators eagerly")
                 trainer._drop_graph()
                 diff_gauss.set_capacity_plan(None)
@@ -348,31 +369,174 @@ def main():
             overflow = graph.check_overflow()
             if overflow:
                 raise SystemExit(f"instance capacity exceeded during the timed region: {overflow}")
-        # Events cannot bracket kernels inside a replayed graph, so the per-kernel durations are measured
-        # right after the timed windows from the SAME restored state: the same number of steps run eagerly with
-        # HIP events around every kernel of the C ABI (the kernels and their inputs are the same).
+        # Per-kernel durations IN REPLAY MODE: the step is captured once more with every launch of the C ABI bracketed by
+        # external event-record nodes (instag_prof_graph_*: HIP events on the stream the kernel is launched on, inside the
+        # graph) and replayed the same number of steps from the SAME restored state; the kernels run next to the same
+        # concurrent branches as in the timed windows.  (The step is captured again WITHOUT running a train step:
+        # FaceTrainer._recapture.)  If the runtime refuses external event nodes the instrumented steps run eagerly.
         trainer.restore(snap)
         from instag_amd import mlp as mlp_ops
+        n_rendered = 0
+        if use_graph:
+            need = graph.plan.needed()
+            n_rendered = int(max(need)) if need else 0
+        kern, entries, mlp_stats, source = {}, None, None, None
+        if use_graph and not os.environ.get("INSTAG_BENCH_EAGER_EVENTS"):
+            try:
+                kern, entries, mlp_stats = replay_mode_durations(trainer, frames, snap)
+                source = "external event-record nodes inside the replayed hipGraph"
+            except Exception as exc:
+                log(f"graph-mode kernel timing unavailable ({type(exc).__name__}: {exc}); timing eager launches instead")
+                L.instag_prof_enable(0)
+                trainer.restore(snap)
+        if not kern:
+            trainer._drop_graph()
+            diff_gauss.set_capacity_plan(None)
+            L.instag_prof_enable(-1)
+            L.instag_prof_reset()
+            mlp_ops.STATS.update(fwd_flops=0, bwd_flops=0)
+            diff_gauss.KEEP_LAST_STATE = True
+            run(args.steps)
+            torch.cuda.synchronize()
+            diff_gauss.KEEP_LAST_STATE = False
+            entries = traversed_entries(diff_gauss.LAST_STATS.pop("state")) if rank == 0 else None
+            kern = read_kernels()
+            L.instag_prof_enable(0)
+            mlp_stats = dict(mlp_ops.STATS)
+            n_rendered = int(diff_gauss.LAST_STATS.get("num_rendered", 0))
+            source = "HIP events around eager launches (not the replayed graph)"
         trainer._drop_graph()
         diff_gauss.set_capacity_plan(None)
-        L.instag_prof_enable(-1)
-        L.instag_prof_reset()
-        mlp_ops.STATS.update(fwd_flops=0, bwd_flops=0)
-        diff_gauss.KEEP_LAST_STATE = True
-        run(args.steps)
-        torch.cuda.synchronize()
-        diff_gauss.KEEP_LAST_STATE = False
-        entries = traversed_entries(diff_gauss.LAST_STATS.pop("state")) if rank == 0 else None
+        med = statistics.median(times)
+        return dict(times=times, median=med, kern=kern, R=n_rendered, graph=use_graph, why=why, mlp=mlp_stats,
+                    entries=entries, durations_from=source)
+
+    def read_kernels():
         kern = {}
         for name, kid in KERNEL_IDS.items():
             ms, cnt = C.c_double(0), C.c_int64(0)
             L.instag_prof_read(kid, C.byref(ms), C.byref(cnt))
             if cnt.value:
                 kern[name] = {"launches": int(cnt.value), "avg_us": 1e3 * ms.value / cnt.value, "total_ms": ms.value}
-        L.instag_prof_enable(0)
-        med = statistics.median(times)
-        return dict(times=times, median=med, kern=kern, R=int(diff_gauss.LAST_STATS.get("num_rendered", 0)),
-                    graph=use_graph, why=why, mlp=dict(mlp_ops.STATS), entries=entries)
+        return kern
+
+    def replay_mode_durations(trainer, frames, snap):
+        import gc
+        from instag_amd import mlp as mlp_ops
+        _lib.check(L.instag_prof_graph_begin(512), "prof_graph_begin")
+        try:
+            L.instag_prof_enable(int(os.environ.get("INSTAG_BENCH_PROF_MASK", "-1")))
+            L.instag_prof_reset()
+            trainer._drop_graph(keep_mode=True)          # the next step() captures the step again, now instrumented
+            mlp_ops.STATS.update(fwd_flops=0, bwd_flops=0)
+            diff_gauss.KEEP_LAST_STATE = True
+            entries = None
+            for i in range(args.steps):
+                trainer.step(frames[i % len(frames)])
+                torch.cuda.synchronize()
+                if i == 0:
+                    diff_gauss.KEEP_LAST_STATE = False
+                    mlp_stats = {k: v * args.steps for k, v in mlp_ops.STATS.items()}    # counted at capture: one step's
+                    if L.instag_prof_graph_pairs_used() == 0:
+                        raise RuntimeError("no external event pair was captured")
+                _lib.check(L.instag_prof_graph_collect(), "prof_graph_collect")
+            if rank == 0:
+                entries = traversed_entries(diff_gauss.LAST_STATS.pop("state"))
+            else:
+                diff_gauss.LAST_STATS.pop("state", None)
+            kern = read_kernels()
+            return kern, entries, mlp_stats
+        finally:
+            diff_gauss.KEEP_LAST_STATE = False
+            L.instag_prof_enable(0)
+            trainer._drop_graph(keep_mode=True)          # the graphs that hold the pool's events go first
+            gc.collect()
+            torch.cuda.synchronize()
+            L.instag_prof_graph_end()
+
+    def measure_host_frames(windows):
+        """PCIe-inclusive variant of the headline workload: the frames live in pinned HOST memory and are uploaded one
+        step ahead on a copy stream (instag_amd/train.py HostFrameFeeder; train_face.py:324-327,
+        gaussian_renderer/__init__.py:188-189 upload them inside the step)."""
+        from instag_amd.train import HostFrameFeeder
+        trainer = build_trainer(N, dev, sh_degree=args.sh_degree, seed=0, densify=False)
+        frames = make_frames(trainer, False)
+        host = [HostFrameFeeder.to_host(f) for f in frames]
+        feeder = HostFrameFeeder(frames[0], dev)
+        graph = trainer.enable_graph(frames[0])
+
+        def run(n):
+            feeder.prefetch(host[0], 0)
+            for i in range(n):
+                if i + 1 < n:
+                    feeder.prefetch(host[(i + 1) % len(host)], (i + 1) % 2)
+                trainer.step(feeder.take(i % 2))
+                feeder.release(i % 2)
+
+        run(args.warmup)
+        torch.cuda.synchronize()
+        snap = trainer.snapshot()
+        times = []
+        for _ in range(windows):
+            trainer.restore(snap)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            run(args.steps)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            times.append(el)
+        overflow = graph.check_overflow()
+        if overflow:
+            raise SystemExit(f"instance capacity exceeded during the host-frames windows: {overflow}")
+        trainer._drop_graph()
+        diff_gauss.set_capacity_plan(None)
+        log("host frames (PCIe-inclusive): windows ms/step " + " ".join(f"{1e3 * t / args.steps:.3f}" for t in times))
+        return dict(times=times, median=statistics.median(times), bytes_per_frame=int(host[0]._buf.numel()))
+
+    def measure_schedule(iterations, densify):
+        """End-to-end throughput of a reference-schedule run (train_face.py:667-746: densify / prune / opacity reset every
+        100 iterations, arguments/__init__.py:92-97) from iteration 2900: crosses warm_step (3000: regularisers on, hair
+        iterations alternate with plain ones = two captured phases), the opacity reset at 3000 and a density-control
+        event every 100 iterations.  Every event drops the captured steps; step() captures them again by itself
+        (FaceTrainer._recapture).  densify=False is the control: same iterations and phases, no density control."""
+        trainer = build_trainer(N, dev, sh_degree=args.sh_degree, seed=0, densify=densify, schedule="reference")
+        frames = make_frames(trainer, True)
+        trainer.iteration = 2900
+        trainer.enable_graph(frames[0], keep_state=True)
+        n0 = trainer.g.num_points
+        counts, events = [n0], 0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(iterations):
+            due = trainer._densify_due(trainer.iteration + 1)
+            trainer.step(frames[i % len(frames)])
+            if due:
+                events += 1
+                counts.append(trainer.g.num_points)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        rec = trainer.recaptures
+        trainer._drop_graph()
+        diff_gauss.set_capacity_plan(None)
+        log(f"reference schedule (densify={densify}): {iterations} iterations in {el:.3f} s, {events} density-control "
+            f"events, {rec} re-captures, Gaussians {counts[0]} -> {counts[-1]}")
+        return dict(seconds=el, iterations=iterations, events=events, recaptures=rec, gaussians=counts)
 
     log(f"config: {N} Gaussians, {size}x{size}, world {world}")
     main_run = measure(False, max(1, args.windows))
@@ -380,22 +544,44 @@ def main():
     if not args.no_stable_targets:
         stable_run = measure(True, max(1, min(3, args.windows)))
 
+    host_run = None if args.no_host_frames else measure_host_frames(max(1, min(3, args.windows)))
+    sched_run = sched_ctrl = None
+    if not args.no_schedule:
+        sched_run = measure_schedule(args.schedule_iterations, True)
+        sched_ctrl = measure_schedule(args.schedule_iterations, False)
+
     if rank == 0:
         kern, R, med = main_run["kern"], main_run["R"], main_run["median"]
         P = size * size
         M = (args.sh_degree + 1) ** 2
         raster_kernels = [k for k in kern if k not in NON_RASTER]
-        dom = max(raster_kernels, key=lambda k: kern[k]["total_ms"]) if raster_kernels else None
-        roofline = None
-        if dom:
-            ab = algorithmic_bytes(dom, N, M, R, P, grid_points=N)
-            achieved = ab / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            traffic, traffic_src = pmc_traffic(dom, N, size)
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(kern[dom]["avg_us"], 2),
-                        "launches": kern[dom]["launches"], "num_rendered": R}
+        ent = main_run["entries"]
+        # One roofline object per blend launch VARIANT (each is a kernel of its own): its own algorithmic byte count
+        # (SURVEY 8d's per-instance / per-pixel figures x the measured R, P) / its own average launch duration.  Next to
+        # it: the bytes of the list entries the launch really walks (entries in front of each tile's last contributor)
+        # and the HBM bytes the PMC passes counted for that variant.  `roofline` is the variant furthest below the bound.
+        blend = {}
+        for k, (variant, per_r, per_p) in BLEND_VARIANTS.items():
+            if k not in kern:
+                continue
+            dur = kern[k]["avg_us"] * 1e-6
+            ab = per_r * R + per_p * P
+            walked = ent["bwd" if k != "blend_fwd" else "fwd_min"] if ent else None
+            traffic, traffic_src = pmc_traffic(k, N, size)
+            blend[k] = {"bound": "hbm", "kernel": k, "variant": variant, "achieved": round(ab / dur / 1e9, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / dur / 1e9 / HBM_PEAK_GBS, 5),
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "achieved_counter": None if traffic is None else round(traffic / dur / 1e9, 2),
+                        "algorithmic_bytes_per_launch": ab, "bytes_per_instance": per_r, "bytes_per_pixel": per_p,
+                        "walked_entries": walked,
+                        "walked_bytes": None if walked is None else per_r * walked + per_p * P,
+                        "achieved_walked": None if walked is None else round((per_r * walked + per_p * P) / dur / 1e9, 2),
+                        "avg_launch_us": round(kern[k]["avg_us"], 2), "launches": kern[k]["launches"],
+                        "num_rendered": R, "durations_from": main_run["durations_from"]}
+        roofline = min(blend.values(), key=lambda r: r["frac"]) if blend else None
+        dom = roofline["kernel"] if roofline else None
+        if roofline:
+            roofline = dict(roofline, blend_launches={k: v for k, v in blend.items() if k != dom})
         # the other two figures SURVEY.md 8(d) asks for: hash-grid GB/s (HBM) and the MLP kernels' MFMA rate
         secondary = {}
         for k in ("grid_fwd", "grid_bwd"):
@@ -414,14 +600,14 @@ def main():
                                 "launches_per_step": kern[k]["launches"] // max(1, args.steps)}
         # the blend kernels are instruction-issue bound, not HBM bound: their VALU / MFMA floors
         valu = {}
-        ent = main_run["entries"]
         if ent and "blend_bwd" in kern:
-            # this step launches the colour pass (aux colours in its idle GEMM columns) and the mean-only aux pass
-            valu["blend_bwd"] = roofline_valu("blend_bwd", [("blend_backward_kernel<false, 2, false>", 2),
-                                                            ("blend_backward_kernel<false, 0, true>", 1)],
-                                              ent["bwd"], kern["blend_bwd"]["avg_us"], 2)
+            valu["blend_bwd"] = roofline_valu("blend_bwd", [(BLEND_VARIANTS["blend_bwd"][0], 2)], ent["bwd"],
+                                              kern["blend_bwd"]["avg_us"], 1)
+        if ent and "blend_bwd_mean" in kern:
+            valu["blend_bwd_mean"] = roofline_valu("blend_bwd_mean", [(BLEND_VARIANTS["blend_bwd_mean"][0], 1)],
+                                                   ent["bwd"], kern["blend_bwd_mean"]["avg_us"], 1)
         if ent and "blend_fwd" in kern:
-            valu["blend_fwd"] = roofline_valu("blend_fwd", [("blend_forward_kernel<true>", 0)], ent["fwd_min"],
+            valu["blend_fwd"] = roofline_valu("blend_fwd", [(BLEND_VARIANTS["blend_fwd"][0], 0)], ent["fwd_min"],
                                               kern["blend_fwd"]["avg_us"], 1)
             if valu["blend_fwd"]:
                 valu["blend_fwd"]["pairs_are"] = "a lower bound (entries up to the tile's last contributor)"
@@ -443,9 +629,9 @@ def main():
                                  "same snapshotted state"},
             "windows_ms_per_step": [round(1e3 * t / args.steps, 4) for t in main_run["times"]],
             "roofline": roofline,
-            "roofline_valu": (valu.get(dom) or valu.get("blend_bwd")) and dict(
-                valu.get(dom) or valu["blend_bwd"], other={k: v for k, v in valu.items() if v and k != dom},
-                walked=ent),
+            "roofline_valu": valu.get(dom) and dict(valu[dom], other={k: v for k, v in valu.items() if v and k != dom},
+                                                    walked=ent),
+            "kernel_durations_from": main_run["durations_from"],
             "secondary_rooflines": secondary,
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()},
             "raster_fwd_bwd_ms_per_frame": round(sum(v["total_ms"] for k, v in kern.items()
@@ -462,6 +648,32 @@ def main():
                 "num_rendered": stable_run["R"],
                 "kernels_us": {k: round(v["avg_us"], 2) for k, v in stable_run["kern"].items()
                                if k in ("blend_fwd", "blend_bwd", "sort", "preprocess")}}
+        if host_run is not None:
+            hm = host_run["median"]
+            out["host_frames"] = {
+                "workload": "same step, PCIe-inclusive: every frame (image, masks, audio window, expression vector = one "
+                            "packed buffer) lives in pinned host memory and is uploaded one step ahead on a copy stream "
+                            "into a device staging buffer (the reference uploads inside the step, train_face.py:324-327)",
+                "value": round(world * args.steps / hm, 3), "unit": "frames/s",
+                "ms_per_step": round(1e3 * hm / args.steps, 4),
+                "windows_ms_per_step": [round(1e3 * t / args.steps, 4) for t in host_run["times"]],
+                "host_bytes_per_frame": host_run["bytes_per_frame"],
+                "vs_resident": round((args.steps / hm) / (args.steps / med), 4)}
+        if sched_run is not None:
+            fps = world * sched_run["iterations"] / sched_run["seconds"]
+            out["reference_schedule"] = {
+                "workload": "train_face schedule from iteration 2900 (crosses warm_step, the opacity reset at 3000 and a "
+                            "densify / prune event every 100 iterations; hair and plain iterations alternate), rendered "
+                            "targets, end to end INCLUDING density control and the re-captures of the step it forces",
+                "value": round(fps, 3), "unit": "frames/s", "iterations": sched_run["iterations"],
+                "seconds": round(sched_run["seconds"], 4), "density_control_events": sched_run["events"],
+                "recaptures": sched_run["recaptures"], "gaussians_after_each_event": sched_run["gaussians"],
+                "vs_headline": round(fps / value, 4)}
+            if sched_ctrl is not None:
+                cfps = world * sched_ctrl["iterations"] / sched_ctrl["seconds"]
+                out["reference_schedule"]["same_schedule_without_density_control"] = {
+                    "value": round(cfps, 3), "unit": "frames/s", "recaptures": sched_ctrl["recaptures"]}
+                out["reference_schedule"]["vs_no_density_control"] = round(fps / cfps, 4)
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle baseline (bounded sample)")
             out["cpu_baseline"] = cpu_baseline(N, size, args.sh_degree, args.cpu_budget)

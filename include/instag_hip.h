@@ -246,6 +246,17 @@ int instag_debug_depth_sort(const instag_raster_args* a, void* geom, size_t geom
                             uint32_t* order_out, instag_stream_t stream);
 uint32_t instag_debug_depth_sort_blocks(int32_t N);
 
+/* The binning sorts and the instance-offset scan order their workgroups by decoupled look-back with a bounded spin.
+ * A look-back that gives up continues with a wrong prefix -- a mis-sorted list, a wrong image -- so every such event
+ * bumps a sticky device counter.  instag_raster_forward_stage1 reads it at its synchronisation point and fails with
+ * INSTAG_E_HIP; capacity-mode callers (no synchronisation per step) read it here: *count = events since the last clear.
+ * synchronize = 0: `count` must be pinned host memory, the copy is only enqueued on `stream`. */
+int instag_raster_sort_stalls(uint32_t* count, int32_t synchronize, instag_stream_t stream);
+int instag_raster_sort_stalls_clear(instag_stream_t stream);
+/* Test hook: runs the offset scan over 8 items with its ticket counter pre-set so that the one workgroup looks back at
+ * a predecessor that never publishes; returns after the bounded spin has expired (about a second). */
+int instag_debug_scan_stall_probe(instag_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Bias-free ReLU MLP over N rows on the f32 matrix cores (exact fp32).
  * Replaces the per-Gaussian `MLP` modules of scene/motion_net.py:152-173 (sigma_net, aud_ch_att_net,
@@ -568,12 +579,24 @@ int instag_adam_step(const void* tensors, int32_t n_tensors, const void* groups,
  * returns accumulated milliseconds and launch count since the last reset.
  * Kernel ids: 0 preprocess, 1 duplicate, 2 sort, 3 ranges, 4 blend_fwd, 5 blend_bwd,
  *             6 preprocess_bwd, 7 grid_fwd, 8 grid_bwd, 9 sh_fwd, 10 sh_bwd,
- *             11 mlp_fwd, 12 mlp_bwd, 13 mlp_weight_grad, 14 loss_fwd, 15 loss_bwd.
+ *             11 mlp_fwd, 12 mlp_bwd, 13 mlp_weight_grad, 14 loss_fwd, 15 loss_bwd,
+ *             16 blend_bwd mean-only launch (the auxiliary image's d/dmean pass; 5 = every other blend_bwd launch).
+ *
+ * Inside a hipGraph: a launch issued while its stream is being CAPTURED is bracketed with EXTERNAL event-record nodes
+ * (hipEventRecordWithFlags(hipEventRecordExternal)) taken from a pool the caller sized with instag_prof_graph_begin --
+ * events cannot be created while a capture is open.  Every replay of the captured graph re-records them;
+ * instag_prof_graph_collect (after the replay has been synchronised) adds each pair's elapsed time to its kernel's
+ * totals, so the durations are those of the kernels as they run in the replayed graph, next to their concurrent
+ * branches.  instag_prof_graph_end destroys the pool (the graphs that captured its events must be gone by then).
  * ------------------------------------------------------------------------------------------ */
-#define INSTAG_PROF_KERNELS 16
+#define INSTAG_PROF_KERNELS 17
 int instag_prof_enable(int kernel_mask_or_minus1);
 int instag_prof_reset(void);
 int instag_prof_read(int kernel_id, double* total_ms /* (host) */, int64_t* launches /* (host) */);
+int instag_prof_graph_begin(int32_t max_pairs);
+int instag_prof_graph_pairs_used(void);
+int instag_prof_graph_collect(void);
+int instag_prof_graph_end(void);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,53 @@ class RasterArgs(C.Structure):
     ]
 
 
+# ---- streams -------------------------------------------------------------------------------------------------------
+# torch.cuda.Stream() does not create a HIP stream: it hands out the next of 32 pooled streams per (device, priority),
+# round robin.  A process that asks for more than 32 -- every capture used to take a fresh "capture stream" and a fresh
+# warm-up stream, every module kept its own cache of side streams -- therefore gets the SAME HIP stream under two
+# Python objects: a forked pass and the lane it forks to, a "leaf" stream and an operator's side lane, two branches of
+# one captured step.  Every stream of the package now comes from this registry: one per (device, purpose), created once
+# (outside any capture) and guaranteed distinct from every other stream the registry handed out.
+_STREAMS = {}
+
+
+def side_stream(device, tag, priority=0):
+    """The persistent HIP stream of purpose ``tag`` on ``device`` (distinct handles for distinct tags)."""
+    import torch
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, tag)
+    s = _STREAMS.get(key)
+    if s is None:
+        taken = {v.cuda_stream for (d, _), v in _STREAMS.items() if d == index}
+        for _ in range(64):
+            s = torch.cuda.Stream(device=torch.device("cuda", index), priority=priority)
+            if s.cuda_stream not in taken:
+                break
+        else:
+            raise RuntimeError(f"no distinct HIP stream left for {tag!r} ({len(taken)} in use on device {index})")
+        _STREAMS[key] = s
+    return s
+
+
+def capture_stream(device=None):
+    """THE stream every step of the package is captured on (one per device, high priority: the side streams operators
+    fork from it keep the default priority, so the nodes of the step's critical chain win the arbitration where they
+    share the chip -- C3 step 0.5-2.5 % faster).  One stream for all captures, because the autograd engine runs a
+    parameter's AccumulateGrad on the stream that was current when the node was created: with a stream per capture a
+    node kept alive across captures made the engine hop to the EARLIER capture's stream inside the open capture (an
+    un-announced fork; PyTorch's "AccumulateGrad node's stream does not match" warning)."""
+    import torch
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return side_stream(device, "capture", priority=-1)
+
+
+def warmup_stream(device):
+    """Side stream for the eager capacity-mode warm-up steps in front of a capture."""
+    return side_stream(device, "warmup")
+
+
 # ---- stream capture bookkeeping -------------------------------------------------------------------------------------
 # A fork of a fork inside ONE stream capture (origin stream -> stream A -> stream B, B joined back into A, A into the
 # origin) crashes hipStreamEndCapture on ROCm 7.2 (segmentation fault inside capture_end; bisected with
@@ -59,15 +106,14 @@ _CAPTURE_ORIGIN = None
 
 
 class graph_capture:
-    """``torch.cuda.graph(graph, **kw)`` that also records the capture's origin stream for may_fork()."""
+    """``torch.cuda.graph(graph, **kw)`` on the package's capture stream that also records the capture's origin stream
+    for may_fork() and releases the cross-stream tensors held for the capture (_keepalive) when it has ended --
+    whether it succeeded or raised."""
 
     def __init__(self, graph, **kw):
         import torch
         if "stream" not in kw:
-            # capture on a high-priority stream: the side streams operators fork from it (weight gradients, auxiliary
-            # blend pass) keep the default priority, and the nodes of the step's critical chain win the arbitration
-            # where they share the chip with them (C3 step: 0.5-2.5 % faster, four interleaved runs on two boxes)
-            kw = dict(kw, stream=torch.cuda.Stream(priority=-1))
+            kw = dict(kw, stream=capture_stream())
         self._ctx = torch.cuda.graph(graph, **kw)
 
     def __enter__(self):
@@ -81,12 +127,17 @@ class graph_capture:
     def __exit__(self, *exc):
         global _CAPTURE_ORIGIN
         _CAPTURE_ORIGIN = self._prev
-        return self._ctx.__exit__(*exc)
+        try:
+            return self._ctx.__exit__(*exc)
+        finally:
+            from . import _keepalive
+            _keepalive.release()
 
 
 def may_fork(device=None) -> bool:
-    """May an operator fork work onto a second stream from the current stream?  Always outside a capture; inside one
-    only from the capture's origin stream (a capture somebody else opened: origin unknown -> no)."""
+    """May an operator fork work onto a second stream from the current stream?  Outside a capture: unless the current
+    stream carries a whole forked pass (leaf_stream); inside one only from the capture's origin stream (a capture
+    somebody else opened: origin unknown -> no)."""
     import torch
     if _LEAF_STREAMS and any(torch.cuda.current_stream(device) == s for s in _LEAF_STREAMS):
         return False
@@ -139,6 +190,9 @@ _PROTOS = {
     "instag_raster_debug_export_flags": (C.c_int, [vp, sz, i32, vp, vp]),
     "instag_debug_depth_sort": (C.c_int, [C.POINTER(RasterArgs), vp, sz, vp, vp, vp]),
     "instag_debug_depth_sort_blocks": (C.c_uint32, [i32]),
+    "instag_raster_sort_stalls": (C.c_int, [vp, i32, vp]),
+    "instag_raster_sort_stalls_clear": (C.c_int, [vp]),
+    "instag_debug_scan_stall_probe": (C.c_int, [vp]),
     "instag_mlp_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward_add": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -200,12 +254,16 @@ _PROTOS = {
     "instag_prof_enable": (C.c_int, [C.c_int]),
     "instag_prof_reset": (C.c_int, []),
     "instag_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),
+    "instag_prof_graph_begin": (C.c_int, [i32]),
+    "instag_prof_graph_pairs_used": (C.c_int, []),
+    "instag_prof_graph_collect": (C.c_int, []),
+    "instag_prof_graph_end": (C.c_int, []),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
-ABI_VERSION = 8     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
+ABI_VERSION = 9     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
 
 
 def lib():

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import check, ptr
 
 NPARAM = 26
+_ARRIVAL_SLOTS = 64
 
 
 def _ptr_array(tensors):
@@ -132,10 +133,19 @@ def frame_codes(field, a, e):
     # arrival counter of the forward's eight workgroups: one word per network (the universal and the personalised
     # field's branches run on different streams at the same time), zero between launches
     # (and per stream: frames streamed through several lanes at once must not share it either)
-    table = field.__dict__.setdefault("_frame_code_arrivals", {})
-    key = (a.device, torch.cuda.current_stream(a.device).cuda_stream)
-    arrivals = table.get(key)
-    if arrivals is None:
-        arrivals = table[key] = torch.zeros(1, dtype=torch.int32, device=a.device)
+    # The words live in ONE table per (network, device), allocated outside any capture: a word first needed inside a
+    # capture is a free slot of that table, never memory of the capture's private pool that would outlive its graph.
+    # (Every stream of the package is a persistent registry stream, _lib.side_stream: handles are never reused.)
+    capturing = torch.cuda.is_current_stream_capturing()
+    tables = field.__dict__.setdefault("_frame_code_arrivals", {})
+    entry = tables.get(a.device)
+    if entry is None and not capturing:
+        entry = tables[a.device] = (torch.zeros(_ARRIVAL_SLOTS, dtype=torch.int32, device=a.device), {})
+    handle = torch.cuda.current_stream(a.device).cuda_stream
+    if entry is not None and (handle in entry[1] or len(entry[1]) < _ARRIVAL_SLOTS):
+        slot = entry[1].setdefault(handle, len(entry[1]))
+        arrivals = entry[0][slot:slot + 1]
+    else:
+        arrivals = torch.zeros(1, dtype=torch.int32, device=a.device)      # owned by this call (and its capture) only
     enc_a, enc_e = _FrameCodes.apply(a, None if e is None else e.reshape(-1), dims, arrivals, *params)
     return enc_a, (enc_e if e is not None else None)

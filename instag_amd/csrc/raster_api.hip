@@ -22,6 +22,10 @@ struct ProfState {
   std::vector<Pair> pending[INSTAG_PROF_KERNELS];
   double total_ms[INSTAG_PROF_KERNELS] = {0};
   int64_t launches[INSTAG_PROF_KERNELS] = {0};
+  // pool for launches that are being captured into a graph (instag_prof_graph_*)
+  struct GraphPair { hipEvent_t a = nullptr, b = nullptr; int kernel = -1; bool closed = false; };
+  std::vector<GraphPair> graph_pool;
+  int graph_used = 0;
 };
 ProfState& prof() { static ProfState p; return p; }
 }  // namespace
@@ -29,10 +33,29 @@ ProfState& prof() { static ProfState p; return p; }
 ProfScope::ProfScope(int kernel, hipStream_t stream) : kernel_(kernel), stream_(stream) {
   ProfState& p = prof();
   if (!(p.mask & (1 << kernel))) return;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream_, &cs) != hipSuccess) return;
+  if (cs != hipStreamCaptureStatusNone) {
+    // captured launch: external event-record nodes from the pool (no event may be created while a capture is open)
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (p.graph_used >= (int)p.graph_pool.size()) return;
+    ProfState::GraphPair& g = p.graph_pool[p.graph_used];
+    if (hipEventRecordWithFlags(g.a, stream_, hipEventRecordExternal) != hipSuccess) return;
+    g.kernel = kernel;
+    graph_slot_ = p.graph_used++;
+    return;
+  }
   if (hipEventCreate(&start_) != hipSuccess) { start_ = nullptr; return; }
   (void)hipEventRecord(start_, stream_);
 }
 ProfScope::~ProfScope() {
+  if (graph_slot_ >= 0) {
+    ProfState& p = prof();
+    std::lock_guard<std::mutex> lk(p.mu);
+    ProfState::GraphPair& g = p.graph_pool[graph_slot_];
+    g.closed = hipEventRecordWithFlags(g.b, stream_, hipEventRecordExternal) == hipSuccess;
+    return;
+  }
   if (!start_) return;
   hipEvent_t stop;
   if (hipEventCreate(&stop) != hipSuccess) { (void)hipEventDestroy(start_); return; }
@@ -245,7 +268,7 @@ using namespace instag;
 extern "C" {
 
 const char* instag_last_error(void) { return g_err.c_str(); }
-int instag_abi_version(void) { return 8; }
+int instag_abi_version(void) { return 9; }
 
 size_t instag_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t instag_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }
@@ -268,9 +291,15 @@ int instag_raster_forward_stage1(const instag_raster_args* a, void* geom, size_t
   const Camera c = make_camera(a);
   uint32_t* point_offsets = (uint32_t*)(gb + L.point_offsets);
   if (int e = per_gaussian_stage(a, c, gb, L, radii, s)) return e;
-  uint32_t r32 = 0;
+  uint32_t r32 = 0, stalls = 0;
   INSTAG_CHECK_HIP(hipMemcpyAsync(&r32, point_offsets + (a->N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  INSTAG_CHECK_HIP(hipStreamSynchronize(s));
+  if (int e = read_sort_stalls(&stalls, s, /*synchronize=*/true)) return e;
+  if (stalls != 0) {
+    // (sticky: also reports a stall of an EARLIER call's tile sort, which has no synchronisation point of its own)
+    set_error("rasterizer binning: a sort / scan look-back gave up waiting for its predecessor (" +
+              std::to_string(stalls) + " event(s)); the lists of the affected call are wrong");
+    return INSTAG_E_HIP;
+  }
   *num_rendered = (int64_t)r32;
   return INSTAG_OK;
 }
@@ -547,6 +576,34 @@ int instag_debug_depth_sort(const instag_raster_args* a, void* geom, size_t geom
 
 uint32_t instag_debug_depth_sort_blocks(int32_t N) { return geom_layout(N).dsort_blocks; }
 
+int instag_raster_sort_stalls(uint32_t* count, int32_t synchronize, instag_stream_t stream_) {
+  INSTAG_REQUIRE(count != nullptr, "sort_stalls: count is NULL");
+  return read_sort_stalls(count, (hipStream_t)stream_, synchronize != 0);
+}
+
+int instag_raster_sort_stalls_clear(instag_stream_t stream_) { return clear_sort_stalls((hipStream_t)stream_); }
+
+int instag_debug_scan_stall_probe(instag_stream_t stream_) {
+  hipStream_t s = (hipStream_t)stream_;
+  constexpr int N = 8;
+  // [order N][tiles_touched N][point_offsets N] u32, then the scan state (u64: ticket, look-back words)
+  uint32_t host[3 * N];
+  for (int i = 0; i < N; ++i) { host[i] = (uint32_t)i; host[N + i] = 1u; host[2 * N + i] = 0u; }
+  const uint64_t state_host[4] = {1ull, 0ull, 0ull, 0ull};      // ticket = 1: the block becomes block 1, block 0 never runs
+  char* dev = nullptr;
+  INSTAG_CHECK_HIP(hipMalloc((void**)&dev, sizeof(host) + sizeof(state_host)));
+  hipError_t err = hipMemcpyAsync(dev, host, sizeof(host), hipMemcpyHostToDevice, s);
+  if (err == hipSuccess) err = hipMemcpyAsync(dev + sizeof(host), state_host, sizeof(state_host), hipMemcpyHostToDevice, s);
+  int rc = INSTAG_OK;
+  if (err == hipSuccess)
+    rc = launch_scan_counts(N, (const uint32_t*)dev, (const uint32_t*)dev + N, (uint32_t*)dev + 2 * N,
+                            (uint64_t*)(dev + sizeof(host)), s);
+  if (err == hipSuccess) err = hipStreamSynchronize(s);
+  (void)hipFree(dev);
+  if (err != hipSuccess) { set_error(std::string("scan_stall_probe: ") + hipGetErrorString(err)); return INSTAG_E_HIP; }
+  return rc;
+}
+
 int instag_prof_enable(int mask) {
   ProfState& p = prof();
   std::lock_guard<std::mutex> lk(p.mu);
@@ -575,6 +632,61 @@ int instag_prof_reset(void) {
     p.total_ms[k] = 0;
     p.launches[k] = 0;
   }
+  return INSTAG_OK;
+}
+
+int instag_prof_graph_end(void);
+
+int instag_prof_graph_begin(int32_t max_pairs) {
+  INSTAG_REQUIRE(max_pairs > 0 && max_pairs <= 4096, "prof_graph_begin: max_pairs out of range");
+  if (int e = instag_prof_graph_end()) return e;
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  p.graph_pool.resize(max_pairs);
+  for (auto& g : p.graph_pool) {
+    INSTAG_CHECK_HIP(hipEventCreate(&g.a));
+    INSTAG_CHECK_HIP(hipEventCreate(&g.b));
+  }
+  p.graph_used = 0;
+  return INSTAG_OK;
+}
+
+int instag_prof_graph_pairs_used(void) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  int n = 0;
+  for (int i = 0; i < p.graph_used; ++i) n += p.graph_pool[i].closed ? 1 : 0;
+  return n;
+}
+
+int instag_prof_graph_collect(void) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  for (int i = 0; i < p.graph_used; ++i) {
+    const ProfState::GraphPair& g = p.graph_pool[i];
+    if (!g.closed || g.kernel < 0) continue;
+    float ms = 0.f;
+    if (hipEventSynchronize(g.b) == hipSuccess && hipEventElapsedTime(&ms, g.a, g.b) == hipSuccess) {
+      p.total_ms[g.kernel] += ms;
+      p.launches[g.kernel] += 1;
+    } else {
+      (void)hipGetLastError();
+      set_error("prof_graph_collect: a captured event pair could not be read (was the graph replayed and synchronised?)");
+      return INSTAG_E_HIP;
+    }
+  }
+  return INSTAG_OK;
+}
+
+int instag_prof_graph_end(void) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  for (auto& g : p.graph_pool) {
+    if (g.a) (void)hipEventDestroy(g.a);
+    if (g.b) (void)hipEventDestroy(g.b);
+  }
+  p.graph_pool.clear();
+  p.graph_used = 0;
   return INSTAG_OK;
 }
 

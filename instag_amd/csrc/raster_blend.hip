@@ -625,7 +625,7 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
   // at most 16 workgroups per CU: enough to fill every slot the LDS footprint allows four times over; a workgroup
   // takes further segments of the list in strides of the grid
   const uint32_t grid = std::min<uint32_t>(seg_slots, 4096u);
-  ProfScope p(K_BLEND_BWD, s);
+  ProfScope p(aux_mode == 3 ? K_BLEND_BWD_MEAN : K_BLEND_BWD, s);
 #define INSTAG_BB(F, A, X, d, n, e, ax, dax)                                                                            \
   blend_backward_kernel<F, A, X><<<grid, BLOCK, 0, s>>>(c, ranges, point_list, slot_list, rec2d, n_contrib, final_T,     \
                                                        dL_dcolor, d, n, dL_dalpha, e, inst_grad, color_override, ax,    \

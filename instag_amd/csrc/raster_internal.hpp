@@ -55,6 +55,8 @@ int launch_radix_pass(int ipt, bool has_values, bool write_keys, const uint32_t*
                       const uint32_t* vals_in, uint32_t* vals_out, const uint32_t* count_ptr, uint32_t count_max,
                       int shift, int nbits, const uint32_t* hist, int n_hist, int hist_stride, uint32_t* ticket,
                       uint32_t* lookback, hipStream_t s, uint64_t* stamps = nullptr);
+int read_sort_stalls(uint32_t* host_out, hipStream_t s, bool synchronize);
+int clear_sort_stalls(hipStream_t s);
 int launch_hist_reduce(const uint32_t* partials, int nblk, int npass, int slices, uint32_t* out, hipStream_t s);
 int launch_scan_counts(int N, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* point_offsets,
                        uint64_t* state, hipStream_t s);

@@ -28,6 +28,11 @@ constexpr int SPIN_LIMIT = 1 << 21;
 constexpr int LB_CHUNK = 8;
 constexpr uint32_t LB_PARTIAL = 1u << 30, LB_COMPLETE = 2u << 30, LB_FLAGS = 3u << 30, LB_VALUE = ~LB_FLAGS;
 
+// A look-back that gave up (SPIN_LIMIT polls without the predecessor publishing) continues with a wrong prefix: the
+// lists it produces are mis-sorted.  That must never pass silently: every such event bumps this sticky counter, which
+// the host reads at its synchronising calls (instag_raster_forward_stage1, instag_raster_sort_stalls).
+__device__ uint32_t g_sort_stalls = 0;
+
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -206,6 +211,7 @@ radix_pass_kernel(const uint32_t* __restrict__ keys_in, uint32_t* __restrict__ k
                 __builtin_amdgcn_s_sleep(1);
                 st[j] = ld_agent(p);
               }
+              if ((st[j] & LB_FLAGS) == 0u) atomicAdd(&g_sort_stalls, 1u);     // gave up: the result is wrong, say so
             }
             excl += st[j] & LB_VALUE;
             done = (st[j] & LB_FLAGS) == LB_COMPLETE;
@@ -305,15 +311,17 @@ scan_counts_kernel(int N, const uint32_t* __restrict__ order, const uint32_t* __
       const int64_t pb = b - 1 - tid;
       uint64_t st = pb >= 0 ? ld_agent64(lb + pb) : SB_COMPLETE;
       int fc = 64;
+      bool settled = false;
       for (int polls = 0; polls < SPIN_LIMIT; ++polls) {
         const uint64_t cm = __builtin_amdgcn_ballot_w64((st & SB_FLAGS) == SB_COMPLETE);
         const uint64_t em = __builtin_amdgcn_ballot_w64((st & SB_FLAGS) == 0ull);
         fc = cm ? __builtin_ctzll(cm) : 64;
         const uint64_t need = fc >= 63 ? ~0ull : ((2ull << fc) - 1ull);
-        if ((em & need) == 0ull) break;
+        if ((em & need) == 0ull) { settled = true; break; }
         __builtin_amdgcn_s_sleep(1);
         if ((st & SB_FLAGS) == 0ull) st = ld_agent64(lb + pb);
       }
+      if (!settled && tid == 0) atomicAdd(&g_sort_stalls, 1u);                 // gave up: the offsets are wrong, say so
       uint64_t v = (tid <= fc) ? (st & ~SB_FLAGS) : 0ull;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -373,6 +381,20 @@ int launch_hist_reduce(const uint32_t* partials, int nblk, int npass, int slices
   if (npass <= 0 || nblk <= 0) return INSTAG_OK;
   hist_reduce_kernel<<<dim3(npass, slices), SORT_THREADS, 0, s>>>(partials, nblk, npass, div_up(nblk, slices), out);
   INSTAG_CHECK_LAUNCH();
+  return INSTAG_OK;
+}
+
+int read_sort_stalls(uint32_t* host_out, hipStream_t s, bool synchronize) {
+  INSTAG_CHECK_HIP(hipMemcpyFromSymbolAsync(host_out, HIP_SYMBOL(g_sort_stalls), sizeof(uint32_t), 0,
+                                            hipMemcpyDeviceToHost, s));
+  if (synchronize) INSTAG_CHECK_HIP(hipStreamSynchronize(s));
+  return INSTAG_OK;
+}
+
+int clear_sort_stalls(hipStream_t s) {
+  const uint32_t zero = 0;
+  INSTAG_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sort_stalls), &zero, sizeof(uint32_t), 0, hipMemcpyHostToDevice, s));
+  INSTAG_CHECK_HIP(hipStreamSynchronize(s));
   return INSTAG_OK;
 }
 

@@ -38,7 +38,7 @@ def flush_async(device):
     key = (device.type, device.index)
     side = _STATE["streams"].get(key)
     if side is None:
-        side = _STATE["streams"][key] = torch.cuda.Stream(device=device)
+        side = _STATE["streams"][key] = _lib.side_stream(device, "weight_grads")
     main = torch.cuda.current_stream(device)
     side.wait_stream(main)
     with torch.cuda.stream(side):

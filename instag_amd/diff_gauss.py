@@ -86,8 +86,13 @@ class CapacityPlan:
 
     def overflowed(self):
         """Host check (synchronises): list of (slot, largest R needed) of every slot whose capacity was exceeded by ANY
-        call since the last clear() -- the flag is sticky on the device, so a check after many replays misses nothing."""
+        call since the last clear() -- the flag is sticky on the device, so a check after many replays misses nothing.
+        Raises if a binning sort / scan look-back gave up in the meantime (its lists are wrong: sort_stalls())."""
         st = self._all.cpu()
+        stalls = sort_stalls()
+        if stalls:
+            raise RuntimeError(f"rasterizer binning: {stalls} sort / scan look-back(s) gave up waiting for their "
+                               "predecessor since the last check; the affected steps rendered wrong tile lists")
         return [(k, int(st[k, 2])) for k in range(len(self.capacities)) if int(st[k, 1]) != 0]
 
     def poll_overflow(self):
@@ -96,12 +101,18 @@ class CapacityPlan:
         result = None
         if self._event is not None and self._event.query():
             st = self._host
+            if int(self._host_stalls[0]) != 0:
+                raise RuntimeError(f"rasterizer binning: {int(self._host_stalls[0])} sort / scan look-back(s) gave up "
+                                   "waiting for their predecessor; the affected steps rendered wrong tile lists")
             result = [(k, int(st[k, 2])) for k in range(len(self.capacities)) if int(st[k, 1]) != 0]
             self._event = None
         if self._event is None:
             if self._host is None:
                 self._host = torch.zeros(len(self.capacities), 4, dtype=torch.int32).pin_memory()
+                self._host_stalls = torch.zeros(1, dtype=torch.int32).pin_memory()
             self._host.copy_(self._all, non_blocking=True)
+            check(_lib.lib().instag_raster_sort_stalls(C.c_void_p(self._host_stalls.data_ptr()), 0,
+                                                       _lib.current_stream()), "sort_stalls")
             self._event = torch.cuda.Event()
             self._event.record()
         return result
@@ -117,6 +128,16 @@ class CapacityPlan:
     def clear(self):
         self._all.zero_()
         self._event = None
+
+
+def sort_stalls(clear: bool = False) -> int:
+    """Sticky count of binning look-backs that gave up (csrc/raster_sort.hip g_sort_stalls); synchronises."""
+    L = _lib.lib()
+    n = C.c_uint32(0)
+    check(L.instag_raster_sort_stalls(C.byref(n), 1, _lib.current_stream()), "sort_stalls")
+    if clear and n.value:
+        check(L.instag_raster_sort_stalls_clear(_lib.current_stream()), "sort_stalls_clear")
+    return int(n.value)
 
 
 _CAPACITY_PLAN = None
@@ -244,6 +265,14 @@ def join_pending_aux(final: bool = False):
 # launch on the tail of the step: set FOLD_AUX_M2D around backward, call take_folded_aux(leaf) right after it.
 FOLD_AUX_M2D = False
 _FOLDED = []
+
+
+def reset_aux_state():
+    """Forget every pending / folded aux share (the backward pass that produced them raised)."""
+    global FOLD_AUX_M2D
+    FOLD_AUX_M2D = False
+    del _PENDING_AUX[:]
+    del _FOLDED[:]
 
 
 def take_folded_aux(leaf):
@@ -387,7 +416,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             key = (dev.type, dev.index)
             side = _AUX_STREAMS.get(key)
             if side is None:
-                side = _AUX_STREAMS[key] = torch.cuda.Stream(device=dev)
+                side = _AUX_STREAMS[key] = _lib.side_stream(dev, "aux_backward")
             # (starting the mean-only pass BEHIND the main blend launch instead of beside it was measured: the main launch
             # got 35 us shorter, the step 35 us longer -- the pass then competes with the memory-bound kernels downstream)
             side.wait_event(ready)

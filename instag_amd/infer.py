@@ -77,7 +77,7 @@ class FuseRenderer:
         cap = int(max(needed) * headroom * max(1.0, n_face / max(1, n_mouth))) + 4096
         self._plan = diff_gauss.CapacityPlan([cap, cap] * K, dev)
         diff_gauss.set_capacity_plan(self._plan)
-        lanes = [torch.cuda.Stream(device=dev) for _ in range(K)]
+        lanes = [_lib.side_stream(dev, ("infer_lane", k)) for k in range(K)]
 
         def all_frames():
             """frame k on lane k, forked from / joined into the current stream.  (On a forked lane the operators keep
@@ -95,7 +95,7 @@ class FuseRenderer:
                 main.wait_stream(lanes[k])
             return outs
 
-        s = torch.cuda.Stream(device=dev)
+        s = _lib.warmup_stream(dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             for _ in range(2):
@@ -108,8 +108,6 @@ class FuseRenderer:
         with _no_gc(), _lib.graph_capture(self._graph):
             outs = all_frames()
             self._out = torch.stack(outs)
-        from . import _keepalive
-        _keepalive.release()
         self._lanes = lanes
         return self
 

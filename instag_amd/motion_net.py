@@ -15,14 +15,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 CONCURRENT_AUDIO = True       # fork the audio branch onto a second stream (parallel hipGraph branch)
-_SIDE_STREAMS = {}
 
 
 def _side_stream(device, index=0):
-    key = (device.type, device.index, index)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+    from . import _lib
+    return _lib.side_stream(device, ("frame_branch", index))
 
 
 class LazyOutputs(dict):

@@ -70,9 +70,8 @@ class MultiTensorAdam:
             host[i] = float(g["lr"])
         self._lr_dev.copy_(host, non_blocking=True)
 
-    @torch.no_grad()
-    def step(self):
-        L = _lib.lib()
+    def _gather(self):
+        """[(param, grad or None, exp_avg, exp_avg_sq, group index)] of everything one launch steps."""
         tensors = []
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
@@ -88,46 +87,70 @@ class MultiTensorAdam:
                 if grad is not None and not grad.is_contiguous():
                     grad = grad.contiguous()
                 tensors.append((p, grad, st["exp_avg"], st["exp_avg_sq"], gi))
-        if not tensors:
-            return
+        return tensors
+
+    def _layout(self, tensors):
+        """(Re)build the device-side tables when the parameter / state set changed: chunk table, group table, pointer
+        table, learning rates, per-tensor step counters.  Allocations and host-to-device copies: never inside a stream
+        capture -- a caller that is about to capture step() calls prepare() first."""
+        L = _lib.lib()
         dev = tensors[0][0].device
         chunk = L.instag_adam_chunk_elems()
         key = tuple((t[0].data_ptr(), t[0].numel(), t[2].data_ptr()) for t in tensors)
-        relayout = self._dev != dev or key != self._layout_key
-        if relayout:
-            # static part: chunk table, group table, pinned staging buffers
-            chunks = [(ti, c) for ti, t in enumerate(tensors) for c in range((t[0].numel() + chunk - 1) // chunk)]
-            self._chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
-            garr = np.zeros(len(self.param_groups), dtype=_GROUP_DT)
-            for i, g in enumerate(self.param_groups):
-                garr[i] = (g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], int(bool(g["decoupled"])), 0)
-            self._groups_dev = torch.from_numpy(garr.view(np.uint8).copy()).to(dev)
-            self._tensors_host = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8).pin_memory()
-            self._tensors_dev = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8, device=dev)
-            self._lr_host = torch.zeros(len(self.param_groups), dtype=torch.float32).pin_memory()
-            self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
-            # per-tensor step counters follow their parameter's state across re-layouts (densify / prune)
-            steps = torch.zeros(len(tensors), dtype=torch.float32, device=dev)
-            for i, t in enumerate(tensors):
-                prev = self._state_of(t[0]).get("step")
-                if prev is not None:
-                    steps[i:i + 1].copy_(prev.reshape(1))
-            self._step = steps
-            self._tickets = torch.zeros(len(tensors), dtype=torch.int32, device=dev)   # adam.hip: TICKET
-            for i, t in enumerate(tensors):
-                self._state_of(t[0])["step"] = steps[i:i + 1]
-            self._dev, self._layout_key = dev, key
-            self.set_lrs()
-        self._keep = [t[1] for t in tensors]          # keep contiguous grad copies alive until the launch ran
+        if self._dev == dev and key == self._layout_key:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("MultiTensorAdam: the parameter set changed since the last step; call prepare() before "
+                               "capturing step() into a graph")
+        # static part: chunk table, group table, pinned staging buffers
+        chunks = [(ti, c) for ti, t in enumerate(tensors) for c in range((t[0].numel() + chunk - 1) // chunk)]
+        self._chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
+        garr = np.zeros(len(self.param_groups), dtype=_GROUP_DT)
+        for i, g in enumerate(self.param_groups):
+            garr[i] = (g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], int(bool(g["decoupled"])), 0)
+        self._groups_dev = torch.from_numpy(garr.view(np.uint8).copy()).to(dev)
+        self._tensors_host = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8).pin_memory()
+        self._tensors_dev = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8, device=dev)
+        self._lr_host = torch.zeros(len(self.param_groups), dtype=torch.float32).pin_memory()
+        self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
+        # per-tensor step counters follow their parameter's state across re-layouts (densify / prune)
+        steps = torch.zeros(len(tensors), dtype=torch.float32, device=dev)
+        for i, t in enumerate(tensors):
+            prev = self._state_of(t[0]).get("step")
+            if prev is not None:
+                steps[i:i + 1].copy_(prev.reshape(1))
+        self._step = steps
+        self._tickets = torch.zeros(len(tensors), dtype=torch.int32, device=dev)   # adam.hip: TICKET
+        for i, t in enumerate(tensors):
+            self._state_of(t[0])["step"] = steps[i:i + 1]
+        self._dev, self._layout_key = dev, key
+        self.set_lrs()
         if len(tensors) <= L.instag_adam_grads_max():
             # parameter / moment pointers sit in the device table (uploaded when the layout changes); the gradient
             # pointers, new every step, travel in the kernel arguments: nothing to copy in front of the launch
-            if relayout:
-                tarr = self._tensors_host.numpy().view(_TENSOR_DT)
-                for i, (p, grad, m, v, gi) in enumerate(tensors):
-                    tarr[i] = (p.data_ptr(), 0, m.data_ptr(), v.data_ptr(), p.numel(), gi, 0)
-                self._tensors_dev.copy_(self._tensors_host, non_blocking=True)
-                self._grads_host = np.zeros(len(tensors), dtype=np.uint64)
+            tarr = self._tensors_host.numpy().view(_TENSOR_DT)
+            for i, (p, grad, m, v, gi) in enumerate(tensors):
+                tarr[i] = (p.data_ptr(), 0, m.data_ptr(), v.data_ptr(), p.numel(), gi, 0)
+            self._tensors_dev.copy_(self._tensors_host, non_blocking=True)
+            self._grads_host = np.zeros(len(tensors), dtype=np.uint64)
+
+    @torch.no_grad()
+    def prepare(self):
+        """Bring the device-side tables up to date with the current parameter set WITHOUT stepping (after a densify /
+        prune, in front of a stream capture of step())."""
+        tensors = self._gather()
+        if tensors:
+            self._layout(tensors)
+
+    @torch.no_grad()
+    def step(self):
+        L = _lib.lib()
+        tensors = self._gather()
+        if not tensors:
+            return
+        self._layout(tensors)
+        self._keep = [t[1] for t in tensors]          # keep contiguous grad copies alive until the launch ran
+        if len(tensors) <= L.instag_adam_grads_max():
             gh = self._grads_host
             for i, t in enumerate(tensors):
                 gh[i] = 0 if t[1] is None else t[1].data_ptr()

@@ -17,29 +17,21 @@ from .motion_net import MotionNetwork as _MotionNetwork
 
 CONCURRENT_PASSES = True      # fork the attention raster pass(es) onto a second stream
 SHARED_ATTN_PASS = True       # attention map as an auxiliary colour set of the main raster pass
-# Fuse stage (training): the mouth pass on a second stream beside the face pass.  Measured 1.45 -> 1.26 ms per captured
-# step, but OFF: with it on, a process that runs the stage tests ends in a segmentation fault inside hipGraphLaunch of a
-# LATER, unrelated face-step graph (test_face_schedule_replays_one_graph_per_phase).  Narrowed, not solved: the fault
-# also comes when only the EAGER steps ran the passes concurrently; with the rule that a forked pass never forks further
-# (_lib.leaf_stream) the suite passes in its default order (137 tests) but a soak that repeats the stage file four times
-# still faults in the same test, and the same soak with the switch off passes (207 tests).  DESIGN.md section 5.
-CONCURRENT_FUSE_PASSES = False
-
-
-_SIDE_STREAMS = {}
+# Fuse stage (training): the mouth pass on a second stream beside the face pass (1.45 -> 1.26 ms per captured step in
+# round 2).  INSTAG_CONCURRENT_FUSE=0 / 1 overrides the default.
+import os as _os
+CONCURRENT_FUSE_PASSES = _os.environ.get("INSTAG_CONCURRENT_FUSE", "0") == "1"
 
 
 def _side_stream(device):
     """Second HIP stream per device: independent work (the attention raster pass) is forked onto it so that it
     overlaps the main pass -- both blend kernels are bound by their longest tile and leave most CUs idle.
-    ``device`` may be a (device, tag) pair: a separate stream per purpose."""
-    tag = None
+    ``device`` may be a (device, tag) pair: a separate stream per purpose (all from _lib.side_stream's registry)."""
+    from . import _lib
+    tag = "attn"
     if isinstance(device, tuple):
         device, tag = device
-    key = (device.type, device.index, tag)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+    return _lib.side_stream(device, ("renderer", tag))
 
 
 def _settings(cam, pc, bg_color, scaling_modifier, debug=False):

@@ -60,9 +60,10 @@ class Frame:
     def _named_tensors(self):
         return [(k, getattr(self, k)) for k in self.TENSORS] + [(k, self.talking_dict[k]) for k in self._dict_keys()]
 
-    def packed(self, device=None) -> "Frame":
+    def packed(self, device=None, pin: bool = False) -> "Frame":
         """Copy whose tensors are views into ONE byte buffer, so that feeding a frame to a captured step is a
-        single device copy instead of one per tensor."""
+        single device copy instead of one per tensor.  ``pin`` (host copies): page-locked memory, so that the upload
+        of the whole frame is one asynchronous copy (HostFrameFeeder)."""
         named = self._named_tensors()
         device = device if device is not None else named[0][1].device
         offs, total = [], 0
@@ -70,6 +71,8 @@ class Frame:
             offs.append(total)
             total += (t.numel() * t.element_size() + 255) // 256 * 256
         buf = torch.zeros(total, dtype=torch.uint8, device=device)
+        if pin and buf.device.type == "cpu":
+            buf = buf.pin_memory()
         views = {}
         for (k, t), o in zip(named, offs):
             nbytes = t.numel() * t.element_size()
@@ -98,6 +101,46 @@ class Frame:
             getattr(self, k).copy_(getattr(other, k), non_blocking=True)
         for k in self._dict_keys():
             self.talking_dict[k].copy_(other.talking_dict[k], non_blocking=True)
+
+
+class HostFrameFeeder:
+    """Frames that live in (pinned) HOST memory, uploaded one step ahead of the step that reads them.
+
+    The reference uploads a frame's tensors inside the iteration that uses them (train_face.py:324-327 masks and image,
+    gaussian_renderer/__init__.py:188-189 audio window and expression vector: a handful of blocking ``.cuda()`` copies,
+    ~4 MB at 512x512).  Here a frame is ONE packed byte buffer (Frame.packed): while step i runs, frame i+1 travels on a
+    copy stream into one of two device staging buffers; step i+1 waits for that copy's event (long since signalled),
+    and its first action -- the device-to-device copy into the captured step's static frame -- reads the staging
+    buffer.  The copy stream in turn waits until the step that last read the staging slot has finished with it."""
+
+    def __init__(self, example: Frame, device):
+        self.device = torch.device(device)
+        self.stage = [example.packed(self.device), example.packed(self.device)]
+        self.stream = _lib.side_stream(self.device, "frame_upload")
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        for e in self.consumed:
+            e.record(torch.cuda.current_stream(self.device))
+
+    @staticmethod
+    def to_host(frame: Frame) -> Frame:
+        return frame.packed("cpu", pin=True)
+
+    def prefetch(self, host_frame: Frame, slot: int):
+        """Start the upload of ``host_frame`` into staging slot ``slot`` on the copy stream."""
+        self.stream.wait_event(self.consumed[slot])
+        with torch.cuda.stream(self.stream):
+            self.stage[slot].copy_from(host_frame)
+            self.ready[slot].record(self.stream)
+
+    def take(self, slot: int) -> Frame:
+        """The staged frame, valid for work enqueued on the current stream from now on."""
+        torch.cuda.current_stream(self.device).wait_event(self.ready[slot])
+        return self.stage[slot]
+
+    def release(self, slot: int):
+        """Everything enqueued on the current stream so far is the last reader of staging slot ``slot``."""
+        self.consumed[slot].record(torch.cuda.current_stream(self.device))
 
 
 def make_frame(cam, frame_data) -> Frame:
@@ -143,7 +186,9 @@ def allreduce_gradients(params: List[torch.Tensor], extras: Optional[List[torch.
     world = dist.get_world_size()
     extras = extras or []
     params = with_grad(params)
-    g = flat_grad_bucket(params)
+    if not params and not extras:
+        return                      # nothing to exchange (same on every rank: the set depends on the phase only)
+    g = flat_grad_bucket(params) if params else torch.empty(0, dtype=extras[0].dtype, device=extras[0].device)
     n_g = g.numel()
     bucket = torch.cat([g] + [e.reshape(-1).to(g.dtype) for e in extras])
     dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
@@ -206,6 +251,9 @@ class FaceTrainer:
         self._graph = None
         self._graph_phase = None
         self._graph_cache = {}
+        self._graph_mode = None       # set by enable_graph: headroom / split / sticky capacity of the captured steps
+        self._pool = None             # one private memory pool for every capture of this trainer (re-captures reuse it)
+        self.recaptures = 0
 
     # ---- optimizers: learning rates are device scalars on the GPU so a captured step can be replayed -------
     def _setup_optimizers(self):
@@ -297,18 +345,24 @@ class FaceTrainer:
         from . import diff_gauss
         # fold_aux (only callers that run _stats_and_optimizers(pkg) next): the auxiliary image's share of the screen-space
         # gradient is added by the statistics kernel instead of by a launch of its own at the end of backward
-        diff_gauss.FOLD_AUX_M2D = bool(fold_aux and self.on_gpu)
-        with deferred_grads(self.device if self.on_gpu else None):
-            # the MLPs' weight gradients are batched into one launch at the end (deferred.py); the root gradient is
-            # a cached constant (no fill launch per step)
-            if self.on_gpu:
-                if getattr(self, "_one", None) is None:
-                    self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
-                loss.backward(gradient=self._one)
-            else:
-                loss.backward()
-        if diff_gauss.FOLD_AUX_M2D:
+        fold = bool(fold_aux and self.on_gpu)
+        diff_gauss.FOLD_AUX_M2D = fold
+        try:
+            with deferred_grads(self.device if self.on_gpu else None):
+                # the MLPs' weight gradients are batched into one launch at the end (deferred.py); the root gradient is
+                # a cached constant (no fill launch per step)
+                if self.on_gpu:
+                    if getattr(self, "_one", None) is None:
+                        self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+                    loss.backward(gradient=self._one)
+                else:
+                    loss.backward()
+        except BaseException:
+            diff_gauss.reset_aux_state()       # a failed backward must not withhold the NEXT step's aux share
+            raise
+        finally:
             diff_gauss.FOLD_AUX_M2D = False
+        if fold:
             pkg["_m2d_aux"] = diff_gauss.take_folded_aux(pkg["viewspace_points"])
         return pkg, loss, Ll1
 
@@ -393,17 +447,54 @@ class FaceTrainer:
             green = (rgb[:, 0] < 30 / 255) & (rgb[:, 1] > 225 / 255) & (rgb[:, 2] < 30 / 255)
             self.g.prune_points(green)
             self.g.prune_points(self.g.get_xyz[:, -1] < -0.07)
-        self._drop_graph()
+        self._drop_graph(keep_mode=True)          # (graph mode stays on: the next iteration captures its step again)
         return True
 
-    def _drop_graph(self):
-        """Forget every captured step (the parameter set changed, or the caller wants eager launches)."""
+    def _drop_graph(self, keep_mode: bool = False):
+        """Forget every captured step (the parameter set changed, or the caller wants eager launches).  ``keep_mode``:
+        graph mode stays on -- step() captures again when it next needs a step of some phase."""
         if self._graph is not None or getattr(self, "_graph_cache", None):
             from . import diff_gauss
             diff_gauss.set_capacity_plan(None)
         self._graph = None
         self._graph_phase = None
         self._graph_cache = {}
+        if not keep_mode:
+            self._graph_mode = None
+
+    def _prepare_optimizers(self):
+        """Device-side tables of the fused optimizers brought up to date with the parameter set (no step)."""
+        for o in ((self._combined,) if self._combined is not None else (self.motion_optimizer, self.g.optimizer)):
+            if hasattr(o, "prepare"):
+                o.prepare()
+
+    def _recapture(self, frame: Frame, phase: FacePhase, min_capacity: int = 0):
+        """Capture the step of ``phase`` again WITHOUT running a single train step: graph mode is on (enable_graph was
+        called once, its warm-up steps warmed every library and measured the instance counts) and only the parameter
+        set (densify / prune / opacity reset) or the needed capacity changed since.  The capacity follows the Gaussian
+        count; the training state and the iteration counter are untouched, so the decision to capture may be taken by
+        every rank of a data-parallel run independently of what the others replay."""
+        mode = self._graph_mode
+        n = max(1, self.g.num_points)
+        cap = max(int(mode["capacity"] * max(1.0, n / mode["capacity_n"])), int(min_capacity))
+        g = GraphedStep(self, frame, mode["headroom"], 0, mode["split"], phase, min_capacity=cap)
+        mode["capacity"], mode["capacity_n"] = g.capacity, n
+        self._graph_cache[phase] = g
+        self.recaptures = getattr(self, "recaptures", 0) + 1
+        return g
+
+    def _overflow_decision(self, graph) -> int:
+        """Every CHECK_EVERY replays: did any step since the last look need more instances than the captured capacity?
+        One synchronising read of the sticky device flags, made COLLECTIVE with several ranks (all-reduce MAX of flag
+        and peak), so that every rank takes the same decision in the same step and captures with the same capacity.
+        -> 0, or the peak need."""
+        over = graph.plan.overflowed()
+        peak = max([v for _, v in over], default=0)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([peak], dtype=torch.int64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            peak = int(t.item())
+        return peak
 
     def step(self, frame: Frame):
         self.iteration += 1
@@ -411,32 +502,39 @@ class FaceTrainer:
         self._set_learning_rates(it)
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         phase = self.phase_of(it)
-        cache = getattr(self, "_graph_cache", None) or {}
+        mode = getattr(self, "_graph_mode", None)
+        g = None
         if self._densify_due(it):
-            self._drop_graph()              # the parameter set is about to change: every captured step is stale
-        elif cache or self._graph is not None:
+            # the parameter set is about to change: every captured step is stale.  This iteration runs eagerly (density
+            # control sits between backward and the optimizers); the next one captures again
+            self._drop_graph(keep_mode=True)
+        elif mode is not None or self._graph_cache or self._graph is not None:
             # one captured step per phase (FacePhase): the schedule alternates between a few of them (the hair
-            # iterations toggle six times out of seven); a phase nobody captured runs eagerly
-            g = cache.get(phase)
-            if g is None and self._graph is not None and getattr(self, "_graph_phase", phase) == phase:
+            # iterations toggle six times out of seven)
+            g = self._graph_cache.get(phase)
+            if g is None and self._graph is not None and self._graph_phase == phase:
                 g = self._graph
+            if g is None and mode is not None and mode["auto"]:
+                g = self._recapture(frame, phase)
             if g is None and self._graph is not None:
                 from . import diff_gauss
-                diff_gauss.set_capacity_plan(None)
+                diff_gauss.set_capacity_plan(None)          # a phase nobody captured (auto off): eager launches
             self._graph, self._graph_phase = g, (phase if g is not None else None)
-        if self._graph is not None:
-            self._graph.replay(frame)
-            loss, Ll1 = self._graph.loss, self._graph.l1
-            if self._graph.overflow_due():
-                # some replayed step needed more instances than the captured capacity (its image was truncated to the
-                # nearest Gaussians, gradients of the dropped ones zero): capture again, sized from the peak need
-                peak = max(self._graph.plan.peak())
-                phases = list(self._graph_cache) or [self._graph_phase]
-                self._drop_graph()
-                for ph in phases:
-                    self.enable_graph(frame, phase=ph, min_capacity=int(1.4 * peak) + 4096)
-                self._graph = self._graph_cache.get(phase)
-                self._graph_phase = phase if self._graph is not None else None
+        if g is not None:
+            g.replay(frame)
+            loss, Ll1 = g.loss, g.l1
+            if g.check_due():
+                peak = self._overflow_decision(g)
+                if peak:
+                    # some replayed step needed more instances than the captured capacity (its image was truncated to
+                    # the nearest Gaussians, gradients of the dropped ones zero): capture again, sized from the peak
+                    # need -- lazily, phase by phase, without consuming iterations (_recapture)
+                    if mode is None:
+                        mode = self._graph_mode = dict(headroom=1.4, split=g.split, auto=True, capacity=g.capacity,
+                                                       capacity_n=max(1, self.g.num_points))
+                    mode["capacity"] = max(mode["capacity"], int(1.4 * peak) + 4096)
+                    mode["auto"] = True
+                    self._drop_graph(keep_mode=True)
         else:
             from . import diff_gauss
             if diff_gauss._CAPACITY_PLAN is not None:
@@ -448,49 +546,80 @@ class FaceTrainer:
         return self.last
 
     # ---- state snapshot (benchmark windows start from the same state; in place, so captured graphs stay valid) ----
-    def _state_tensors(self):
-        ts = [p.data for p in self._all_params()]
+    def _optimizer_states(self):
+        """[(optimizer state dict of one parameter)] in a fixed order (motion optimizer first, groups, parameters)."""
+        out = []
         for opt_ in (self.motion_optimizer, self.g.optimizer):
             for grp in opt_.param_groups:
                 for p in grp["params"]:
-                    st = opt_.state.get(p) if hasattr(opt_.state, "get") else None
-                    if st:
-                        ts += [st[k] for k in ("exp_avg", "exp_avg_sq", "step") if torch.is_tensor(st.get(k))]
+                    out.append(opt_.state.get(p) if hasattr(opt_.state, "get") else None)
+        return out
+
+    def _state_tensors(self):
+        ts = [p.data for p in self._all_params()]
+        for st in self._optimizer_states():
+            if st:
+                ts += [st[k] for k in ("exp_avg", "exp_avg_sq", "step") if torch.is_tensor(st.get(k))]
         ts += [self.g.xyz_gradient_accum, self.g.denom, self.g.max_radii2D]
         return ts
 
     @torch.no_grad()
     def snapshot(self):
-        return dict(iteration=self.iteration, tensors=[t.detach().clone() for t in self._state_tensors()])
+        opt = [None if not st else {k: st[k].detach().clone() for k in ("exp_avg", "exp_avg_sq", "step")
+                                     if torch.is_tensor(st.get(k))} for st in self._optimizer_states()]
+        return dict(iteration=self.iteration, params=[p.data.detach().clone() for p in self._all_params()], opt=opt,
+                    stats=[t.detach().clone() for t in (self.g.xyz_gradient_accum, self.g.denom, self.g.max_radii2D)])
 
     @torch.no_grad()
     def restore(self, snap):
-        """Copy a snapshot() back IN PLACE (same parameter set required: no densification in between)."""
-        live = self._state_tensors()
-        assert len(live) == len(snap["tensors"]), "the parameter / optimizer-state set changed since the snapshot"
-        for dst, src in zip(live, snap["tensors"]):
+        """Copy a snapshot() back IN PLACE (same parameter set required: no densification in between), so captured
+        graphs stay valid.  Optimizer state that did not exist yet at the snapshot (no step had run) goes back to
+        zero moments and a zero step count, which is what a first step starts from."""
+        params = self._all_params()
+        assert len(params) == len(snap["params"]), "the parameter set changed since the snapshot"
+        for p, src in zip(params, snap["params"]):
+            assert p.shape == src.shape, "the parameter set changed since the snapshot"
+            p.data.copy_(src)
+        for st, saved in zip(self._optimizer_states(), snap["opt"]):
+            if not st:
+                continue
+            for k in ("exp_avg", "exp_avg_sq", "step"):
+                if torch.is_tensor(st.get(k)):
+                    if saved and k in saved:
+                        st[k].copy_(saved[k])
+                    else:
+                        st[k].zero_()
+        for dst, src in zip((self.g.xyz_gradient_accum, self.g.denom, self.g.max_radii2D), snap["stats"]):
             dst.copy_(src)
         self.iteration = snap["iteration"]
 
     # ---- graph mode --------------------------------------------------------------------------------------------
     def enable_graph(self, example_frame: Frame, headroom: float = 1.4, warmup_steps: int = 3,
                      split_for_allreduce: Optional[bool] = None, phase: Optional[FacePhase] = None,
-                     min_capacity: int = 0):
-        """Capture the whole step into a hipGraph.  Runs `warmup_steps` eager steps plus two capacity-mode steps
-        first (they advance the iteration counter like any other step) to measure the instance counts and warm
-        every library.  The graph holds the launches of one phase (FacePhase): `phase`, or the phase of the iteration
-        right after the capture.  Captured steps are kept per phase, so a schedule that alternates between phases
-        replays whichever was captured; step() launches eagerly in a phase nobody captured, and every captured step
-        is dropped when the parameter set changes (densify / prune / opacity reset)."""
+                     min_capacity: int = 0, auto_recapture: bool = True, keep_state: bool = False):
+        """Capture the whole step into a hipGraph and switch graph mode on.  Runs `warmup_steps` eager steps plus two
+        capacity-mode steps first to measure the instance counts and warm every library: real train steps that advance
+        the iteration counter -- unless ``keep_state``, which restores parameters, optimizer state, statistics and the
+        counter afterwards.  The graph holds the launches of one phase (FacePhase): `phase`, or the phase of the
+        iteration right after the capture.  Captured steps are kept per phase; every one of them is dropped when the
+        parameter set changes (densify / prune / opacity reset) or a replay overflowed the instance capacity.  With
+        ``auto_recapture`` step() then captures the step it needs again by itself, without warm-up steps and without
+        touching the training state (_recapture); without it such a step launches eagerly."""
         if not hasattr(self, "_graph_cache"):
             self._graph_cache = {}
         self._graph = None
         if phase is None:
-            phase = self.phase_of(self.iteration + max(1, warmup_steps) + 3)   # the iteration right after capture
-        self._graph = GraphedStep(self, example_frame, headroom, warmup_steps, split_for_allreduce, phase,
-                                  min_capacity=min_capacity)
+            after = self.iteration + (0 if keep_state else max(1, warmup_steps) + 2) + 1
+            phase = self.phase_of(after)                                       # the iteration right after capture
+        snap = self.snapshot() if keep_state else None
+        self._graph = GraphedStep(self, example_frame, headroom, max(1, warmup_steps), split_for_allreduce, phase,
+                                  min_capacity=min_capacity, restore=snap)
         self._graph_phase = phase
         self._graph_cache[phase] = self._graph
+        prev = getattr(self, "_graph_mode", None)
+        self._graph_mode = dict(headroom=headroom, split=self._graph.split, auto=bool(auto_recapture),
+                                capacity=max(self._graph.capacity, prev["capacity"] if prev else 0),
+                                capacity_n=max(1, self.g.num_points))
         return self._graph
 
 
@@ -499,12 +628,18 @@ class _no_gc:
     fault in capture_end) is addressed at its cause in instag_amd/_keepalive.py: tensors that cross streams are no
     longer marked with record_stream inside a capture, the capture's owner keeps them alive until it has ended.  The
     collector stays off during the window all the same: a collection there frees an earlier step's blocks into the
-    capture's private pool at an arbitrary point of the captured sequence, which makes captures irreproducible."""
+    capture's private pool at an arbitrary point of the captured sequence, which makes captures irreproducible.
+    ``collect=False`` (re-captures inside a train loop): no full collection in front either -- it costs tens of
+    milliseconds, as much as ten train steps."""
+
+    def __init__(self, collect: bool = True):
+        self.collect = collect
 
     def __enter__(self):
         import gc
         self.was = gc.isenabled()
-        gc.collect()
+        if self.collect:
+            gc.collect()
         gc.disable()
 
     def __exit__(self, *exc):
@@ -518,7 +653,11 @@ class GraphedStep:
     CHECK_EVERY = 64         # replays between two looks at the (sticky, device-side) overflow flags
 
     def __init__(self, trainer: FaceTrainer, example: Frame, headroom: float, warmup_steps: int,
-                 split_for_allreduce: Optional[bool] = None, phase: FacePhase = C3_PHASE, min_capacity: int = 0):
+                 split_for_allreduce: Optional[bool] = None, phase: FacePhase = C3_PHASE, min_capacity: int = 0,
+                 restore=None):
+        """``warmup_steps`` > 0: the cold path (eager steps measure the instance count and warm every library; with
+        ``restore`` = a trainer.snapshot() the training state is put back afterwards).  0: the warm path of
+        FaceTrainer._recapture -- nothing runs, ``min_capacity`` is the capacity."""
         from . import diff_gauss
         self.phase = phase
         t = self.trainer = trainer
@@ -528,42 +667,55 @@ class GraphedStep:
         # two graphs with the (eager) gradient all-reduce between them; can be forced for single-rank tests
         self.split = self.distributed if split_for_allreduce is None else bool(split_for_allreduce)
         self.static = example.clone_static()
-        # 1. eager warm-up in the normal (host round trip) mode: measures R of both raster passes
-        diff_gauss.set_capacity_plan(None)
-        needed = 0
-        for _ in range(max(1, warmup_steps)):
-            t.iteration += 1
-            t._set_learning_rates(t.iteration)
-            # (only the package is kept, and only for the statistics: a live loss tensor would keep this step's autograd
-            # graph -- and with it every parameter's gradient accumulator, bound to THIS stream -- alive into the capture,
-            # whose backward would then hop to this stream for every AccumulateGrad)
-            pkg = t._forward_backward(self.static, phase, fold_aux=True)[0]
-            t._stats_and_optimizers(pkg, self.distributed)
-            t._zero_grad()
-            del pkg        # a live autograd graph keeps grad accumulators bound to this (non-capture) stream
-            needed = max(needed, diff_gauss.LAST_STATS["num_rendered"])
-        cap = max(int(needed * headroom) + 4096, int(min_capacity))
-        self.plan = diff_gauss.CapacityPlan([cap, cap], dev)
-        self._replays = 0
-        diff_gauss.set_capacity_plan(self.plan)
-        # 2. one eager step in capacity mode on a side stream (allocator / library warm-up for capture)
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            for _ in range(2):
+        cold = warmup_steps > 0
+        if cold:
+            # 1. eager warm-up in the normal (host round trip) mode: measures R of both raster passes
+            diff_gauss.set_capacity_plan(None)
+            needed = 0
+            for _ in range(warmup_steps):
                 t.iteration += 1
                 t._set_learning_rates(t.iteration)
-                self.plan.begin_step()
+                # (only the package is kept, and only for the statistics: a live loss tensor would keep this step's
+                # autograd graph -- and with it every parameter's gradient accumulator, bound to THIS stream -- alive
+                # into the capture, whose backward would then hop to this stream for every AccumulateGrad)
                 pkg = t._forward_backward(self.static, phase, fold_aux=True)[0]
                 t._stats_and_optimizers(pkg, self.distributed)
                 t._zero_grad()
                 del pkg
-        torch.cuda.current_stream(dev).wait_stream(s)
-        torch.cuda.synchronize(dev)
+                needed = max(needed, diff_gauss.LAST_STATS["num_rendered"])
+            cap = max(int(needed * headroom) + 4096, int(min_capacity))
+        else:
+            assert min_capacity > 0, "a warm capture needs the capacity of an earlier one"
+            cap = int(min_capacity)
+            t._prepare_optimizers()          # tables of the new parameter set: allocations / uploads outside the capture
+        self.plan = diff_gauss.CapacityPlan([cap, cap], dev)
+        self._replays = 0
+        diff_gauss.set_capacity_plan(self.plan)
+        if cold:
+            # 2. two eager steps in capacity mode on a side stream (allocator / library warm-up for capture)
+            s = _lib.warmup_stream(dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(2):
+                    t.iteration += 1
+                    t._set_learning_rates(t.iteration)
+                    self.plan.begin_step()
+                    pkg = t._forward_backward(self.static, phase, fold_aux=True)[0]
+                    t._stats_and_optimizers(pkg, self.distributed)
+                    t._zero_grad()
+                    del pkg
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            if restore is not None:
+                t.restore(restore)
+                t._set_learning_rates(max(1, t.iteration))
         # 3. capture.  With several ranks the gradient exchange stays outside the graphs:
         #    graph A = forward + backward (+ bucket fill), eager all-reduce, graph B = statistics + optimizers.
         # other threads (the collective library's watchdog) may touch the HIP runtime while this thread captures
         mode = {"capture_error_mode": "thread_local"} if self.distributed else {}
+        if t._pool is None:
+            t._pool = torch.cuda.graph_pool_handle()
+        mode["pool"] = t._pool
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         dot = os.environ.get("INSTAG_GRAPH_DOT")       # diagnostics: the captured step's nodes and edges (DOT)
@@ -571,7 +723,7 @@ class GraphedStep:
             self.graph_a.enable_debug_mode()
         self.plan.begin_step()
         if not self.split:
-            with _no_gc(), _lib.graph_capture(self.graph_a, **mode):
+            with _no_gc(cold), _lib.graph_capture(self.graph_a, **mode):
                 pkg, loss, l1 = t._forward_backward(self.static, phase, fold_aux=True)
                 t._stats_and_optimizers(pkg, False)
                 t._zero_grad()
@@ -579,14 +731,14 @@ class GraphedStep:
             # window intermittently crash hipStreamEndCapture)
             del pkg
         else:
-            with _no_gc(), _lib.graph_capture(self.graph_a, **mode):
+            with _no_gc(cold), _lib.graph_capture(self.graph_a, **mode):
                 pkg, loss, l1 = t._forward_backward(self.static, phase)
                 self._vs_grad, self._radii = pkg["viewspace_points"].grad, pkg["radii"]
                 self._params = with_grad(t._all_params())
                 self._bucket = flat_grad_bucket(self._params)
             del pkg
             self.graph_b = torch.cuda.CUDAGraph()
-            with _no_gc(), _lib.graph_capture(self.graph_b, **mode):
+            with _no_gc(False), _lib.graph_capture(self.graph_b, **mode):
                 with torch.no_grad():
                     if self.distributed:
                         # mean over ranks of the summed gradients
@@ -595,11 +747,13 @@ class GraphedStep:
                     t._update_stats(self._vs_grad, self._radii)        # local; exchanged when a densification reads them
                     t._step_optimizers()
                     t._zero_grad()
-        from . import _keepalive
-        _keepalive.release()               # the captures have ended: cross-stream tensors held for them may go
         if dot:
             self.graph_a.debug_dump(dot)
-        self.loss, self.l1 = loss, l1
+        # detached: a retained loss would keep the captured step's autograd graph alive, and with it every parameter's
+        # AccumulateGrad node, bound to the capture stream -- the next backward on any other stream (an eager step, the
+        # instrumented pass of bench.py) then hops to the capture stream for every parameter
+        self.loss, self.l1 = loss.detach(), l1.detach()
+        del loss, l1
         self.capacity = cap
 
     def replay(self, frame: Frame):
@@ -616,15 +770,17 @@ class GraphedStep:
         sticky: every step since the capture / the last clear counts)."""
         return self.plan.overflowed()
 
-    def overflow_due(self):
-        """True every CHECK_EVERY replays if a replayed step overflowed (one synchronising read per CHECK_EVERY steps)."""
+    def check_due(self) -> bool:
+        """True every CHECK_EVERY replays: the caller then reads the sticky overflow flags (FaceTrainer._overflow_decision:
+        one synchronising read per CHECK_EVERY steps -- a function of the replay count alone, hence the same step on every
+        rank)."""
         if self._replays < self.CHECK_EVERY:
             return False
         self._replays = 0
-        return bool(self.plan.poll_overflow())        # asynchronous: the answer of the previous poll, no device wait
+        return True
 
 
-def build_trainer(n_gaussians, device, sh_degree=1, seed=0, densify=False, encoder_cls=None, raw=None):
+def build_trainer(n_gaussians, device, sh_degree=1, seed=0, densify=False, encoder_cls=None, raw=None, schedule=None):
     """Synthetic config-C3 trainer: N Gaussians + PMF + UMF with random-init weights."""
     from .motion_net import MotionNetwork, PersonalizedMotionNetwork
     from .scene_synth import synthetic_gaussians
@@ -635,4 +791,4 @@ def build_trainer(n_gaussians, device, sh_degree=1, seed=0, densify=False, encod
     g = GaussianModel(sh_degree, neural_motion_grid=pmf)
     g.load_raw(raw if raw is not None else synthetic_gaussians(n_gaussians, sh_degree=sh_degree, seed=seed), device)
     bg = torch.tensor([0.0, 1.0, 0.0], device=device)
-    return FaceTrainer(g, umf, bg, densify=densify, seed=seed)
+    return FaceTrainer(g, umf, bg, densify=densify, seed=seed, schedule=schedule)

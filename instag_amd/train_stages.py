@@ -124,7 +124,7 @@ class GraphedStage:
         self.capacities = [int(r * headroom) + 4096 for r in counts]
         self.plan = diff_gauss.CapacityPlan(self.capacities, device)
         diff_gauss.set_capacity_plan(self.plan)
-        side = torch.cuda.Stream(device=device)        # allocator / library warm-up in capacity mode
+        side = _lib.warmup_stream(device)              # allocator / library warm-up in capacity mode
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             for _ in range(2):
@@ -148,10 +148,10 @@ class GraphedStage:
                 raise
         # body returns (..., keepalive): the render package stays referenced until the capture has ended (ROCm 7.2:
         # releasing it inside the capture window intermittently crashes hipStreamEndCapture), then it is dropped
-        self.out = tuple(out[:-1])
+        # (detached: a retained loss would keep the step's autograd graph -- and every parameter's AccumulateGrad node,
+        # bound to the capture stream -- alive into the next backward on another stream)
+        self.out = tuple(o.detach() if torch.is_tensor(o) else o for o in out[:-1])
         del out
-        from . import _keepalive
-        _keepalive.release()               # the capture has ended: cross-stream tensors held for it may go
 
     CHECK_EVERY = 64         # replays between two looks at the (sticky, device-side) overflow flags
 

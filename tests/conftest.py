@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a gradient accumulator bound to another stream than the node feeding it means an autograd graph outlived its step
+    # (a retained loss, a per-capture stream): inside a stream capture that is an un-announced fork.  Never tolerated.
+    config.addinivalue_line("filterwarnings", "error:The AccumulateGrad node's stream does not match")
 
 
 @pytest.fixture(scope="session")

@@ -46,6 +46,42 @@ def main():
         results[mode] = vec
     diff = float((results["eager"] - results["graph"]).abs().max())
     assert diff <= 1e-5, f"graph-split DP step differs from the eager DP step by {diff}"
+
+    # Only ONE rank overflows its instance capacity: the decision to capture again is collective (all-reduce MAX of the
+    # sticky flags at a replay count every rank reaches in the same step), the capture consumes no iteration and runs no
+    # collective, so the ranks keep stepping in lock step and the replicas stay identical.
+    from instag_amd.train import GraphedStep
+    GraphedStep.CHECK_EVERY = 3
+    tr = build_trainer(3000, dev, seed=2)
+    try:
+        tr.enable_graph(frames[0], warmup_steps=1)
+        phase = tr._graph.phase
+        need = max(tr._graph.plan.needed())
+        assert need > 2048, need
+        # rank 1 captures again with a capacity far below what its frames need
+        tr._drop_graph(keep_mode=True)
+        if rank == 1:
+            tr._graph_mode["capacity"] = 1024
+        tr._recapture(frames[0], phase)
+        caps = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(caps, torch.tensor([tr._graph_cache[phase].capacity]))
+        assert int(caps[1]) == 1024 < need <= int(caps[0]), caps
+        base = tr.recaptures
+        it0 = tr.iteration
+        for i in range(8):
+            tr.step(frames[i % 3])
+        assert tr.iteration == it0 + 8
+        assert tr.recaptures > base, "the overflow of rank 1 must make EVERY rank capture again"
+        assert tr._graph is not None and tr._graph.capacity >= need and not tr._graph.check_overflow()
+        its = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(its, torch.tensor([tr.iteration, tr.recaptures]))
+        assert torch.equal(its[0], its[1]), its
+    finally:
+        diff_gauss.set_capacity_plan(None)
+    vec = torch.cat([tr.g.get_xyz.detach().reshape(-1), next(tr.motion_net.sigma_net.parameters()).detach().reshape(-1)]).cpu()
+    gathered = [torch.zeros_like(vec) for _ in range(world)]
+    dist.all_gather(gathered, vec)
+    assert torch.equal(gathered[0], gathered[1]), "replicas diverged across the one-sided overflow"
     dist.barrier()
     if rank == 0:
         print("DP-OK", diff)

@@ -106,6 +106,37 @@ def test_dp_fused_bucket_allreduce_gloo_world2():
     assert torch.allclose(r0["stat"], torch.full((50, 1), 3.0)) and torch.allclose(r0["cnt"], torch.full((50, 1), 2.0))
 
 
+def _overflow_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from instag_amd.train import FaceTrainer, allreduce_gradients
+        tr = FaceTrainer.__new__(FaceTrainer)
+        tr.device = torch.device("cpu")
+        # only rank 0 saw an overflow (slot 0, peak need 5000 instances)
+        graph = SimpleNamespace(plan=SimpleNamespace(overflowed=lambda: [(0, 5000)] if rank == 0 else []))
+        peak = tr._overflow_decision(graph)
+        quiet = tr._overflow_decision(SimpleNamespace(plan=SimpleNamespace(overflowed=lambda: [])))
+        allreduce_gradients([torch.nn.Parameter(torch.zeros(3))])        # no gradient anywhere: returns, no collective
+        results[rank] = (peak, quiet)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp_overflow_decision_is_collective_gloo_world2():
+    """The decision to capture a step again after an instance-capacity overflow is the same on every rank even when
+    only one rank overflowed (all-reduce MAX of the sticky flag / peak): ranks that disagreed would run different
+    numbers of collectives (instag_amd/train.py step())."""
+    world = 2
+    mgr = mp.Manager()
+    results = mgr.dict()
+    port = 29500 + (os.getpid() + 13) % 2000
+    mp.spawn(_overflow_worker, args=(world, port, results), nprocs=world, join=True)
+    assert results[0] == results[1] == (5000, 0)
+
+
 def test_grad_bucket_roundtrip():
     from instag_amd.train import flat_grad_bucket, scatter_grad_bucket, with_grad
     ps = [torch.nn.Parameter(torch.randn(5, 2)), torch.nn.Parameter(torch.randn(3)), torch.nn.Parameter(torch.randn(4))]

@@ -526,6 +526,39 @@ def test_split_sh_storage_matches_concatenated(deg):
         assert g_s[k] is not None and torch.equal(g_s[k], g_c[k]), k
 
 
+def test_stalled_look_back_is_reported_not_silent():
+    """A binning look-back whose predecessor never publishes gives up after a bounded spin -- and says so: the sticky
+    device counter makes the next synchronising rasterizer call raise (and CapacityPlan.overflowed() in capacity
+    mode), instead of a silently mis-sorted tile list (csrc/raster_sort.hip g_sort_stalls)."""
+    from instag_amd import _lib, diff_gauss
+    from instag_amd.diff_gauss import GaussianRasterizer
+    L = _lib.lib()
+    dev = "cuda"
+    assert diff_gauss.sort_stalls(clear=True) == 0
+    a, settings = make_scene(500, 64)
+    inp = {k: v.to(dev) for k, v in a.items()}
+
+    def render():
+        m2 = torch.zeros(500, 3, device=dev)
+        return GaussianRasterizer(hip_settings(settings, dev))(
+            means3D=inp["means3D"], means2D=m2, shs=inp["shs"], opacities=inp["opacities"], scales=inp["scales"],
+            rotations=inp["rotations"], extra_attrs=inp["extra"])
+    render()                                                     # healthy: no stall
+    assert diff_gauss.sort_stalls() == 0
+    try:
+        _lib.check(L.instag_debug_scan_stall_probe(_lib.current_stream()), "probe")   # block 1 waits for a block 0 that never runs
+        assert diff_gauss.sort_stalls() == 1
+        with pytest.raises(RuntimeError, match="look-back gave up"):
+            render()
+        plan = diff_gauss.CapacityPlan([4096], torch.device(dev))
+        with pytest.raises(RuntimeError, match="gave up"):
+            plan.overflowed()
+    finally:
+        assert diff_gauss.sort_stalls(clear=True) >= 1
+    assert diff_gauss.sort_stalls() == 0
+    render()
+
+
 def test_dp_two_ranks_share_one_gpu():
     """Data-parallel train step with two ranks on this one card (gloo): replicas stay bit-identical, and the
     two-graph form used with several ranks agrees with the eager form (tests/dp_worker.py)."""

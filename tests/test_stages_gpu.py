@@ -99,7 +99,8 @@ def test_face_phase_step_matches_torch_loss_statement(it):
 def test_reference_schedule_density_control_order():
     """schedule="reference": statistics -> densify / prune / opacity reset -> optimizers (train_face.py:667-788).  In
     a density-control iteration the rebuilt Gaussians take no Adam step (they carry no gradient), the motion field
-    does; a captured graph is dropped when the parameter set changes."""
+    does; every captured graph is dropped when the parameter set changes and -- graph mode staying on -- the next
+    iteration captures its step again by itself, without consuming iterations."""
     from instag_amd import diff_gauss
     from instag_amd.gaussian_model import GaussianModel
     from instag_amd.motion_net import MotionNetwork, PersonalizedMotionNetwork
@@ -127,20 +128,67 @@ def test_reference_schedule_density_control_order():
             out = tr.step(frames[i % 3])
             assert tr.iteration == i
             assert torch.isfinite(out["loss"]), i
-            if i == 8:
-                assert tr._graph is not None and not tr._graph.check_overflow()      # replayed
             counts.append(tr.g.num_points)
             assert not torch.equal(w_before, next(tr.motion_net.sigma_net.parameters()).detach()), i
             if due:
                 assert tr._graph is None, "the graph must be dropped when the parameter set is rebuilt"
                 st = tr.g.optimizer.state[tr.g._p["xyz"]]
                 assert st["exp_avg"].shape == tr.g._p["xyz"].shape
+            elif i >= 8:
+                # replayed: iteration 8 from the graph enable_graph captured, 10 / 11 from graphs step() captured itself
+                # for the rebuilt parameter set (and the phase of that iteration)
+                assert tr._graph is not None and tr._graph.phase == out["phase"] and not tr._graph.check_overflow(), i
+                assert tr._graph.static.original_image.shape[-1] == 96
             assert tr.g.xyz_gradient_accum.shape[0] == tr.g.num_points == tr.g.max_radii2D.shape[0]
         assert len(set(counts)) > 1, counts          # densify / prune changed N at least once
-        # iteration 9 is a density-control iteration (9 % 3 == 0): run eagerly, the graph dropped
+        assert tr.recaptures >= 2
+        # iteration 12 is a density-control iteration (12 % 3 == 0): run eagerly, every graph dropped
         assert tr._graph is None
     finally:
         diff_gauss.set_capacity_plan(None)
+
+
+def test_density_control_graph_mode_matches_eager():
+    """A run that crosses density-control events in graph mode (captured steps dropped at every event and captured
+    again by step() itself, no iteration consumed, training state untouched by the captures) == the same run launched
+    eagerly: same Gaussian counts after every event, same losses, same parameters."""
+    from instag_amd import diff_gauss
+    from instag_amd.gaussian_model import GaussianModel
+    from instag_amd.motion_net import MotionNetwork, PersonalizedMotionNetwork
+    from instag_amd.scene_synth import synthetic_gaussians
+    from instag_amd.train import FaceTrainer
+    dev = torch.device("cuda")
+    frames = _frames(96, 3, dev, priors=True)
+    Opt = type("Opt", (SmallOpt,), {"iterations": 40, "densify_until_iter": 30, "opacity_reset_interval": 12})
+    runs = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)
+        args = SimpleNamespace(audio_extractor="deepspeech", type="face")
+        g = GaussianModel(1, neural_motion_grid=PersonalizedMotionNetwork(args=args).to(dev))
+        g.load_raw(synthetic_gaussians(3000, sh_degree=1, seed=3), dev)
+        tr = FaceTrainer(g, MotionNetwork(args=args).to(dev), torch.tensor([0.0, 1.0, 0.0], device=dev), opt=Opt,
+                         densify=True, seed=0, schedule="reference")
+        try:
+            if mode == "graph":
+                tr.enable_graph(frames[0], warmup_steps=1, keep_state=True)      # no iteration consumed
+                assert tr.iteration == 0
+            losses, counts = [], []
+            for i in range(1, 23):
+                out = tr.step(frames[i % 3])
+                assert tr.iteration == i
+                losses.append(float(out["loss"]))
+                counts.append(tr.g.num_points)
+            if mode == "graph":
+                assert tr.recaptures >= 5, tr.recaptures
+        finally:
+            diff_gauss.set_capacity_plan(None)
+        runs[mode] = (losses, counts, tr.g.get_xyz.detach().clone(),
+                      next(tr.motion_net.sigma_net.parameters()).detach().clone())
+    (le, ce, xe, we), (lg, cg, xg, wg) = runs["eager"], runs["graph"]
+    assert ce == cg, (ce, cg)
+    for a_, b_ in zip(le, lg):
+        assert abs(a_ - b_) <= 1e-4 * max(1.0, abs(a_)), (le, lg)
+    assert float((xe - xg).abs().max()) <= 1e-5 and float((we - wg).abs().max()) <= 1e-4
 
 
 def _mouth_setup(dev, n_face=1500, n_mouth=900, seed=4):
@@ -405,6 +453,96 @@ def _plain_render_motion(frame, pc, motion_net, bg, personalized, align):
                     scales=scales.detach(), rotations=rots.detach(), extra_attrs=ones)[0]
     return dict(render=img, depth=depth, normal=normal, alpha=alpha, radii=radii, motion=m, attn=attn_of(m),
                 p_attn=attn_of(p) if personalized else None, viewspace_points=m2, p_motion=p)
+
+
+def _plain_fuse_inference(frame, pc, net, pcm, netm, bg, personalized, scene_bg, k=10):
+    """synthesize_fuse.py:46-74 with plain torch ops and separate rasterizer calls: render_motion(align=True) ->
+    render_motion_mouth_con(align=True, inference=True) -> composite.  At inference the mouth branch reads
+    ``motion_net_face.cache`` (gaussian_renderer/__init__.py:362-363), which in the reference is the very dictionary
+    render_motion has just updated in place (d_xyz += p.d_xyz; d_xyz *= p_scale, :207-217): here ``face["motion"]``."""
+    import math
+    from instag_amd.diff_gauss import GaussianRasterizationSettings, GaussianRasterizer
+    with torch.no_grad():
+        face = _plain_render_motion(frame, pc, net, bg, personalized, True)
+        cache = face["motion"]
+        s = GaussianRasterizationSettings(
+            image_height=frame.image_height, image_width=frame.image_width, tanfovx=math.tan(frame.FoVx * 0.5),
+            tanfovy=math.tan(frame.FoVy * 0.5), bg=bg, scale_modifier=1.0, viewmatrix=frame.world_view_transform,
+            projmatrix=frame.full_proj_transform, sh_degree=pcm.active_sh_degree, campos=frame.camera_center,
+            prefiltered=False, debug=False)
+        aud = frame.talking_dict["auds"]
+        p = pcm.neural_motion_grid(pcm.get_xyz, aud)                                   # :349-350
+        xyz = pcm.get_xyz + p["p_xyz"]                                                 # :352-353
+        dy = cache["d_xyz"][..., 1]                                                    # :362-363, 366
+        motion_max = dy.topk(k, 0, True, True)[0]
+        motion_min = dy.topk(k, 0, False, True)[0]
+        move = torch.stack([motion_max[-1], motion_min[-1], motion_max[-1] - motion_min[-1]]).reshape(1, 3) * 1e2
+        m = dict(netm(xyz, aud, move).items())
+        d_xyz = m["d_xyz"]
+        if personalized:
+            d_xyz += p["d_xyz"]                                                        # :385-390
+        opacity = pcm.get_opacity
+        mr, _, _, ma, _, _ = GaussianRasterizer(s)(
+            means3D=pcm.get_xyz + d_xyz, means2D=torch.zeros_like(pcm.get_xyz), shs=pcm.get_features, opacities=opacity,
+            scales=pcm.get_scaling, rotations=pcm.rotation_activation(pcm._rotation), extra_attrs=torch.ones_like(opacity))
+        mouth_image = mr + scene_bg * (1.0 - ma)                                       # synthesize_fuse.py:66
+        image = face["render"] + mouth_image * (1.0 - face["alpha"])                   # :70
+        return image.clamp(0, 1)                                                       # :72
+
+
+@pytest.mark.parametrize("personalized", [False, True], ids=["align", "personalized+align"])
+def test_fuse_inference_matches_plain_torch(personalized):
+    """SURVEY 8(f)4 value test: FuseRenderer (eager, one hipGraph per frame, three frames per replay on three lanes) ==
+    the reference's inference loop transcribed with plain torch ops (synthesize_fuse.py:46-74), including the mouth
+    branch reading the face field's cache (gaussian_renderer/__init__.py:362-372)."""
+    from instag_amd import diff_gauss
+    from instag_amd.gaussian_model import GaussianModel
+    from instag_amd.infer import FuseRenderer
+    from instag_amd.motion_net import MotionNetwork, MouthMotionNetwork, PersonalizedMotionNetwork
+    dev = torch.device("cuda")
+    torch.manual_seed(21)
+    face_args = SimpleNamespace(audio_extractor="deepspeech", type="face")
+    mouth_args = SimpleNamespace(audio_extractor="deepspeech", type="mouth")
+    pc = GaussianModel(1, PersonalizedMotionNetwork(args=face_args).to(dev)).create_random(3000, dev, seed=1)
+    pcm = GaussianModel(1, PersonalizedMotionNetwork(args=mouth_args).to(dev)).create_random(800, dev, seed=2)
+    net, netm = MotionNetwork(args=face_args).to(dev), MouthMotionNetwork(args=mouth_args).to(dev)
+    with torch.no_grad():
+        # random-init fields move nothing visible: scale the output layers up so the jaw feature, both displacements and
+        # the alignment actually shape the images
+        for mod in (net.sigma_net, netm.sigma_net, pc.neural_motion_grid.sigma_net, pc.neural_motion_grid.align_net,
+                    pcm.neural_motion_grid.sigma_net, pcm.neural_motion_grid.align_net):
+            mod.net[-1].weight.mul_(30.0)
+    frames = _frames(96, 3, dev)
+    bg = torch.zeros(3, device=dev)
+    scene_bgs = [torch.rand(3, 96, 96, device=dev) for _ in frames]
+    want = [_plain_fuse_inference(f, pc, net, pcm, netm, bg, personalized, sb) for f, sb in zip(frames, scene_bgs)]
+    assert float((want[0] - want[1]).abs().max()) > 1e-2                      # the frames differ
+    static = _plain_fuse_inference(frames[0], pc, net, pcm, netm, bg, personalized, scene_bgs[1])
+    assert float((static - want[0]).abs().max()) > 1e-3                       # the background shows through
+    r = FuseRenderer(pc, net, pcm, netm, bg, personalized=personalized)
+    worst = 0.0
+    try:
+        for f, sb, w in zip(frames, scene_bgs, want):
+            worst = max(worst, float((r.render(f, sb) - w).abs().max()))
+        r.enable_graph(frames[0])
+        for f, sb, w in zip(frames, scene_bgs, want):
+            got = r.render(f, sb)
+            assert not r.check_overflow()
+            worst = max(worst, float((got - w).abs().max()))
+        r.close()
+        r.enable_graph(frames[0], frames_per_replay=3)
+        got = r.render_batch(frames, scene_bgs)
+        assert not r.check_overflow()
+        for k, w in enumerate(want):
+            worst = max(worst, float((got[k] - w).abs().max()))
+        order = (2, 0, 1, 1, 0)
+        five = r.render_batch([frames[j] for j in order], [scene_bgs[j] for j in order])
+        for k, j in enumerate(order):
+            worst = max(worst, float((five[k] - want[j]).abs().max()))
+    finally:
+        r.close()
+        diff_gauss.set_capacity_plan(None)
+    assert worst <= 2e-6, worst
 
 
 @pytest.mark.parametrize("personalized,align", [(True, True), (True, False), (False, True), (False, False)],
