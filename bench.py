@@ -501,15 +501,18 @@ def main():
         log("host frames (PCIe-inclusive): windows ms/step " + " ".join(f"{1e3 * t / args.steps:.3f}" for t in times))
         return dict(times=times, median=statistics.median(times), bytes_per_frame=int(host[0]._buf.numel()))
 
-    def measure_schedule(iterations, densify):
-        """End-to-end throughput of a reference-schedule run (train_face.py:667-746: densify / prune / opacity reset every
-        100 iterations, arguments/__init__.py:92-97) from iteration 2900: crosses warm_step (3000: regularisers on, hair
-        iterations alternate with plain ones = two captured phases), the opacity reset at 3000 and a density-control
-        event every 100 iterations.  Every event drops the captured steps; step() captures them again by itself
-        (FaceTrainer._recapture).  densify=False is the control: same iterations and phases, no density control."""
-        trainer = build_trainer(N, dev, sh_degree=args.sh_degree, seed=0, densify=densify, schedule="reference")
+    def measure_schedule(iterations, densify, schedule="reference", start=550):
+        """End-to-end throughput of a run across density-control events (train_face.py:667-746: densify / prune every 100
+        iterations after iteration 500, arguments/__init__.py:92-97) from iteration `start`.  Every event drops the
+        captured steps; step() captures them again by itself (FaceTrainer._recapture).
+        schedule="reference": the reference's iteration-dependent phases (the alignment switches on after iteration 1000:
+        one phase change inside the run) and its extra prunes; schedule=None: the C3 phase (the headline's step) in every
+        iteration.  densify=False is the control: same iterations and phases, no density control.
+        (The run stays below iteration 3000: from there on the reference prunes every Gaussian whose screen radius exceeds
+        20 px, which in SURVEY 8(d)'s synthetic scene -- sigma = 6.4 px -- is nearly all of them.)"""
+        trainer = build_trainer(N, dev, sh_degree=args.sh_degree, seed=0, densify=densify, schedule=schedule)
         frames = make_frames(trainer, True)
-        trainer.iteration = 2900
+        trainer.iteration = start
         trainer.enable_graph(frames[0], keep_state=True)
         n0 = trainer.g.num_points
         counts, events = [n0], 0
@@ -534,9 +537,12 @@ def main():
         rec = trainer.recaptures
         trainer._drop_graph()
         diff_gauss.set_capacity_plan(None)
-        log(f"reference schedule (densify={densify}): {iterations} iterations in {el:.3f} s, {events} density-control "
-            f"events, {rec} re-captures, Gaussians {counts[0]} -> {counts[-1]}")
-        return dict(seconds=el, iterations=iterations, events=events, recaptures=rec, gaussians=counts)
+        log(f"schedule={schedule} densify={densify}: {iterations} iterations in {el:.3f} s, {events} density-control "
+            f"events, {rec} re-captures ({1e3 * getattr(trainer, 'recapture_seconds', 0.0):.1f} ms of host time), density "
+            f"control {1e3 * getattr(trainer, 'density_seconds', 0.0):.1f} ms, Gaussians {counts[0]} -> {counts[-1]}")
+        return dict(seconds=el, iterations=iterations, events=events, recaptures=rec, gaussians=counts,
+                    recapture_ms=1e3 * getattr(trainer, "recapture_seconds", 0.0),
+                    density_ms=1e3 * getattr(trainer, "density_seconds", 0.0), start=start)
 
     log(f"config: {N} Gaussians, {size}x{size}, world {world}")
     main_run = measure(False, max(1, args.windows))
@@ -545,10 +551,11 @@ def main():
         stable_run = measure(True, max(1, min(3, args.windows)))
 
     host_run = None if args.no_host_frames else measure_host_frames(max(1, min(3, args.windows)))
-    sched_run = sched_ctrl = None
+    sched_run = sched_ctrl = c3_run = None
     if not args.no_schedule:
         sched_run = measure_schedule(args.schedule_iterations, True)
         sched_ctrl = measure_schedule(args.schedule_iterations, False)
+        c3_run = measure_schedule(args.schedule_iterations, True, schedule=None)
 
     if rank == 0:
         kern, R, med = main_run["kern"], main_run["R"], main_run["median"]
@@ -659,21 +666,29 @@ def main():
                 "windows_ms_per_step": [round(1e3 * t / args.steps, 4) for t in host_run["times"]],
                 "host_bytes_per_frame": host_run["bytes_per_frame"],
                 "vs_resident": round((args.steps / hm) / (args.steps / med), 4)}
+        def schedule_entry(run, what):
+            fps = world * run["iterations"] / run["seconds"]
+            return {"workload": what, "value": round(fps, 3), "unit": "frames/s",
+                    "iterations": [run["start"] + 1, run["start"] + run["iterations"]],
+                    "seconds": round(run["seconds"], 4), "density_control_events": run["events"],
+                    "recaptures": run["recaptures"], "recapture_host_ms": round(run["recapture_ms"], 2),
+                    "density_control_host_ms": round(run["density_ms"], 2),
+                    "gaussians_after_each_event": run["gaussians"], "vs_headline": round(fps / value, 4)}
         if sched_run is not None:
-            fps = world * sched_run["iterations"] / sched_run["seconds"]
-            out["reference_schedule"] = {
-                "workload": "train_face schedule from iteration 2900 (crosses warm_step, the opacity reset at 3000 and a "
-                            "densify / prune event every 100 iterations; hair and plain iterations alternate), rendered "
-                            "targets, end to end INCLUDING density control and the re-captures of the step it forces",
-                "value": round(fps, 3), "unit": "frames/s", "iterations": sched_run["iterations"],
-                "seconds": round(sched_run["seconds"], 4), "density_control_events": sched_run["events"],
-                "recaptures": sched_run["recaptures"], "gaussians_after_each_event": sched_run["gaussians"],
-                "vs_headline": round(fps / value, 4)}
+            out["reference_schedule"] = schedule_entry(
+                sched_run, "FaceTrainer(schedule='reference', densify=True): the reference's phases (alignment on after "
+                           "iteration 1000: one phase change) and density control (densify / prune every 100 iterations + "
+                           "its colour / depth prunes), rendered targets, end to end INCLUDING density control and the "
+                           "re-captures of the step it forces")
             if sched_ctrl is not None:
                 cfps = world * sched_ctrl["iterations"] / sched_ctrl["seconds"]
                 out["reference_schedule"]["same_schedule_without_density_control"] = {
                     "value": round(cfps, 3), "unit": "frames/s", "recaptures": sched_ctrl["recaptures"]}
-                out["reference_schedule"]["vs_no_density_control"] = round(fps / cfps, 4)
+                out["reference_schedule"]["vs_no_density_control"] = round(out["reference_schedule"]["value"] / cfps, 4)
+        if c3_run is not None:
+            out["c3_phase_with_density_control"] = schedule_entry(
+                c3_run, "the headline's step (C3 phase in every iteration) with density control on (densify / prune every "
+                        "100 iterations), rendered targets, end to end including the re-captures")
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU oracle baseline (bounded sample)")
             out["cpu_baseline"] = cpu_baseline(N, size, args.sh_degree, args.cpu_budget)

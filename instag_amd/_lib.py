@@ -134,6 +134,21 @@ class graph_capture:
             _keepalive.release()
 
 
+class GraphPool:
+    """A private memory pool that outlives the graphs captured into it.  torch frees a graph pool when the last graph
+    using it is destroyed (and asserts if its handle is used again); a trainer that drops every captured step at a
+    density-control event and captures again right after would allocate a fresh pool -- hundreds of MB of hipMalloc --
+    every time.  A one-node graph captured into the pool and kept here holds it open, so every later capture reuses
+    the same blocks."""
+
+    def __init__(self, device):
+        import torch
+        self.handle = torch.cuda.graph_pool_handle()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, pool=self.handle, stream=capture_stream(device)):
+            self._anchor = torch.zeros(64, device=device)
+
+
 def may_fork(device=None) -> bool:
     """May an operator fork work onto a second stream from the current stream?  Outside a capture: unless the current
     stream carries a whole forked pass (leaf_stream); inside one only from the capture's origin stream (a capture

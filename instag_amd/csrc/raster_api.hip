@@ -1,4 +1,5 @@
 // C-ABI entry points of the rasterizer (see include/instag_hip.h) + buffer layouts, scan and sort.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -30,17 +31,54 @@ struct ProfState {
 ProfState& prof() { static ProfState p; return p; }
 }  // namespace
 
+// An event-record NODE in the graph `stream` is being captured into (the event is re-recorded by every replay).
+// hipEventRecordWithFlags(hipEventRecordExternal) is the direct way; under a capture torch opened it returns
+// hipErrorInvalidValue on ROCm 7.0/7.2 (a plain HIP program gets hipSuccess: scripts/probes/event_node_probe.hip), so the
+// node is otherwise added by hand: capture info -> hipGraphAddEventRecordNode behind the stream's current dependencies
+// -> the node becomes the stream's dependency set.
+static hipError_t record_external(hipEvent_t ev, hipStream_t stream) {
+  static bool direct_ok = true;
+  if (direct_ok) {
+    if (hipEventRecordWithFlags(ev, stream, hipEventRecordExternal) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    direct_ok = false;
+  }
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t ndeps = 0;
+  hipError_t e = hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, &deps, &ndeps);
+  if (e != hipSuccess) return e;
+  if (st != hipStreamCaptureStatusActive || graph == nullptr) return hipErrorIllegalState;
+  hipGraphNode_t node = nullptr;
+  e = hipGraphAddEventRecordNode(&node, graph, deps, ndeps, ev);
+  if (e != hipSuccess) return e;
+  return hipStreamUpdateCaptureDependencies(stream, &node, 1, hipStreamSetCaptureDependencies);
+}
+
 ProfScope::ProfScope(int kernel, hipStream_t stream) : kernel_(kernel), stream_(stream) {
   ProfState& p = prof();
   if (!(p.mask & (1 << kernel))) return;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream_, &cs) != hipSuccess) return;
+  const hipError_t qe = hipStreamIsCapturing(stream_, &cs);
+  static const bool debug = getenv("INSTAG_PROF_DEBUG") != nullptr;
+  if (debug)
+    fprintf(stderr, "[instag prof] kernel %d stream %p: hipStreamIsCapturing -> %s, status %d, pool %zu used %d\n", kernel,
+            (void*)stream_, hipGetErrorString(qe), (int)cs, p.graph_pool.size(), p.graph_used);
+  if (qe != hipSuccess) { (void)hipGetLastError(); return; }
   if (cs != hipStreamCaptureStatusNone) {
     // captured launch: external event-record nodes from the pool (no event may be created while a capture is open)
     std::lock_guard<std::mutex> lk(p.mu);
     if (p.graph_used >= (int)p.graph_pool.size()) return;
     ProfState::GraphPair& g = p.graph_pool[p.graph_used];
-    if (hipEventRecordWithFlags(g.a, stream_, hipEventRecordExternal) != hipSuccess) return;
+    const hipError_t err = record_external(g.a, stream_);
+    if (err != hipSuccess) {
+      fprintf(stderr, "[instag prof] external event record (start, kernel %d, slot %d, stream %p) failed: %s\n", kernel,
+              p.graph_used, (void*)stream_, hipGetErrorString(err));
+      (void)hipGetLastError();
+      return;
+    }
     g.kernel = kernel;
     graph_slot_ = p.graph_used++;
     return;
@@ -53,7 +91,13 @@ ProfScope::~ProfScope() {
     ProfState& p = prof();
     std::lock_guard<std::mutex> lk(p.mu);
     ProfState::GraphPair& g = p.graph_pool[graph_slot_];
-    g.closed = hipEventRecordWithFlags(g.b, stream_, hipEventRecordExternal) == hipSuccess;
+    const hipError_t err = record_external(g.b, stream_);
+    g.closed = err == hipSuccess;
+    if (!g.closed) {
+      fprintf(stderr, "[instag prof] external event record (stop, kernel %d, slot %d, stream %p) failed: %s\n", kernel_,
+              graph_slot_, (void*)stream_, hipGetErrorString(err));
+      (void)hipGetLastError();
+    }
     return;
   }
   if (!start_) return;

@@ -18,9 +18,16 @@ from .motion_net import MotionNetwork as _MotionNetwork
 CONCURRENT_PASSES = True      # fork the attention raster pass(es) onto a second stream
 SHARED_ATTN_PASS = True       # attention map as an auxiliary colour set of the main raster pass
 # Fuse stage (training): the mouth pass on a second stream beside the face pass (1.45 -> 1.26 ms per captured step in
-# round 2).  INSTAG_CONCURRENT_FUSE=0 / 1 overrides the default.
+# round 2).  Round 2 shipped it switched off behind a segmentation fault inside hipGraphLaunch of a LATER, unrelated
+# face-step graph that only a soak of the stage tests showed.  Round 3 removed the two ownership defects the bisect
+# pointed at: side streams drawn from torch's round-robin pool could be the SAME HIP stream
+# under two names once a process had asked for more than 32 (the "fuse" stream is created late, so it was the one that
+# could alias an operator's lane or a capture's warm-up stream: _lib.side_stream now guarantees distinct handles), and
+# captured steps kept their loss -- hence their autograd graph and every parameter's gradient accumulator -- alive, bound
+# to a per-capture stream that later backward passes then hopped to inside an open capture (one capture stream, detached
+# outputs).  The GPU suite passes with the switch on; INSTAG_CONCURRENT_FUSE=0 switches it off.
 import os as _os
-CONCURRENT_FUSE_PASSES = _os.environ.get("INSTAG_CONCURRENT_FUSE", "0") == "1"
+CONCURRENT_FUSE_PASSES = _os.environ.get("INSTAG_CONCURRENT_FUSE", "1") == "1"
 
 
 def _side_stream(device):
@@ -218,8 +225,8 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         eye = preds["ambient_eye"]
         return torch.cat([preds["ambient_aud"], eye, torch.zeros_like(eye)], dim=-1)
 
-    def attn_pass(preds):
-        out = rasterizer(means3D=means3D.detach(), means2D=screenspace_points, shs=None,
+    def attn_pass(preds, carrier=None):
+        out = rasterizer(means3D=means3D.detach(), means2D=screenspace_points if carrier is None else carrier, shs=None,
                          colors_precomp=attn_colors(preds), opacities=opacity.detach(), scales=scales.detach(),
                          rotations=rotations.detach(), cov3Ds_precomp=None, extra_attrs=ones)
         return out[0]
@@ -235,12 +242,18 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
         # remaining attention pass(es) only share inputs with the main pass: run them on a second stream
         main_stream = torch.cuda.current_stream(dev)
         side = _side_stream(dev)
+        # The screen-space gradient carrier is a leaf that the side-stream pass(es) AND the main pass write a gradient to.
+        # A leaf's gradient accumulator runs on ONE stream (the one current at the leaf's first use): fed directly from
+        # two streams, one of the producers always mismatches ("AccumulateGrad node's stream does not match").  The side
+        # passes therefore get a view made HERE, on the main stream: their gradient reaches the leaf through the view's
+        # backward node, which runs where the view was made.
+        side_carrier = screenspace_points.view_as(screenspace_points)
         side.wait_stream(main_stream)
         with torch.cuda.stream(side):
             if not shared:
-                rendered_attn = attn_pass(motion_preds)
+                rendered_attn = attn_pass(motion_preds, side_carrier)
             if personalized:
-                p_rendered_attn = attn_pass(p_motion_preds)
+                p_rendered_attn = attn_pass(p_motion_preds, side_carrier)
 
     shs = pc.get_features_pair if (means3D.is_cuda and hasattr(pc, "get_features_pair")) else pc.get_features
     outs = rasterizer(
@@ -350,7 +363,12 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
     if not inference:
         if exp_feat is None:
             exp_feat = _zeros_const(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
-        motion_preds_face = motion_net_face(pc_face.get_xyz, audio_feat, exp_feat)
+        # (gaussian_renderer/__init__.py:361 evaluates the face field with autograd on and then reads it under no_grad
+        # only, :365-372: no gradient can reach it.  Evaluated without a graph here: same values, no activations saved,
+        # and -- when this pass runs on a stream of its own beside the face pass -- no gradient accumulators of the
+        # face field's parameters created on that stream)
+        with torch.no_grad():
+            motion_preds_face = motion_net_face(pc_face.get_xyz, audio_feat, exp_feat)
     else:
         motion_preds_face = motion_net_face.cache
     h_face = None if inference else dict.get(motion_preds_face, "_h")

@@ -429,6 +429,8 @@ class FaceTrainer:
         iteration.  Any change of the parameter set drops a captured graph."""
         if not self._densify_due(it):
             return False
+        import time
+        t0 = time.perf_counter()
         o = self.opt
         interval_hit = it > o.densify_from_iter and it % o.densification_interval == 0
         if it < o.densify_until_iter:
@@ -448,6 +450,7 @@ class FaceTrainer:
             self.g.prune_points(green)
             self.g.prune_points(self.g.get_xyz[:, -1] < -0.07)
         self._drop_graph(keep_mode=True)          # (graph mode stays on: the next iteration captures its step again)
+        self.density_seconds = getattr(self, "density_seconds", 0.0) + time.perf_counter() - t0     # host time (it syncs)
         return True
 
     def _drop_graph(self, keep_mode: bool = False):
@@ -474,6 +477,8 @@ class FaceTrainer:
         set (densify / prune / opacity reset) or the needed capacity changed since.  The capacity follows the Gaussian
         count; the training state and the iteration counter are untouched, so the decision to capture may be taken by
         every rank of a data-parallel run independently of what the others replay."""
+        import time
+        t0 = time.perf_counter()
         mode = self._graph_mode
         n = max(1, self.g.num_points)
         cap = max(int(mode["capacity"] * max(1.0, n / mode["capacity_n"])), int(min_capacity))
@@ -481,6 +486,7 @@ class FaceTrainer:
         mode["capacity"], mode["capacity_n"] = g.capacity, n
         self._graph_cache[phase] = g
         self.recaptures = getattr(self, "recaptures", 0) + 1
+        self.recapture_seconds = getattr(self, "recapture_seconds", 0.0) + time.perf_counter() - t0      # host time
         return g
 
     def _overflow_decision(self, graph) -> int:
@@ -714,8 +720,8 @@ class GraphedStep:
         # other threads (the collective library's watchdog) may touch the HIP runtime while this thread captures
         mode = {"capture_error_mode": "thread_local"} if self.distributed else {}
         if t._pool is None:
-            t._pool = torch.cuda.graph_pool_handle()
-        mode["pool"] = t._pool
+            t._pool = _lib.GraphPool(dev)
+        mode["pool"] = t._pool.handle
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         dot = os.environ.get("INSTAG_GRAPH_DOT")       # diagnostics: the captured step's nodes and edges (DOT)

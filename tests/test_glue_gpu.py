@@ -268,6 +268,10 @@ def test_mouth_branch_gpu_matches_cpu_modules():
     oc, od = cpu(x, a, move), dev(x.cuda(), a.cuda(), move.cuda())
     for k in oc:
         _close(od[k], oc[k], k, tol=2e-5)
+    # (the outputs go before the next forward: alive, they would keep this forward's autograd graph -- and the gradient
+    # accumulators of `dev`'s parameters, bound to THIS call's streams -- into a backward whose audio branch runs on a
+    # side stream; PyTorch warns about exactly that, and tests/conftest.py turns the warning into an error)
+    del od, oc
 
     # end to end: face model + face field feed the jaw-movement feature, mouth model is rendered
     size = 96
@@ -287,6 +291,9 @@ def test_mouth_branch_gpu_matches_cpu_modules():
     assert all(p_.grad is None for p_ in face_net.parameters())          # the movement feature carries no gradient
 
     # fuse stage: face over mouth over the scene background; with a zero bg_color it is plain "over" compositing
+    # (the first render's package goes first: its autograd graph would keep the mouth parameters' gradient accumulators
+    # bound to this stream, while render_fuse may run the mouth pass -- and its backward -- on a stream of its own)
+    del pkg
     from instag_amd.renderer import render_fuse
     pc_face.neural_motion_grid = PersonalizedMotionNetwork(args=face_args).cuda()
     scene_bg = torch.rand(3, size, size, device="cuda")

@@ -570,6 +570,8 @@ def test_dp_two_ranks_share_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29531", os.path.join(root, "tests", "dp_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=root)
+    if r.returncode != 0:
+        sys.stderr.write("---- dp_worker stdout ----\n" + r.stdout[-4000:] + "\n---- dp_worker stderr ----\n" + r.stderr[-12000:])
     assert r.returncode == 0 and "DP-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
