@@ -466,12 +466,7 @@ def main():
         graph = trainer.enable_graph(frames[0])
 
         def run(n):
-            feeder.prefetch(host[0], 0)
-            for i in range(n):
-                if i + 1 < n:
-                    feeder.prefetch(host[(i + 1) % len(host)], (i + 1) % 2)
-                trainer.step(feeder.take(i % 2))
-                feeder.release(i % 2)
+            feeder.run(trainer.step, host, n)
 
         run(args.warmup)
         torch.cuda.synchronize()

@@ -106,20 +106,39 @@ _CAPTURE_ORIGIN = None
 
 
 class graph_capture:
-    """``torch.cuda.graph(graph, **kw)`` on the package's capture stream that also records the capture's origin stream
-    for may_fork() and releases the cross-stream tensors held for the capture (_keepalive) when it has ended --
-    whether it succeeded or raised."""
+    """Stream capture of one graph on the package's capture stream; records the capture's origin stream for may_fork()
+    and releases the cross-stream tensors held for the capture (_keepalive) when it has ended -- whether it succeeded
+    or raised.  The default form is ``torch.cuda.graph`` (device synchronisation + allocator cache flush in front: right
+    for a first capture).  ``light=True`` is for re-captures inside a train loop: ``torch.cuda.graph.__enter__`` costs a
+    device synchronisation and an ``empty_cache()`` (3 ms of hipFree, and every eager allocation after it pays hipMalloc
+    again); here the capture simply begins -- the private pool is kept open by a GraphPool, nothing of the current
+    stream's pending work is touched by recording launches."""
 
-    def __init__(self, graph, **kw):
+    def __init__(self, graph, light: bool = False, **kw):
         import torch
         if "stream" not in kw:
             kw = dict(kw, stream=capture_stream())
-        self._ctx = torch.cuda.graph(graph, **kw)
+        self._light = bool(light)
+        self._graph = graph
+        if self._light:
+            self._stream_ctx = torch.cuda.stream(kw["stream"])
+            self._begin = {k: v for k, v in kw.items() if k in ("pool", "capture_error_mode")}
+        else:
+            self._ctx = torch.cuda.graph(graph, **kw)
 
     def __enter__(self):
         global _CAPTURE_ORIGIN
         import torch
-        r = self._ctx.__enter__()
+        if self._light:
+            self._stream_ctx.__enter__()
+            try:
+                self._graph.capture_begin(**self._begin)
+            except BaseException:
+                self._stream_ctx.__exit__(None, None, None)
+                raise
+            r = None
+        else:
+            r = self._ctx.__enter__()
         self._prev = _CAPTURE_ORIGIN
         _CAPTURE_ORIGIN = torch.cuda.current_stream()
         return r
@@ -128,6 +147,12 @@ class graph_capture:
         global _CAPTURE_ORIGIN
         _CAPTURE_ORIGIN = self._prev
         try:
+            if self._light:
+                try:
+                    self._graph.capture_end()
+                finally:
+                    self._stream_ctx.__exit__(*exc)
+                return None
             return self._ctx.__exit__(*exc)
         finally:
             from . import _keepalive

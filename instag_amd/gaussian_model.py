@@ -92,7 +92,9 @@ def sh_to_rgb(deg: int, features: torch.Tensor, xyz: torch.Tensor, camera_center
     d = xyz - camera_center.reshape(1, 3)
     d = d / d.norm(dim=1, keepdim=True)
     m = (deg + 1) ** 2
-    rgb = torch.einsum("nm,nmc->nc", sh_basis(deg, d), features[:, :m, :])
+    # (elementwise, not einsum: the batched-GEMM route would load the BLAS library for an [N, 4] x [N, 4, 3] contraction --
+    # ~0.3 s on first use, in the middle of a density-control event)
+    rgb = (sh_basis(deg, d)[:, :, None] * features[:, :m, :]).sum(dim=1)
     return torch.clamp_min(rgb + 0.5, 0.0)
 
 
@@ -434,7 +436,8 @@ class GaussianModel:
         samples = torch.randn(stds.shape, device=stds.device, generator=generator) * stds
         rots = quat_to_rotmat(self._p["rotation"].data[sel]).repeat(N, 1, 1)
         extra = {k: self._p[k].data[sel].repeat(N, *([1] * (self._p[k].dim() - 1))) for k in PARAM_NAMES}
-        extra["xyz"] = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._p["xyz"].data[sel].repeat(N, 1)
+        # (R @ sample written elementwise: torch.bmm would load the BLAS library -- 0.9 s on first use, inside the event)
+        extra["xyz"] = (rots * samples.unsqueeze(1)).sum(dim=-1) + self._p["xyz"].data[sel].repeat(N, 1)
         extra["scaling"] = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
         self._append(extra)
         prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device=sel.device, dtype=torch.bool)))

@@ -104,21 +104,28 @@ class Frame:
 
 
 class HostFrameFeeder:
-    """Frames that live in (pinned) HOST memory, uploaded one step ahead of the step that reads them.
+    """Frames that live in (pinned) HOST memory, uploaded ahead of the step that reads them.
 
     The reference uploads a frame's tensors inside the iteration that uses them (train_face.py:324-327 masks and image,
     gaussian_renderer/__init__.py:188-189 audio window and expression vector: a handful of blocking ``.cuda()`` copies,
     ~4 MB at 512x512).  Here a frame is ONE packed byte buffer (Frame.packed): while step i runs, frame i+1 travels on a
-    copy stream into one of two device staging buffers; step i+1 waits for that copy's event (long since signalled),
-    and its first action -- the device-to-device copy into the captured step's static frame -- reads the staging
-    buffer.  The copy stream in turn waits until the step that last read the staging slot has finished with it."""
+    second stream into one of ``slots`` device staging buffers, and step i+1's first action -- the device-to-device copy
+    into the captured step's static frame -- reads the staging buffer.
 
-    def __init__(self, example: Frame, device):
+    All ordering is done on the HOST (event.synchronize(), no stream-to-stream waits): a cross-stream wait is a barrier
+    packet in front of the replayed graph, and two of them per step cost 2.6 % of the step (scripts/probes/
+    host_frames_probe2.py: 0.933 -> 0.958 ms), more than the upload itself, which overlaps (0.938 ms).  The host runs a few
+    steps ahead of the device in replay mode, so a staging slot is reused only ``slots`` steps later and the host-side
+    wait for its last reader returns at once."""
+
+    def __init__(self, example: Frame, device, slots: int = 4):
         self.device = torch.device(device)
-        self.stage = [example.packed(self.device), example.packed(self.device)]
-        self.stream = _lib.side_stream(self.device, "frame_upload")
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
-        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        self.slots = int(slots)
+        self.stage = [example.packed(self.device) for _ in range(self.slots)]
+        # (no stream of its own: the capture warm-up stream exists anyway and is idle outside enable_graph)
+        self.stream = _lib.warmup_stream(self.device)
+        self.ready = [torch.cuda.Event() for _ in range(self.slots)]
+        self.consumed = [torch.cuda.Event() for _ in range(self.slots)]
         for e in self.consumed:
             e.record(torch.cuda.current_stream(self.device))
 
@@ -127,20 +134,30 @@ class HostFrameFeeder:
         return frame.packed("cpu", pin=True)
 
     def prefetch(self, host_frame: Frame, slot: int):
-        """Start the upload of ``host_frame`` into staging slot ``slot`` on the copy stream."""
-        self.stream.wait_event(self.consumed[slot])
+        """Start the upload of ``host_frame`` into staging slot ``slot`` (once the slot's last reader has finished)."""
+        self.consumed[slot].synchronize()
         with torch.cuda.stream(self.stream):
             self.stage[slot].copy_from(host_frame)
             self.ready[slot].record(self.stream)
 
     def take(self, slot: int) -> Frame:
-        """The staged frame, valid for work enqueued on the current stream from now on."""
-        torch.cuda.current_stream(self.device).wait_event(self.ready[slot])
+        """The staged frame (its upload has completed when this returns)."""
+        self.ready[slot].synchronize()
         return self.stage[slot]
 
     def release(self, slot: int):
         """Everything enqueued on the current stream so far is the last reader of staging slot ``slot``."""
         self.consumed[slot].record(torch.cuda.current_stream(self.device))
+
+    def run(self, step, host_frames, n: int):
+        """``step(frame)`` over n frames (host_frames cyclically), each uploaded one step ahead."""
+        k = self.slots
+        self.prefetch(host_frames[0], 0)
+        for i in range(n):
+            if i + 1 < n:
+                self.prefetch(host_frames[(i + 1) % len(host_frames)], (i + 1) % k)
+            step(self.take(i % k))
+            self.release(i % k)
 
 
 def make_frame(cam, frame_data) -> Frame:
@@ -223,6 +240,38 @@ def face_phase(iteration: int, opt=OptimizationParams, warm_step: int = 3000, ha
     priors = (not mode_long) and iteration > warm_step + 2000
     return FacePhase(align=align, warm=iteration > warm_step, hair_mask_iter=hair, priors=priors,
                      prior_depth=priors and iteration % opt.opacity_reset_interval > 100)
+
+
+_DENSITY_WARM = set()
+
+
+@torch.no_grad()
+def warm_density_control(device, sh_degree: int = 1, opt=OptimizationParams):
+    """Run every torch operator of a density-control event once, on a 256-Gaussian dummy model.  torch loads a kernel's
+    code object on the kernel's first launch; the masked gathers, concatenations, random draws and reductions of
+    densify / prune / opacity reset otherwise pay that (~0.8 s in total on this image) inside the first event of a run,
+    with the device idle.  Called once per device by FaceTrainer.enable_graph when density control is on."""
+    device = torch.device(device)
+    key = (device.type, device.index, sh_degree)
+    if key in _DENSITY_WARM or device.type != "cuda":
+        return
+    _DENSITY_WARM.add(key)
+    from .gaussian_model import sh_to_rgb
+    g = GaussianModel(sh_degree).create_random(256, device, seed=0)
+    g.training_setup(opt, fused=True)
+    gen = torch.Generator(device=device).manual_seed(0)
+    for _ in range(2):
+        n = g.num_points
+        g.xyz_gradient_accum = torch.rand(n, 1, device=device)
+        g.denom = torch.ones(n, 1, device=device)
+        g.max_radii2D = torch.rand(n, device=device) * 30.0
+        g._p["scaling"].data[: n // 2] -= 3.0                        # both the clone and the split selection non-empty
+        g.densify_and_prune(0.5, 0.005, 0.2, 20, generator=gen)
+        g.reset_opacity()
+        rgb = sh_to_rgb(g.active_sh_degree, g.get_features, g.get_xyz, torch.zeros(3, device=device))
+        g.prune_points((rgb[:, 0] < 30 / 255) & (rgb[:, 1] > 225 / 255) & (rgb[:, 2] < 30 / 255))
+        g.prune_points(g.get_xyz[:, -1] < -0.07)
+    torch.cuda.synchronize(device)
 
 
 class FaceTrainer:
@@ -618,6 +667,8 @@ class FaceTrainer:
             after = self.iteration + (0 if keep_state else max(1, warmup_steps) + 2) + 1
             phase = self.phase_of(after)                                       # the iteration right after capture
         snap = self.snapshot() if keep_state else None
+        if self.densify and self.on_gpu:
+            warm_density_control(self.device, self.g.max_sh_degree, self.opt)
         self._graph = GraphedStep(self, example_frame, headroom, max(1, warmup_steps), split_for_allreduce, phase,
                                   min_capacity=min_capacity, restore=snap)
         self._graph_phase = phase
@@ -722,6 +773,7 @@ class GraphedStep:
         if t._pool is None:
             t._pool = _lib.GraphPool(dev)
         mode["pool"] = t._pool.handle
+        mode["light"] = not cold
         self.graph_a = torch.cuda.CUDAGraph()
         self.graph_b = None
         dot = os.environ.get("INSTAG_GRAPH_DOT")       # diagnostics: the captured step's nodes and edges (DOT)
