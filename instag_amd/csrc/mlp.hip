@@ -18,6 +18,8 @@
 // with both operands read straight from global memory (one coalesced 128-B row segment per half
 // wave); per-wave partial tiles are combined in a fixed order (LDS, then a second pass), so the
 // result is bitwise reproducible.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace instag {
@@ -783,7 +785,10 @@ weight_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int cou
   if (g == 0 && i < count) dW[i] = ((s_part[0][e] + s_part[1][e]) + s_part[2][e]) + s_part[3][e];
 }
 
-inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256)); }
+inline int wg_blocks(int N) {
+  static const int cap = [] { const char* e = getenv("INSTAG_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+  return std::max(1, std::min(cap, (N + 255) / 256));
+}
 
 // Two workgroups per CU, each staging the weights once and walking a strided list of 32-row tiles.  (768 and 1024
 // workgroups -- one tile per wave at 100k rows -- measured the same or slower: sigma_net forward 44.9 / 44.6 / 47.8 us.)

@@ -62,6 +62,12 @@ class _MotionGlue(torch.autograd.Function):
         return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:], None
 
 
+# sigma_net's three weight-gradient GEMMs (60 % of the step's weight-gradient bytes) launched right behind its backward
+# kernel, beside the attention heads' and the encoder's backward, instead of later beside the personalised field's
+import os as _os
+EARLY_SIGMA_WEIGHT_GRADS = _os.environ.get("INSTAG_WGRAD_EARLY", "0") == "1"
+
+
 class _GlueSigma(torch.autograd.Function):
     """motion_glue followed by sigma_net (scene/motion_net.py:291-306) as ONE autograd node whose backward is one
     kernel: sigma_net's backward writes d_enc_x / d_aud / d_eye_pre from its accumulators and keeps the per-frame
@@ -127,6 +133,8 @@ class _GlueSigma(torch.autograd.Function):
             for dz, inp, idx in jobs:
                 if ctx.needs_input_grad[5 + idx]:
                     deferred.defer_weight_grad(dz, inp, ctx.weights[idx])
+            if EARLY_SIGMA_WEIGHT_GRADS:
+                deferred.flush_async(dev)
         else:
             for dz, inp, idx in jobs:
                 if ctx.needs_input_grad[5 + idx]:

@@ -70,6 +70,27 @@ def render(viewpoint_camera, pc, pipe=None, bg_color=None, scaling_modifier=1.0,
             "depth": depth, "alpha": alpha, "normal": normal, "radii": radii}
 
 
+class _BackwardCut(torch.autograd.Function):
+    """Identity on a set of tensors, as ONE autograd node: the place where FaceTrainer's three-segment data-parallel
+    step cuts the backward pass.  ``torch.autograd.grad(loss, cut_outputs)`` stops AT this node -- it runs the loss
+    block, the rasterizer and the deform operator and nothing of the motion fields (without the node the capture
+    points would sit on the encoders' own nodes, and the engine would have to run every producer of those nodes'
+    other inputs -- the whole sigma-net / attention-head backward -- before it could hand the gradients out);
+    ``torch.autograd.backward(cut_outputs, grads)`` continues from here."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for t in tensors)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return grads
+
+
+MARK_BACKWARD_CUT = False     # set by FaceTrainer._forward_backward_cut around its render_motion call
+
+
 _ONES = {}
 
 
@@ -113,6 +134,7 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
 
     xyz = pc.get_xyz
     p_motion_preds = None
+    cut_tensors = amb_cut = None
     if xyz.is_cuda and hasattr(motion_net, "start_audio"):
         # both networks' audio branches depend only on the frame: start them now, each on its own side stream
         motion_net.start_audio(audio_feat, 1, exp_feat)
@@ -178,8 +200,19 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
     elif fused:
         # deltas + softplus / normalize / sigmoid in one HIP kernel per pass (instag_amd/glue.py)
         from .glue import deform_activate
-        outs_d = deform_activate(xyz_route, pc._scaling, pc._rotation, pc._opacity, motion_preds["_h"],
-                                 p_route if p_route is not None else p_motion_preds["_p"], motion_reg_weight)
+        p_in = p_route if p_route is not None else p_motion_preds["_p"]
+        h_in, amb_cut = motion_preds["_h"], None
+        if MARK_BACKWARD_CUT:
+            # every tensor through which a gradient crosses from the rasterizer side (deform operator, attention
+            # colours) to the motion fields goes through one identity node: the three-segment step's cut
+            amb_in = motion_preds["_amb3"] if (return_attn and SHARED_ATTN_PASS) else None
+            ins = [t for t in (xyz_route, h_in, p_in, amb_in) if t is not None]
+            cut_tensors = list(_BackwardCut.apply(*ins))
+            xyz_c, h_in, p_in = cut_tensors[0], cut_tensors[1], cut_tensors[2]
+            amb_cut = cut_tensors[3] if amb_in is not None else None
+        else:
+            xyz_c = xyz_route
+        outs_d = deform_activate(xyz_c, pc._scaling, pc._rotation, pc._opacity, h_in, p_in, motion_reg_weight)
         means3D, scales, rotations, opacity = outs_d[:4]
         motion_reg = outs_d[4] if motion_reg_weight is not None else None
         # The reference scales the universal field's displacement IN PLACE (d_xyz *= p_scale, :217): the dictionary it
@@ -256,10 +289,13 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
                 p_rendered_attn = attn_pass(p_motion_preds, side_carrier)
 
     shs = pc.get_features_pair if (means3D.is_cuda and hasattr(pc, "get_features_pair")) else pc.get_features
+    aux = attn_colors(motion_preds) if shared else None
+    if cut_tensors is not None and shared:
+        aux = amb_cut
     outs = rasterizer(
         means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None, opacities=opacity,
         scales=scales, rotations=rotations, cov3Ds_precomp=None, extra_attrs=ones,
-        **({"aux_colors": attn_colors(motion_preds)} if shared else {}))
+        **({"aux_colors": aux} if shared else {}))
     image, depth, normal, alpha, radii, extra = outs[:6]
     if shared:
         rendered_attn = outs[6]
@@ -280,7 +316,9 @@ def render_motion(viewpoint_camera, pc, motion_net, pipe=None, bg_color=None, sc
             "visibility_filter": lambda: radii > 0,      # one launch, only when somebody reads it
             "depth": depth, "alpha": alpha, "normal": normal, "radii": radii, "motion": motion_preds,
             "p_motion": p_motion_preds if personalized or align else None, "attn": rendered_attn,
-            "p_attn": p_rendered_attn, "motion_reg": motion_reg})
+            "p_attn": p_rendered_attn, "motion_reg": motion_reg,
+            # (fused shared-pass path only; None otherwise)
+            "_cut": cut_tensors if (cut_tensors is not None and shared and not fork) else None})
 
 
 def _top_values(v, kmax, largest):

@@ -415,6 +415,59 @@ class FaceTrainer:
             pkg["_m2d_aux"] = diff_gauss.take_folded_aux(pkg["viewspace_points"])
         return pkg, loss, Ll1
 
+    def _forward_backward_cut(self, frame: Frame, phase: FacePhase = C3_PHASE):
+        """The step's forward and the FIRST part of its backward: from the loss through the loss block, the rasterizer
+        and the deform operator -- up to the tensors render_motion names as the cut (the motion fields' head outputs,
+        the routed position, the attention colours).  Afterwards the gradients of every per-Gaussian parameter except
+        the position (SH coefficients, opacity, scale, rotation: 20 of 24 floats per Gaussian at SH degree 1, 8 MB at
+        100k) are FINAL and in ``.grad``; ``finish()`` runs the rest of the backward pass (motion fields, encoders,
+        position).  A data-parallel step exchanges the first bucket while ``finish()`` computes (GraphedStep "early").
+        -> (pkg, loss, Ll1, early_params, finish)"""
+        from . import renderer
+        from .renderer import render_motion
+        from .deferred import deferred_grads
+        from . import diff_gauss
+        assert self.on_gpu
+        renderer.MARK_BACKWARD_CUT = True
+        try:
+            pkg = render_motion(frame, self.g, self.motion_net, None, self.bg, return_attn=True, personalized=False,
+                                align=phase.align, motion_reg_weight=1e-5 if phase.warm else None)
+        finally:
+            renderer.MARK_BACKWARD_CUT = False
+        loss, Ll1 = self.loss_fn(frame, pkg, warm=phase.warm, hair_mask_iter=phase.hair_mask_iter,
+                                 priors=phase.priors, prior_depth=phase.prior_depth)
+        cut = dict.get(pkg, "_cut")
+        if not cut:
+            raise RuntimeError("the three-segment step needs render_motion's fused path (align=True on the GPU)")
+        cut = [c for c in cut if c is not None and c.requires_grad]
+        vs = pkg["viewspace_points"]
+        early = [q for k, q in self.g._p.items() if k != "xyz" and q.requires_grad]
+        if getattr(self, "_one", None) is None:
+            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        try:
+            with deferred_grads(self.device):
+                got = torch.autograd.grad(loss, cut + early + [vs], grad_outputs=self._one, allow_unused=True,
+                                          retain_graph=False)
+        except BaseException:
+            diff_gauss.reset_aux_state()
+            raise
+        g_cut, g_early, g_vs = got[:len(cut)], got[len(cut):len(cut) + len(early)], got[-1]
+        have = []
+        for q, gq in zip(early, g_early):
+            if gq is not None:
+                q.grad = gq
+                have.append(q)
+        # (the aux image's share of the screen-space gradient was put into vs.grad by the block's exit)
+        if g_vs is not None:
+            vs.grad = g_vs if vs.grad is None else vs.grad.add_(g_vs)
+        roots = [(c, gc) for c, gc in zip(cut, g_cut) if gc is not None]
+
+        def finish():
+            with deferred_grads(self.device):
+                torch.autograd.backward([c for c, _ in roots], [gc for _, gc in roots])
+
+        return pkg, loss, Ll1, have, finish
+
     @torch.no_grad()
     def _update_stats(self, vs_grad, radii, grad_add=None):
         """Densification statistics of this rank's frame (train_face.py:670-671; scene/gaussian_model.py:683-685).
@@ -721,8 +774,18 @@ class GraphedStep:
         dev = t.device
         assert dev.type == "cuda", "graph mode needs the GPU"
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        # two graphs with the (eager) gradient all-reduce between them; can be forced for single-rank tests
-        self.split = self.distributed if split_for_allreduce is None else bool(split_for_allreduce)
+        # two graphs with the (eager) gradient all-reduce between them; can be forced for single-rank tests.
+        # "early": THREE graphs -- A' (forward, backward down to the motion fields' outputs), A'' (the motion fields'
+        # backward), B (scale, hand back, statistics, optimizers): the bucket of the per-Gaussian gradients that are
+        # final after A' (8 of the 10 MB at 100k Gaussians) is exchanged WHILE A'' runs, the small second bucket
+        # (positions + networks) behind it.  INSTAG_DP_EARLY_ALLREDUCE=1 makes it the form several ranks use.
+        if split_for_allreduce is None:
+            split_for_allreduce = ("early" if os.environ.get("INSTAG_DP_EARLY_ALLREDUCE", "1") == "1" else True) \
+                if self.distributed else False
+        # (the cut runs through the fused deform operator, which needs the alignment on: a phase without it -- the same
+        # on every rank -- takes the two-graph form)
+        self.early = split_for_allreduce == "early" and bool(phase.align)
+        self.split = bool(split_for_allreduce)
         self.static = example.clone_static()
         cold = warmup_steps > 0
         if cold:
@@ -780,6 +843,7 @@ class GraphedStep:
         if dot:
             self.graph_a.enable_debug_mode()
         self.plan.begin_step()
+        self.graph_a2 = None
         if not self.split:
             with _no_gc(cold), _lib.graph_capture(self.graph_a, **mode):
                 pkg, loss, l1 = t._forward_backward(self.static, phase, fold_aux=True)
@@ -788,6 +852,30 @@ class GraphedStep:
             # nothing captured is released before the capture has ended (ROCm 7.2: frees inside the capture
             # window intermittently crash hipStreamEndCapture)
             del pkg
+        elif self.early:
+            with _no_gc(cold), _lib.graph_capture(self.graph_a, **mode):
+                pkg, loss, l1, early, finish = t._forward_backward_cut(self.static, phase)
+                self._vs_grad, self._radii = pkg["viewspace_points"].grad, pkg["radii"]
+                self._params_early = early
+                self._bucket_early = flat_grad_bucket(early)
+            self.graph_a2 = torch.cuda.CUDAGraph()
+            with _no_gc(False), _lib.graph_capture(self.graph_a2, **mode):
+                finish()
+                ids = {id(q) for q in early}
+                self._params = [q for q in with_grad(t._all_params()) if id(q) not in ids]
+                self._bucket = flat_grad_bucket(self._params)
+            del pkg, finish
+            self.graph_b = torch.cuda.CUDAGraph()
+            with _no_gc(False), _lib.graph_capture(self.graph_b, **mode):
+                with torch.no_grad():
+                    if self.distributed:
+                        self._bucket_early.mul_(1.0 / dist.get_world_size())
+                        self._bucket.mul_(1.0 / dist.get_world_size())
+                    scatter_grad_bucket(self._params_early, self._bucket_early)
+                    scatter_grad_bucket(self._params, self._bucket)
+                    t._update_stats(self._vs_grad, self._radii)
+                    t._step_optimizers()
+                    t._zero_grad()
         else:
             with _no_gc(cold), _lib.graph_capture(self.graph_a, **mode):
                 pkg, loss, l1 = t._forward_backward(self.static, phase)
@@ -818,6 +906,17 @@ class GraphedStep:
         self._replays += 1
         self.static.copy_from(frame)
         self.graph_a.replay()
+        if self.graph_a2 is not None:
+            # the first bucket travels while the motion fields' backward runs (the collective library works on its own
+            # stream, ordered behind graph A' by the stream it was issued from); graph B waits for both exchanges
+            work = dist.all_reduce(self._bucket_early, op=dist.ReduceOp.SUM, async_op=True) if self.distributed else None
+            self.graph_a2.replay()
+            if self.distributed:
+                work2 = dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM, async_op=True)
+                work.wait()
+                work2.wait()
+            self.graph_b.replay()
+            return
         if self.graph_b is not None:
             if self.distributed:
                 dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)       # the division by the world size is in graph B

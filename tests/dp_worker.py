@@ -22,18 +22,23 @@ def main():
     frames = [make_frame(cams[(rank + k * world) % len(cams)].to(dev), synthetic_frame(128, rank + k * world, dev))
               for k in range(3)]
     results = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "graph-early"):
         tr = build_trainer(3000, dev, seed=1)
         try:
             if mode == "graph":
+                tr.enable_graph(frames[0], warmup_steps=2, split_for_allreduce=True)      # the two-graph form
+                assert tr._graph.split and tr._graph.graph_a2 is None
+            elif mode == "graph-early":
+                # the default with several ranks: three graphs, the per-Gaussian bucket is exchanged (asynchronously)
+                # beside the motion fields' backward
                 tr.enable_graph(frames[0], warmup_steps=2)
-                assert tr._graph.split, "several ranks must use the two-graph form"
+                assert tr._graph.split and tr._graph.graph_a2 is not None, "several ranks must use the split forms"
             else:
                 for _ in range(4):
                     tr.step(frames[0])
             for i in range(4):
                 tr.step(frames[i % 3])
-            if mode == "graph":
+            if mode != "eager":
                 assert not tr._graph.check_overflow()
         finally:
             diff_gauss.set_capacity_plan(None)
@@ -46,6 +51,8 @@ def main():
         results[mode] = vec
     diff = float((results["eager"] - results["graph"]).abs().max())
     assert diff <= 1e-5, f"graph-split DP step differs from the eager DP step by {diff}"
+    diff_early = float((results["eager"] - results["graph-early"]).abs().max())
+    assert diff_early <= 1e-5, f"three-segment DP step differs from the eager DP step by {diff_early}"
 
     # Only ONE rank overflows its instance capacity: the decision to capture again is collective (all-reduce MAX of the
     # sticky flags at a replay count every rank reaches in the same step), the capture consumes no iteration and runs no

@@ -296,13 +296,23 @@ def test_graphed_train_step_matches_eager():
     frames = [make_frame(cams[i].to(dev), synthetic_frame(128, i, dev)) for i in range(3)]
     losses = {}
     params = {}
-    for mode in ("eager", "graph", "graph-split"):
+    for mode in ("eager", "graph", "graph-split", "graph-early"):
         tr = build_trainer(3000, dev, seed=1)
         try:
             if mode != "eager":
                 # 2 eager + 2 capacity-mode steps on frame 0; "graph-split" = the two-graph form used with several
-                # ranks (forward+backward | gradient exchange | statistics+optimizers)
-                tr.enable_graph(frames[0], warmup_steps=2, split_for_allreduce=(mode == "graph-split"))
+                # ranks (forward+backward | gradient exchange | statistics+optimizers); "graph-early" = the
+                # three-graph form whose first bucket (SH, opacity, scale, rotation gradients, final before the motion
+                # fields' backward runs) is exchanged beside that backward
+                tr.enable_graph(frames[0], warmup_steps=2,
+                                split_for_allreduce={"graph": False, "graph-split": True, "graph-early": "early"}[mode])
+                if mode == "graph-early":
+                    g = tr._graph
+                    assert g.graph_a2 is not None and g.graph_b is not None
+                    names = {k for k, q in tr.g._p.items() if any(q is e for e in g._params_early)}
+                    assert names == {"f_dc", "f_rest", "opacity", "scaling", "rotation"}, names
+                    assert any(q is tr.g._p["xyz"] for q in g._params)
+                    assert g._bucket_early.numel() == 20 * tr.g.num_points
             else:
                 for _ in range(4):
                     tr.step(frames[0])
@@ -316,7 +326,7 @@ def test_graphed_train_step_matches_eager():
         losses[mode] = ls
         params[mode] = tr.g.get_xyz.detach().clone()
     assert tr.iteration == 10
-    for mode in ("graph", "graph-split"):
+    for mode in ("graph", "graph-split", "graph-early"):
         for a_, b_ in zip(losses["eager"], losses[mode]):
             assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (mode, losses["eager"], losses[mode])
         assert float((params["eager"] - params[mode]).abs().max()) <= 1e-5
