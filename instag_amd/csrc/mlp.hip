@@ -333,7 +333,7 @@ mlp_forward_kernel(MlpDims d, const float* __restrict__ X, const float* __restri
                 v[i] = mul[b][4 * q + i] * act;
               }
           }
-          if (valid && f0 < K0) {            // (K0 = 74 is even: 8-byte stores)
+          if (valid && f0 < K0 && gf.h_in != nullptr) {            // (K0 = 74 is even: 8-byte stores; null: forward only)
             float* hp = gf.h_in + row * K0 + f0;
             *reinterpret_cast<float2*>(hp) = make_float2(v[0], v[1]);
             if (f0 + 2 < K0) *reinterpret_cast<float2*>(hp + 2) = make_float2(v[2], v[3]);
@@ -571,7 +571,7 @@ mlp2_forward_kernel(Mlp2Dims d, const float* __restrict__ X, const float* __rest
       f32x16 h1[HBA], out[1];
       layer_forward<KQ0, KB0, HBA>(wa1, in0, h1, l31, h);
       relu_blocks<HBA>(h1);
-      store_blocks<HBA, 8 * HQA>(A1A, row, valid, d.HA, h, h1);
+      if (A1A) store_blocks<HBA, 8 * HQA>(A1A, row, valid, d.HA, h, h1);      // (null: forward only, nothing kept)
       layer_forward<HQA, HBA, 1>(wa2, h1, out, l31, h);
       store_block(YA, row, valid, d.OA, 0, h, out[0]);
     }
@@ -579,7 +579,7 @@ mlp2_forward_kernel(Mlp2Dims d, const float* __restrict__ X, const float* __rest
       f32x16 h1[HBB], out[1];
       layer_forward<KQ0, KB0, HBB>(wb1, in0, h1, l31, h);
       relu_blocks<HBB>(h1);
-      store_blocks<HBB, 8 * HQB>(A1B, row, valid, d.HB, h, h1);
+      if (A1B) store_blocks<HBB, 8 * HQB>(A1B, row, valid, d.HB, h, h1);
       layer_forward<HQB, HBB, 1>(wb2, h1, out, l31, h);
       store_block(YB, row, valid, d.OB, 0, h, out[0]);
     }
@@ -785,10 +785,10 @@ weight_grad_reduce_kernel(const float* __restrict__ partial, int nparts, int cou
   if (g == 0 && i < count) dW[i] = ((s_part[0][e] + s_part[1][e]) + s_part[2][e]) + s_part[3][e];
 }
 
-inline int wg_blocks(int N) {
-  static const int cap = [] { const char* e = getenv("INSTAG_WGRAD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
-  return std::max(1, std::min(cap, (N + 255) / 256));
-}
+// (256 workgroups per GEMM is the measured optimum, round 2: 128 -> +33 % per GEMM, 512 -> +5 %; round 3 in the step:
+// 128 / 64 workgroups -- to leave the personalised field's backward, which runs beside the GEMMs, more of the chip --
+// 0.907 / 0.925 ms per step against 0.908-0.915 with 256)
+inline int wg_blocks(int N) { return std::max(1, std::min(256, (N + 255) / 256)); }
 
 // Two workgroups per CU, each staging the weights once and walking a strided list of 32-row tiles.  (768 and 1024
 // workgroups -- one tile per wave at 100k rows -- measured the same or slower: sigma_net forward 44.9 / 44.6 / 47.8 us.)
@@ -968,7 +968,9 @@ int instag_mlp_forward_glue(const float* enc_x, const float* aud, const float* e
                             instag_stream_t stream) {
   const int K0 = GLUE_KX + GLUE_KA + GLUE_KE;
   INSTAG_REQUIRE(instag_mlp_backward_glue_supported(K0, H, O, GLUE_KX, GLUE_KA, GLUE_KE), "mlp_forward_glue: unsupported shape");
-  INSTAG_REQUIRE(enc_x && aud && eye_pre && enc_a && enc_e && w1 && w2 && w3 && y && h_in && amb, "mlp_forward_glue: NULL tensor");
+  INSTAG_REQUIRE(enc_x && aud && eye_pre && enc_a && enc_e && w1 && w2 && w3 && y && amb, "mlp_forward_glue: NULL tensor");
+  INSTAG_REQUIRE((h_in == nullptr) == (a1 == nullptr) && (a1 == nullptr) == (a2 == nullptr),
+                 "mlp_forward_glue: h_in, a1 and a2 go together (all NULL: forward only, nothing is kept for a backward)");
   if (N <= 0) return INSTAG_OK;
   const MlpDims d{N, K0, H, O};
   const GlueFwd gf{enc_x, aud, eye_pre, enc_a, enc_e, h_in, amb};
@@ -997,7 +999,8 @@ int instag_mlp2_forward(const float* x, const float* wa1, const float* wa2, cons
                         float* ya, float* yb, float* a1a, float* a1b, int32_t N, int32_t K0, int32_t HA, int32_t OA,
                         int32_t HB, int32_t OB, instag_stream_t stream) {
   INSTAG_REQUIRE(instag_mlp2_supported(K0, HA, OA, HB, OB), "mlp2_forward: unsupported shape pair");
-  INSTAG_REQUIRE(x && wa1 && wa2 && wb1 && wb2 && ya && yb && a1a && a1b, "mlp2_forward: NULL tensor");
+  INSTAG_REQUIRE(x && wa1 && wa2 && wb1 && wb2 && ya && yb, "mlp2_forward: NULL tensor");
+  INSTAG_REQUIRE((a1a == nullptr) == (a1b == nullptr), "mlp2_forward: a1a and a1b go together (both NULL: forward only)");
   if (N <= 0) return INSTAG_OK;
   const Mlp2Dims d{N, K0, HA, OA, HB, OB};
   hipStream_t s = (hipStream_t)stream;

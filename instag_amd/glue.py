@@ -62,12 +62,6 @@ class _MotionGlue(torch.autograd.Function):
         return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:], None
 
 
-# sigma_net's three weight-gradient GEMMs (60 % of the step's weight-gradient bytes) launched right behind its backward
-# kernel, beside the attention heads' and the encoder's backward, instead of later beside the personalised field's
-import os as _os
-EARLY_SIGMA_WEIGHT_GRADS = _os.environ.get("INSTAG_WGRAD_EARLY", "0") == "1"
-
-
 class _GlueSigma(torch.autograd.Function):
     """motion_glue followed by sigma_net (scene/motion_net.py:291-306) as ONE autograd node whose backward is one
     kernel: sigma_net's backward writes d_enc_x / d_aud / d_eye_pre from its accumulators and keeps the per-frame
@@ -88,11 +82,13 @@ class _GlueSigma(torch.autograd.Function):
         K0, H, O = KX + KA + KE, w1c.shape[0], w3c.shape[0]
         dev = enc_x.device
         stream = _lib.current_stream()
-        h_in = torch.empty(N, K0, dtype=torch.float32, device=dev)
+        # (forward only -- no input needs a gradient: inference, the mouth branch's jaw feature -- nothing is kept)
+        keep = any(ctx.needs_input_grad)
+        h_in = torch.empty(N, K0, dtype=torch.float32, device=dev) if keep else None
         amb = torch.empty(N, 3, dtype=torch.float32, device=dev)
         y = torch.empty(N, O, dtype=torch.float32, device=dev)
-        a1 = torch.empty(N, H, dtype=torch.float32, device=dev)
-        a2 = torch.empty(N, H, dtype=torch.float32, device=dev)
+        a1 = torch.empty(N, H, dtype=torch.float32, device=dev) if keep else None
+        a2 = torch.empty(N, H, dtype=torch.float32, device=dev) if keep else None
         check(L.instag_mlp_forward_glue(ptr(enc_x), ptr(aud), ptr(eye_pre), ptr(enc_a), ptr(enc_e), ptr(w1c), ptr(w2c),
                                         ptr(w3c), ptr(y), ptr(a1), ptr(a2), ptr(h_in), ptr(amb), N, H, O, stream),
               "mlp_forward_glue")
@@ -133,8 +129,6 @@ class _GlueSigma(torch.autograd.Function):
             for dz, inp, idx in jobs:
                 if ctx.needs_input_grad[5 + idx]:
                     deferred.defer_weight_grad(dz, inp, ctx.weights[idx])
-            if EARLY_SIGMA_WEIGHT_GRADS:
-                deferred.flush_async(dev)
         else:
             for dz, inp, idx in jobs:
                 if ctx.needs_input_grad[5 + idx]:

@@ -122,8 +122,9 @@ class _SharedInputMLPs(torch.autograd.Function):
             (HA, OA), (HB, OB) = (ws[0].shape[0], ws[1].shape[0]), (ws[2].shape[0], ws[3].shape[0])
             ya = torch.empty(N, OA, dtype=torch.float32, device=x.device)
             yb = torch.empty(N, OB, dtype=torch.float32, device=x.device)
-            a1a = torch.empty(N, HA, dtype=torch.float32, device=x.device)
-            a1b = torch.empty(N, HB, dtype=torch.float32, device=x.device)
+            keep = any(ctx.needs_input_grad)          # forward only (inference, the jaw feature): nothing is kept
+            a1a = torch.empty(N, HA, dtype=torch.float32, device=x.device) if keep else None
+            a1b = torch.empty(N, HB, dtype=torch.float32, device=x.device) if keep else None
             check(L.instag_mlp2_forward(ptr(x), ptr(ws[0]), ptr(ws[1]), ptr(ws[2]), ptr(ws[3]), ptr(ya), ptr(yb),
                                         ptr(a1a), ptr(a1b), N, K0, HA, OA, HB, OB, _lib.current_stream()),
                   "mlp2_forward")

@@ -215,7 +215,7 @@ class _TriPlaneField(nn.Module):
         if enc_x is None:
             enc_x = self.encode_x(x, bound=self.bound, shift=x_shift)
         aud_ch_att = eye_pre = None
-        if self.exp_eye and enc_x.is_cuda and enc_x.dim() == 2 and torch.is_grad_enabled() and enc_x.requires_grad:
+        if self.exp_eye and enc_x.is_cuda and enc_x.dim() == 2:
             from . import mlp as _mlp
             na, ne = self.aud_ch_att_net, self.eye_att_net
             if na.num_layers == 2 and ne.num_layers == 2 and \
@@ -250,8 +250,9 @@ class _TriPlaneField(nn.Module):
             from . import glue as _glue
             if _glue.motion_glue_supported(enc_x, aud_ch_att, eye_pre):
                 # repeat / mul / relu / cat / norm chain as one HIP kernel per pass (instag_amd/glue.py)
-                if torch.is_grad_enabled() and enc_x.requires_grad and \
-                        _glue.glue_sigma_supported(enc_x, aud_ch_att, eye_pre, self.sigma_net):
+                # (also without gradients -- inference, the mouth branch's jaw feature: the same two launches, and
+                # the forward-only form of the kernels keeps no activations)
+                if _glue.glue_sigma_supported(enc_x, aud_ch_att, eye_pre, self.sigma_net):
                     # glue + sigma_net as one autograd node: its backward is ONE kernel (instag_amd/glue.py:_GlueSigma)
                     h, amb = _glue.glue_sigma(enc_x, aud_ch_att, eye_pre, enc_a, enc_e, self.sigma_net,
                                               frame_stream=side if fork else None)

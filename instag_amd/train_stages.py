@@ -98,6 +98,15 @@ def _push_lrs(*optimizers):
             o.set_lrs()
 
 
+def _combine(*optimizers):
+    """One launch (and one learning-rate upload) for several fused optimizers -- the reference steps them back to back
+    (train_mouth.py:286-291, train_fuse_con.py:236-240); None when one of them is not the fused kind (CPU tests)."""
+    from .optim import CombinedAdam, MultiTensorAdam
+    if all(isinstance(o, MultiTensorAdam) for o in optimizers):
+        return CombinedAdam(list(optimizers))
+    return None
+
+
 class GraphedStage:
     """A stage trainer's whole step (forward, loss, backward, statistics, optimizers) captured once into a hipGraph
     and replayed: ``body(frame) -> (outputs..., keepalive)`` must be free of host round trips; the rasterizer runs in
@@ -221,6 +230,7 @@ class MouthTrainer:
         self.rng = random.Random(seed)                                       # k = randint(10, 50), train_mouth.py:175
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.motion_optimizer = _make_optimizers(gaussians, motion_net, opt, self.on_gpu)
+        self._combined = _combine(self.motion_optimizer, self.g.optimizer) if self.on_gpu else None
         self._base_lr = [float(g["lr"]) for g in self.motion_optimizer.param_groups]
         self._graph = None
         self._graph_key = None
@@ -232,7 +242,10 @@ class MouthTrainer:
         for grp, base in zip(self.motion_optimizer.param_groups, self._base_lr):
             grp["lr"] = base * f
         self.g.update_learning_rate(it)
-        _push_lrs(self.motion_optimizer, self.g.optimizer)
+        if self._combined is not None:
+            _push_lrs(self._combined)
+        else:
+            _push_lrs(self.motion_optimizer, self.g.optimizer)
 
     def _freeze_late(self):
         """train_mouth.py:189-196: after bg_iter the motion field and the Gaussians' geometry stop learning."""
@@ -303,6 +316,9 @@ class MouthTrainer:
             self.g.reset_opacity()
 
     def _step_optimizers(self):
+        if self._combined is not None:
+            self._combined.step()
+            return
         self.motion_optimizer.step()
         self.g.optimizer.step()
 
@@ -399,6 +415,7 @@ class FuseTrainer:
         self.iteration = 0
         gaussians.training_setup(opt, fused=self.on_gpu)
         gaussians_mouth.training_setup(opt, fused=self.on_gpu)
+        self._combined = _combine(gaussians.optimizer, gaussians_mouth.optimizer) if self.on_gpu else None
         for net in (motion_net, motion_net_mouth):
             for p in net.parameters():
                 p.requires_grad_(False)
@@ -421,13 +438,16 @@ class FuseTrainer:
 
     def _set_learning_rates(self, it):
         self.g.update_learning_rate(it)           # train_fuse_con.py:85 (the mouth model keeps its initial rates)
-        _push_lrs(self.g.optimizer)
+        _push_lrs(self._combined if self._combined is not None else self.g.optimizer)
 
     def _body(self, frame: Frame):
         out, loss, Ll1 = self.forward(frame)
         _backward(loss, self.device)
-        self.g.optimizer.step()
-        self.g_mouth.optimizer.step()
+        if self._combined is not None:
+            self._combined.step()
+        else:
+            self.g.optimizer.step()
+            self.g_mouth.optimizer.step()
         self.g.optimizer.zero_grad(set_to_none=True)
         self.g_mouth.optimizer.zero_grad(set_to_none=True)
         return loss, Ll1, out["image"], out
