@@ -529,6 +529,23 @@ int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* imag
                               const float* bg, const int32_t* lips_rect, const float* maps, const float* out,
                               const float* g_loss, const float* g_l1, float* d_image, float* d_alpha, float* d_attn,
                               instag_stream_t stream);
+/* The same pair with the scalar stage DEFERRED into the backward launch: the forward writes `maps` and `partials` only
+ * (one launch), the backward's first workgroup adds the partial sums up (the same additions in the same order as the
+ * forward's scalar stage: same bits) and writes out[5]; the other workgroups derive 1 / #hair pixels and 1 / lips area,
+ * the only scalars the gradients use, themselves.  For callers that run the backward right behind the forward and read
+ * the loss value afterwards (a train step): one launch less on the step's critical chain.  `extra` / `n_extra` as given
+ * to the forward. */
+int instag_face_loss_forward_deferred(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                                      const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                                      const float* bg, const float* alpha, const float* attn, const int32_t* lips_rect,
+                                      const float* extra, int32_t n_extra, float* maps, float* partials,
+                                      instag_stream_t stream);
+int instag_face_loss_backward_deferred(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                                       const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                                       const float* bg, const int32_t* lips_rect, const float* maps,
+                                       const float* partials, const float* extra, int32_t n_extra, float* out,
+                                       const float* g_loss, const float* g_l1, float* d_image, float* d_alpha,
+                                       float* d_attn, instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Monocular geometry priors of the face branch (csrc/prior.hip); replaces train_face.py:458-504 with

@@ -282,6 +282,8 @@ _PROTOS = {
     "instag_face_loss_num_partials": (C.c_int64, [i32, i32]),
     "instag_face_loss_forward": (C.c_int, [vp] * 11 + [i32] + [vp] * 4),
     "instag_face_loss_backward": (C.c_int, [vp] * 16),
+    "instag_face_loss_forward_deferred": (C.c_int, [vp] * 11 + [i32] + [vp] * 3),
+    "instag_face_loss_backward_deferred": (C.c_int, [vp] * 11 + [i32] + [vp] * 7),
     "instag_geometry_prior_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float,
                                                 vp, vp, vp, vp]),
     "instag_geometry_prior_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float,

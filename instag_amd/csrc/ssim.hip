@@ -292,13 +292,14 @@ face_loss_forward_kernel(FaceCfg cfg, FaceIn in, float* __restrict__ maps, float
 }
 
 // out[0] loss, out[1] L1, out[2] SSIM, out[3] 1 / max(#hair pixels, 1), out[4] 1 / lips-rect area (0 when empty)
-// eight waves, one per partial-sum array (fixed summation order inside a wave: lane-strided, then a butterfly)
-__global__ void __launch_bounds__(512)
-face_loss_finalize_kernel(FaceCfg cfg, const float* __restrict__ part, int tiles, const int32_t* __restrict__ lips,
-                          const float* __restrict__ extra, int n_extra, float* __restrict__ out) {
-  __shared__ float s_sum[9];
-  {
-    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// one wave per partial-sum array (fixed summation order inside a wave: lane-strided, then a butterfly); called by
+// `nwaves` waves of one workgroup (8: the finalize kernel; 4: the backward kernel's first workgroup, which takes the
+// arrays in two rounds) -- the same additions in the same order either way, so both produce the same bits
+__device__ __forceinline__ void face_loss_partial_sums(const float* __restrict__ part, int tiles,
+                                                       const float* __restrict__ extra, int n_extra, float* s_sum,
+                                                       int nwaves) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < 8; k += nwaves) {
     const float* p = k < 2 ? part + (size_t)k * 3 * tiles : part + (size_t)6 * tiles + (size_t)(k - 2) * tiles;
     const int n = k < 2 ? 3 * tiles : tiles;
     float acc = 0.f;
@@ -315,34 +316,77 @@ face_loss_finalize_kernel(FaceCfg cfg, const float* __restrict__ part, int tiles
       if (lane == 0) s_sum[8] = e;
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const float npix = (float)cfg.H * (float)cfg.W;
-    const float l1 = s_sum[1] / (3.f * npix), ssim = s_sum[0] / (3.f * npix);
-    float loss = l1 + cfg.w_dssim * (1.f - ssim);
-    if (cfg.flags & F_ALPHA) loss += cfg.w_alpha * (s_sum[2] / npix + s_sum[3] / npix);
-    const float inv_cnt = 1.f / fmaxf(s_sum[6], 1.f);
-    if (cfg.flags & F_HAIR_ATTN) loss += cfg.w_hair * (s_sum[4] * inv_cnt + s_sum[5] * inv_cnt);
-    float inv_area = 0.f;
-    if (cfg.flags & F_LIPS) {
-      const int r0 = max(lips[0], 0), r1 = min(lips[1], cfg.H), c0 = max(lips[2], 0), c1 = min(lips[3], cfg.W);
-      const float area = (float)max(r1 - r0, 0) * (float)max(c1 - c0, 0);
-      inv_area = area > 0.f ? 1.f / area : 0.f;
-      loss += cfg.w_lips * s_sum[7] * inv_area;
-    }
-    if (extra) loss += cfg.w_extra * s_sum[8];
-    out[0] = loss; out[1] = l1; out[2] = ssim; out[3] = inv_cnt; out[4] = inv_area;
-  }
 }
+
+__device__ __forceinline__ float lips_inv_area(const FaceCfg& cfg, const int32_t* __restrict__ lips) {
+  const int r0 = max(lips[0], 0), r1 = min(lips[1], cfg.H), c0 = max(lips[2], 0), c1 = min(lips[3], cfg.W);
+  const float area = (float)max(r1 - r0, 0) * (float)max(c1 - c0, 0);
+  return area > 0.f ? 1.f / area : 0.f;
+}
+
+__device__ __forceinline__ void face_loss_scalars(const FaceCfg& cfg, const float* s_sum, const int32_t* __restrict__ lips,
+                                                  bool has_extra, float* __restrict__ out) {
+  const float npix = (float)cfg.H * (float)cfg.W;
+  const float l1 = s_sum[1] / (3.f * npix), ssim = s_sum[0] / (3.f * npix);
+  float loss = l1 + cfg.w_dssim * (1.f - ssim);
+  if (cfg.flags & F_ALPHA) loss += cfg.w_alpha * (s_sum[2] / npix + s_sum[3] / npix);
+  const float inv_cnt = 1.f / fmaxf(s_sum[6], 1.f);
+  if (cfg.flags & F_HAIR_ATTN) loss += cfg.w_hair * (s_sum[4] * inv_cnt + s_sum[5] * inv_cnt);
+  float inv_area = 0.f;
+  if (cfg.flags & F_LIPS) {
+    inv_area = lips_inv_area(cfg, lips);
+    loss += cfg.w_lips * s_sum[7] * inv_area;
+  }
+  if (has_extra) loss += cfg.w_extra * s_sum[8];
+  out[0] = loss; out[1] = l1; out[2] = ssim; out[3] = inv_cnt; out[4] = inv_area;
+}
+
+__global__ void __launch_bounds__(512)
+face_loss_finalize_kernel(FaceCfg cfg, const float* __restrict__ part, int tiles, const int32_t* __restrict__ lips,
+                          const float* __restrict__ extra, int n_extra, float* __restrict__ out) {
+  __shared__ float s_sum[9];
+  face_loss_partial_sums(part, tiles, extra, n_extra, s_sum, 8);
+  __syncthreads();
+  if (threadIdx.x == 0) face_loss_scalars(cfg, s_sum, lips, extra != nullptr, out);
+}
+
+// The forward's scalar stage folded into the backward launch (instag_face_loss_*_deferred): the gradients never needed
+// the loss VALUE -- only 1 / #hair pixels and 1 / lips area, which every workgroup that uses them derives itself -- so
+// the one-workgroup kernel between the two tile kernels was 7 us of the step's critical chain for nothing.
+struct FaceFin {
+  const float* part; int tiles; const float* extra; int n_extra; float* out;
+};
 
 __global__ void __launch_bounds__(256)
 face_loss_backward_kernel(FaceCfg cfg, FaceIn in, const float* __restrict__ maps, const float* __restrict__ out,
                           const float* __restrict__ g_loss, const float* __restrict__ g_l1,
-                          float* __restrict__ d_image, float* __restrict__ d_alpha, float* __restrict__ d_attn) {
+                          float* __restrict__ d_image, float* __restrict__ d_alpha, float* __restrict__ d_attn,
+                          FaceFin fin) {
   __shared__ float s_m[3][HS][HS + 1];
   __shared__ float s_h[3][HS][TS + 1];
+  __shared__ float s_sum[9];
   const int H = cfg.H, W = cfg.W;
   const int c = blockIdx.z;
+  // deferred scalar stage (fin.part != null): 1 / #hair pixels for the channel-0 workgroups (the per-tile counts are
+  // small integers: any summation order gives the same float), everything for the first workgroup, which also writes
+  // the loss scalars the forward left out
+  float inv_cnt = 0.f;
+  if (fin.part != nullptr) {
+    const bool first = blockIdx.x == 0 && blockIdx.y == 0 && c == 0;
+    if (first) {
+      face_loss_partial_sums(fin.part, fin.tiles, fin.extra, fin.n_extra, s_sum, 4);
+      __syncthreads();
+      if (threadIdx.x == 0) face_loss_scalars(cfg, s_sum, in.lips, fin.extra != nullptr, fin.out);
+      inv_cnt = 1.f / fmaxf(s_sum[6], 1.f);
+    } else if (c == 0 && (cfg.flags & F_HAIR_ATTN)) {
+      const float* hp = fin.part + (size_t)6 * fin.tiles + (size_t)4 * fin.tiles;
+      float acc = 0.f;
+      for (int i = threadIdx.x; i < fin.tiles; i += 256) acc += hp[i];
+      acc = block_sum_256(acc, s_sum);
+      inv_cnt = 1.f / fmaxf(acc, 1.f);
+    }
+    __syncthreads();
+  }
   const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
   const size_t plane = (size_t)H * W;
   const size_t C3 = 3 * plane;
@@ -394,10 +438,11 @@ face_loss_backward_kernel(FaceCfg cfg, FaceIn in, const float* __restrict__ maps
     const bool head = plain ? false : (mouth_mode ? in_lips(in, gy, gx) : (hair || in.face[pix] != 0));
     if (d_alpha) d_alpha[pix] = (cfg.flags & F_ALPHA) ? g * cfg.w_alpha / (float)plane * (head ? -1.f : 1.f) : 0.f;
     if (d_attn) {
-      const float gh = ((cfg.flags & F_HAIR_ATTN) && hair) ? g * cfg.w_hair * out[3] : 0.f;
+      const float gh = ((cfg.flags & F_HAIR_ATTN) && hair) ? g * cfg.w_hair * (fin.part ? inv_cnt : out[3]) : 0.f;
       float gp = 0.f;
       if (cfg.flags & F_LIPS)
-        if (gy >= in.lips[0] && gy < in.lips[1] && gx >= in.lips[2] && gx < in.lips[3]) gp = g * cfg.w_lips * out[4];
+        if (gy >= in.lips[0] && gy < in.lips[1] && gx >= in.lips[2] && gx < in.lips[3])
+          gp = g * cfg.w_lips * (fin.part ? lips_inv_area(cfg, in.lips) : out[4]);
       d_attn[pix] = gh;
       d_attn[plane + pix] = gh + gp;
       d_attn[2 * plane + pix] = 0.f;
@@ -450,11 +495,11 @@ int64_t instag_face_loss_num_partials(int32_t H, int32_t W) {
   return (int64_t)12 * ((H + TS - 1) / TS) * ((W + TS - 1) / TS);
 }
 
-int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
-                             const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
-                             const float* bg, const float* alpha, const float* attn, const int32_t* lips_rect,
-                             const float* extra, int32_t n_extra, float* maps, float* partials, float* out,
-                             instag_stream_t stream) {
+static int face_loss_forward_impl(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                                  const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                                  const float* bg, const float* alpha, const float* attn, const int32_t* lips_rect,
+                                  const float* extra, int32_t n_extra, float* maps, float* partials, float* out,
+                                  bool finalize, instag_stream_t stream) {
   FaceCfg c;
   if (int rc = face_cfg(cfg, &c)) return rc;
   const bool mouth_mode = (c.flags & F_MOUTH) != 0;
@@ -475,17 +520,38 @@ int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image
     face_loss_forward_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(c, in, maps, partials);
     INSTAG_CHECK_LAUNCH();
   }
+  if (!finalize) return INSTAG_OK;
   face_loss_finalize_kernel<<<1, 512, 0, (hipStream_t)stream>>>(c, partials, (int)(grid.x * grid.y), lips_rect, extra,
                                                               extra ? n_extra : 0, out);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
 }
 
-int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
-                              const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
-                              const float* bg, const int32_t* lips_rect, const float* maps, const float* out,
-                              const float* g_loss, const float* g_l1, float* d_image, float* d_alpha, float* d_attn,
-                              instag_stream_t stream) {
+int instag_face_loss_forward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                             const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                             const float* bg, const float* alpha, const float* attn, const int32_t* lips_rect,
+                             const float* extra, int32_t n_extra, float* maps, float* partials, float* out,
+                             instag_stream_t stream) {
+  return face_loss_forward_impl(cfg, image, gt, face_mask, hair_mask, mouth_mask, bg, alpha, attn, lips_rect, extra,
+                                n_extra, maps, partials, out, /*finalize=*/true, stream);
+}
+
+int instag_face_loss_forward_deferred(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                                      const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                                      const float* bg, const float* alpha, const float* attn, const int32_t* lips_rect,
+                                      const float* extra, int32_t n_extra, float* maps, float* partials,
+                                      instag_stream_t stream) {
+  INSTAG_REQUIRE(partials != nullptr, "face_loss_forward_deferred: NULL partials");
+  float dummy = 0.f;       // (`out` is written by instag_face_loss_backward_deferred; the forward only checks it for NULL)
+  return face_loss_forward_impl(cfg, image, gt, face_mask, hair_mask, mouth_mask, bg, alpha, attn, lips_rect, extra,
+                                n_extra, maps, partials, &dummy, /*finalize=*/false, stream);
+}
+
+static int face_loss_backward_impl(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                                   const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                                   const float* bg, const int32_t* lips_rect, const float* maps, const float* out,
+                                   const float* g_loss, const float* g_l1, float* d_image, float* d_alpha, float* d_attn,
+                                   const FaceFin& fin, instag_stream_t stream) {
   FaceCfg c;
   if (int rc = face_cfg(cfg, &c)) return rc;
   const bool mouth_mode = (c.flags & F_MOUTH) != 0;
@@ -496,11 +562,35 @@ int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* imag
   INSTAG_REQUIRE(!(c.flags & F_LIPS) || lips_rect, "face_loss_backward: lips term without lips_rect");
   const FaceIn in{image, gt, face_mask, hair_mask, mouth_mask, bg, nullptr, nullptr, lips_rect, nullptr};
   dim3 grid((c.W + TS - 1) / TS, (c.H + TS - 1) / TS, 3);
+  FaceFin f = fin;
+  f.tiles = (int)(grid.x * grid.y);
   ProfScope p(K_LOSS_BWD, (hipStream_t)stream);
   face_loss_backward_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(c, in, maps, out, g_loss, g_l1, d_image, d_alpha,
-                                                                   d_attn);
+                                                                   d_attn, f);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
+}
+
+int instag_face_loss_backward(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                              const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                              const float* bg, const int32_t* lips_rect, const float* maps, const float* out,
+                              const float* g_loss, const float* g_l1, float* d_image, float* d_alpha, float* d_attn,
+                              instag_stream_t stream) {
+  return face_loss_backward_impl(cfg, image, gt, face_mask, hair_mask, mouth_mask, bg, lips_rect, maps, out, g_loss,
+                                 g_l1, d_image, d_alpha, d_attn, FaceFin{nullptr, 0, nullptr, 0, nullptr}, stream);
+}
+
+int instag_face_loss_backward_deferred(const instag_face_loss_cfg* cfg, const float* image, const float* gt,
+                                       const uint8_t* face_mask, const uint8_t* hair_mask, const uint8_t* mouth_mask,
+                                       const float* bg, const int32_t* lips_rect, const float* maps,
+                                       const float* partials, const float* extra, int32_t n_extra, float* out,
+                                       const float* g_loss, const float* g_l1, float* d_image, float* d_alpha,
+                                       float* d_attn, instag_stream_t stream) {
+  INSTAG_REQUIRE(partials && out, "face_loss_backward_deferred: NULL partials / out");
+  INSTAG_REQUIRE(extra == nullptr || n_extra >= 1, "face_loss_backward_deferred: n_extra must be >= 1");
+  return face_loss_backward_impl(cfg, image, gt, face_mask, hair_mask, mouth_mask, bg, lips_rect, maps, out, g_loss,
+                                 g_l1, d_image, d_alpha, d_attn,
+                                 FaceFin{partials, 0, extra, extra ? n_extra : 0, out}, stream);
 }
 
 }  // extern "C"

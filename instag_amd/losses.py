@@ -210,6 +210,24 @@ def face_loss_torch(image, gt, face_mask, hair_mask, mouth_mask, bg, alpha=None,
     return loss, Ll1
 
 
+# A caller that runs backward right behind the loss and reads the loss VALUE only afterwards (the train steps) sets this
+# around its loss call: the forward then launches the tile kernel only, and the backward launch also produces the
+# scalars (csrc/ssim.hip, instag_face_loss_*_deferred) -- one launch less on the step's critical chain.  The returned
+# loss / L1 tensors hold their values once backward has run.
+DEFER_FINALIZE = False
+
+
+class defer_finalize:
+    def __enter__(self):
+        global DEFER_FINALIZE
+        self.prev, DEFER_FINALIZE = DEFER_FINALIZE, True
+
+    def __exit__(self, *exc):
+        global DEFER_FINALIZE
+        DEFER_FINALIZE = self.prev
+        return False
+
+
 class _FusedFaceLoss(torch.autograd.Function):
     """(loss, Ll1) of the face branch in two launches forward, one backward (csrc/ssim.hip)."""
 
@@ -237,14 +255,24 @@ class _FusedFaceLoss(torch.autograd.Function):
         maps = torch.empty(3, 3, H, W, dtype=torch.float32, device=dev)
         parts = torch.empty(L.instag_face_loss_num_partials(H, W), dtype=torch.float32, device=dev)
         out = torch.empty(5, dtype=torch.float32, device=dev)
-        check(L.instag_face_loss_forward(C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask), ptr(hair_mask),
-                                         ptr(mouth_mask), ptr(bg), ptr(alpha), ptr(attn), ptr(lips_rect), ptr(extra),
-                                         0 if extra is None else extra.numel(), ptr(maps), ptr(parts), ptr(out),
-                                         _lib.current_stream()), "face_loss_forward")
+        ctx.deferred = bool(DEFER_FINALIZE and any(ctx.needs_input_grad))
+        if ctx.deferred:
+            check(L.instag_face_loss_forward_deferred(C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask),
+                                                      ptr(hair_mask), ptr(mouth_mask), ptr(bg), ptr(alpha), ptr(attn),
+                                                      ptr(lips_rect), ptr(extra), 0 if extra is None else extra.numel(),
+                                                      ptr(maps), ptr(parts), _lib.current_stream()),
+                  "face_loss_forward")
+        else:
+            check(L.instag_face_loss_forward(C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask), ptr(hair_mask),
+                                             ptr(mouth_mask), ptr(bg), ptr(alpha), ptr(attn), ptr(lips_rect), ptr(extra),
+                                             0 if extra is None else extra.numel(), ptr(maps), ptr(parts), ptr(out),
+                                             _lib.current_stream()), "face_loss_forward")
         ctx.cfg = cfg
         ctx.shapes = (alpha is not None, attn is not None, None if extra is None else extra_shape)
+        ctx.has_lips = lips_rect is not None
         ctx.save_for_backward(image, gt, face_mask, hair_mask, mouth_mask, bg, maps, out,
-                              *([lips_rect] if lips_rect is not None else []))
+                              *([lips_rect] if lips_rect is not None else []),
+                              *([parts, extra] if ctx.deferred else []))
         return out[0], out[1]
 
     @staticmethod
@@ -254,7 +282,8 @@ class _FusedFaceLoss(torch.autograd.Function):
         from ._lib import check, ptr
         saved = ctx.saved_tensors
         image, gt, face_mask, hair_mask, mouth_mask, bg, maps, out = saved[:8]
-        lips_rect = saved[8] if len(saved) > 8 else None
+        lips_rect = saved[8] if ctx.has_lips else None
+        parts, extra = (saved[-2], saved[-1]) if ctx.deferred else (None, None)
         has_alpha, has_attn, has_extra = ctx.shapes
         cfg = ctx.cfg
         _, H, W = image.shape
@@ -263,10 +292,18 @@ class _FusedFaceLoss(torch.autograd.Function):
         d_image = torch.empty_like(image)
         d_alpha = torch.empty(1, H, W, dtype=torch.float32, device=image.device) if has_alpha else None
         d_attn = torch.empty(3, H, W, dtype=torch.float32, device=image.device) if has_attn else None
-        check(_lib.lib().instag_face_loss_backward(C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask), ptr(hair_mask),
-                                                   ptr(mouth_mask), ptr(bg), ptr(lips_rect), ptr(maps), ptr(out),
-                                                   ptr(g_loss), ptr(g_l1), ptr(d_image), ptr(d_alpha), ptr(d_attn),
-                                                   _lib.current_stream()), "face_loss_backward")
+        if ctx.deferred:
+            check(_lib.lib().instag_face_loss_backward_deferred(
+                C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask), ptr(hair_mask), ptr(mouth_mask), ptr(bg),
+                ptr(lips_rect), ptr(maps), ptr(parts), ptr(extra), 0 if extra is None else extra.numel(), ptr(out),
+                ptr(g_loss), ptr(g_l1), ptr(d_image), ptr(d_alpha), ptr(d_attn), _lib.current_stream()),
+                "face_loss_backward")
+        else:
+            check(_lib.lib().instag_face_loss_backward(C.byref(cfg), ptr(image), ptr(gt), ptr(face_mask),
+                                                       ptr(hair_mask), ptr(mouth_mask), ptr(bg), ptr(lips_rect),
+                                                       ptr(maps), ptr(out), ptr(g_loss), ptr(g_l1), ptr(d_image),
+                                                       ptr(d_alpha), ptr(d_attn), _lib.current_stream()),
+                  "face_loss_backward")
         d_extra = None
         if has_extra is not None and g_loss is not None:
             # d loss / d extra[i] = w_extra * g for every element (extra enters as a sum); w_extra == 1 needs no launch

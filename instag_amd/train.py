@@ -388,8 +388,13 @@ class FaceTrainer:
         from .renderer import render_motion
         pkg = render_motion(frame, self.g, self.motion_net, None, self.bg, return_attn=True, personalized=False,
                             align=phase.align, motion_reg_weight=1e-5 if phase.warm else None)
-        loss, Ll1 = self.loss_fn(frame, pkg, warm=phase.warm, hair_mask_iter=phase.hair_mask_iter,
-                                 priors=phase.priors, prior_depth=phase.prior_depth)
+        from contextlib import nullcontext
+        from .losses import defer_finalize
+        # (backward follows at once and the loss value is read after the step: the loss block's scalar stage rides in
+        # its backward launch -- unless the prior terms are ADDED to the value here, which needs it now)
+        with (nullcontext() if phase.priors else defer_finalize()):
+            loss, Ll1 = self.loss_fn(frame, pkg, warm=phase.warm, hair_mask_iter=phase.hair_mask_iter,
+                                     priors=phase.priors, prior_depth=phase.prior_depth)
         from .deferred import deferred_grads
         from . import diff_gauss
         # fold_aux (only callers that run _stats_and_optimizers(pkg) next): the auxiliary image's share of the screen-space
@@ -434,8 +439,13 @@ class FaceTrainer:
                                 align=phase.align, motion_reg_weight=1e-5 if phase.warm else None)
         finally:
             renderer.MARK_BACKWARD_CUT = False
-        loss, Ll1 = self.loss_fn(frame, pkg, warm=phase.warm, hair_mask_iter=phase.hair_mask_iter,
-                                 priors=phase.priors, prior_depth=phase.prior_depth)
+        from contextlib import nullcontext
+        from .losses import defer_finalize
+        # (backward follows at once and the loss value is read after the step: the loss block's scalar stage rides in
+        # its backward launch -- unless the prior terms are ADDED to the value here, which needs it now)
+        with (nullcontext() if phase.priors else defer_finalize()):
+            loss, Ll1 = self.loss_fn(frame, pkg, warm=phase.warm, hair_mask_iter=phase.hair_mask_iter,
+                                     priors=phase.priors, prior_depth=phase.prior_depth)
         cut = dict.get(pkg, "_cut")
         if not cut:
             raise RuntimeError("the three-segment step needs render_motion's fused path (align=True on the GPU)")

@@ -329,7 +329,9 @@ class MouthTrainer:
     def _body(self, frame: Frame, phase: MouthPhase, k, stats_on: bool):
         """Everything of an iteration without a density-control event; free of host round trips when `k` is a
         device tensor (the captured form)."""
-        pkg, loss, Ll1 = self.forward(frame, phase, k)
+        from .losses import defer_finalize
+        with defer_finalize():          # (backward follows at once; the loss value is read after the step)
+            pkg, loss, Ll1 = self.forward(frame, phase, k)
         _backward(loss, self.device)
         if stats_on:
             self._accumulate_stats(pkg)
@@ -441,7 +443,9 @@ class FuseTrainer:
         _push_lrs(self._combined if self._combined is not None else self.g.optimizer)
 
     def _body(self, frame: Frame):
-        out, loss, Ll1 = self.forward(frame)
+        from .losses import defer_finalize
+        with defer_finalize():          # (backward follows at once; the loss value is read after the step)
+            out, loss, Ll1 = self.forward(frame)
         _backward(loss, self.device)
         if self._combined is not None:
             self._combined.step()

@@ -195,6 +195,24 @@ def test_face_loss_matches_torch(hair_mask_iter, size):
     if hair_mask_iter:
         assert float(g_h[0][:, hair.cuda()].abs().max()) == 0.0
 
+    # the scalar stage deferred into the backward launch (what the train steps use): the same bits -- values once
+    # backward has run, gradients always
+    from instag_amd.losses import defer_finalize
+
+    def deferred(*a, **kw):
+        with defer_finalize():
+            return face_loss(*a, **kw)
+    loss_d, l1_d, g_d = run(deferred, "cuda", torch.float32)
+    assert float(loss_d) == float(loss_h) and float(l1_d) == float(l1_h)
+    for a, b in zip(g_d, g_h):
+        assert torch.equal(a, b)
+    # without a gradient to compute nothing is deferred: the value is there at once
+    with torch.no_grad(), defer_finalize():
+        loss_n, l1_n = face_loss(image.cuda(), gt.cuda(), face.cuda(), hair.cuda(), mouth.cuda(), bg.cuda(),
+                                 alpha=alpha.cuda(), attn=attn.cuda(), lips_rect=lips.cuda(), extra=extra.cuda(),
+                                 hair_mask_iter=hair_mask_iter)
+    assert float(loss_n) == float(loss_h) and float(l1_n) == float(l1_h)
+
 
 def test_densify_stats_matches_torch():
     from instag_amd.glue import densify_stats
