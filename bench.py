@@ -33,8 +33,8 @@ if ROOT not in sys.path:
 
 KERNEL_IDS = {"preprocess": 0, "duplicate": 1, "sort": 2, "ranges": 3, "blend_fwd": 4, "blend_bwd": 5,
               "preprocess_bwd": 6, "grid_fwd": 7, "grid_bwd": 8, "mlp_fwd": 11, "mlp_bwd": 12, "mlp_wgrad": 13,
-              "blend_bwd_mean": 16}
-NON_RASTER = ("grid_fwd", "grid_bwd", "mlp_fwd", "mlp_bwd", "mlp_wgrad")
+              "blend_bwd_mean": 16, "empty_bracket": 17}
+NON_RASTER = ("grid_fwd", "grid_bwd", "mlp_fwd", "mlp_bwd", "mlp_wgrad", "empty_bracket")
 # the blend launches of the C3 step, each a kernel of its own (template variant) with its own byte count:
 #   blend_fwd       image + attention map, all channels                     60 R + 44 P   
 #   blend_bwd       colour pass, aux colours' gradient in idle GEMM columns  124 R + 44 P  
@@ -562,11 +562,14 @@ def main():
         # (SURVEY 8d's per-instance / per-pixel figures x the measured R, P) / its own average launch duration.  Next to
         # it: the bytes of the list entries the launch really walks (entries in front of each tile's last contributor)
         # and the HBM bytes the PMC passes counted for that variant.  `roofline` is the variant furthest below the bound.
+        # A bracket (event record -> kernel -> event record) also times the dispatch latency behind the first record and
+        # the completion signal in front of the second: measured by an EMPTY bracket in the same graph and taken off.
+        bracket_us = kern["empty_bracket"]["avg_us"] if "empty_bracket" in kern else 0.0
         blend = {}
         for k, (variant, per_r, per_p) in BLEND_VARIANTS.items():
             if k not in kern:
                 continue
-            dur = kern[k]["avg_us"] * 1e-6
+            dur = max(kern[k]["avg_us"] - bracket_us, 1e-3) * 1e-6
             ab = per_r * R + per_p * P
             walked = ent["bwd" if k != "blend_fwd" else "fwd_min"] if ent else None
             traffic, traffic_src = pmc_traffic(k, N, size)
@@ -578,7 +581,8 @@ def main():
                         "walked_entries": walked,
                         "walked_bytes": None if walked is None else per_r * walked + per_p * P,
                         "achieved_walked": None if walked is None else round((per_r * walked + per_p * P) / dur / 1e9, 2),
-                        "avg_launch_us": round(kern[k]["avg_us"], 2), "launches": kern[k]["launches"],
+                        "avg_launch_us": round(dur * 1e6, 2), "avg_bracket_us": round(kern[k]["avg_us"], 2),
+                        "empty_bracket_us": round(bracket_us, 2), "launches": kern[k]["launches"],
                         "num_rendered": R, "durations_from": main_run["durations_from"]}
         roofline = min(blend.values(), key=lambda r: r["frac"]) if blend else None
         dom = roofline["kernel"] if roofline else None
@@ -604,13 +608,13 @@ def main():
         valu = {}
         if ent and "blend_bwd" in kern:
             valu["blend_bwd"] = roofline_valu("blend_bwd", [(BLEND_VARIANTS["blend_bwd"][0], 2)], ent["bwd"],
-                                              kern["blend_bwd"]["avg_us"], 1)
+                                              blend["blend_bwd"]["avg_launch_us"], 1)
         if ent and "blend_bwd_mean" in kern:
             valu["blend_bwd_mean"] = roofline_valu("blend_bwd_mean", [(BLEND_VARIANTS["blend_bwd_mean"][0], 1)],
-                                                   ent["bwd"], kern["blend_bwd_mean"]["avg_us"], 1)
+                                                   ent["bwd"], blend["blend_bwd_mean"]["avg_launch_us"], 1)
         if ent and "blend_fwd" in kern:
             valu["blend_fwd"] = roofline_valu("blend_fwd", [(BLEND_VARIANTS["blend_fwd"][0], 0)], ent["fwd_min"],
-                                              kern["blend_fwd"]["avg_us"], 1)
+                                              blend["blend_fwd"]["avg_launch_us"], 1)
             if valu["blend_fwd"]:
                 valu["blend_fwd"]["pairs_are"] = "a lower bound (entries up to the tile's last contributor)"
         value = world * args.steps / med

@@ -597,7 +597,9 @@ int instag_adam_step(const void* tensors, int32_t n_tensors, const void* groups,
  * Kernel ids: 0 preprocess, 1 duplicate, 2 sort, 3 ranges, 4 blend_fwd, 5 blend_bwd,
  *             6 preprocess_bwd, 7 grid_fwd, 8 grid_bwd, 9 sh_fwd, 10 sh_bwd,
  *             11 mlp_fwd, 12 mlp_bwd, 13 mlp_weight_grad, 14 loss_fwd, 15 loss_bwd,
- *             16 blend_bwd mean-only launch (the auxiliary image's d/dmean pass; 5 = every other blend_bwd launch).
+ *             16 blend_bwd mean-only launch (the auxiliary image's d/dmean pass; 5 = every other blend_bwd launch),
+ *             17 an EMPTY bracket (recorded in front of every blend_fwd launch): the time between two event records with
+ *                nothing between them, i.e. what the bracket adds to every kernel's figure.
  *
  * Inside a hipGraph: a launch issued while its stream is being CAPTURED is bracketed with EXTERNAL event-record nodes
  * (hipEventRecordWithFlags(hipEventRecordExternal)) taken from a pool the caller sized with instag_prof_graph_begin --
@@ -606,7 +608,7 @@ int instag_adam_step(const void* tensors, int32_t n_tensors, const void* groups,
  * totals, so the durations are those of the kernels as they run in the replayed graph, next to their concurrent
  * branches.  instag_prof_graph_end destroys the pool (the graphs that captured its events must be gone by then).
  * ------------------------------------------------------------------------------------------ */
-#define INSTAG_PROF_KERNELS 17
+#define INSTAG_PROF_KERNELS 18
 int instag_prof_enable(int kernel_mask_or_minus1);
 int instag_prof_reset(void);
 int instag_prof_read(int kernel_id, double* total_ms /* (host) */, int64_t* launches /* (host) */);

@@ -39,6 +39,7 @@ enum ProfKernel {
   K_PREPROCESS = 0, K_DUPLICATE = 1, K_SORT = 2, K_RANGES = 3, K_BLEND_FWD = 4, K_BLEND_BWD = 5,
   K_PREPROCESS_BWD = 6, K_GRID_FWD = 7, K_GRID_BWD = 8, K_SH_FWD = 9, K_SH_BWD = 10,
   K_MLP_FWD = 11, K_MLP_BWD = 12, K_MLP_WGRAD = 13, K_LOSS_FWD = 14, K_LOSS_BWD = 15, K_BLEND_BWD_MEAN = 16,
+  K_EMPTY_BRACKET = 17,      // two event records with nothing between them: what a bracket itself costs
 };
 struct ProfScope {
   ProfScope(int kernel, hipStream_t stream);

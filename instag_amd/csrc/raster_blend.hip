@@ -589,6 +589,7 @@ int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t*
                          float* seg_state, uint32_t* tile_rounds, hipStream_t s) {
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
+  { ProfScope calibration(K_EMPTY_BRACKET, s); }
   ProfScope p(K_BLEND_FWD, s);
   if (aux_colors)
     blend_forward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,

@@ -12,17 +12,20 @@ SUM=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT" "$SUM"
 cd /tmp && export TMPDIR=/tmp
 
-# 1. kernel trace + stats of the default bench command
+# 1. kernel trace + stats of the HEADLINE workload alone (the default command's other workloads -- host-fed frames,
+#    schedule runs with other Gaussian counts -- would mix their launches into the per-kernel averages): the JSON line of
+#    this very run is kept next to the stats, so that roofline.avg_launch_us can be set against the CSV's AverageNs
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o run --output-format csv -- python3 "$ROOT/bench.py" \
-    > "$OUT/trace.log" 2>&1 || exit 1
+    --no-host-frames --no-schedule --no-stable-targets --no-cpu-baseline > "$OUT/trace.log" 2>&1 || exit 1
 grep '^{"metric"' "$OUT/trace.log" > "$SUM/${TAG}_bench_c3_under_rocprof.json"
 cp "$OUT/trace/run_kernel_stats.csv" "$SUM/${TAG}_bench_c3_kernel_stats.csv"
 python3 "$ROOT/scripts/category_summary.py" "$OUT/trace" > "$SUM/${TAG}_bench_c3_category_summary.txt" || exit 1
+python3 "$ROOT/scripts/median_timeline.py" "$OUT/trace" > "$SUM/${TAG}_timeline_median_step.txt" || exit 1
 echo "[profile] trace done"
 
 # 2. HBM traffic: two TCC passes
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o run --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 \
+  rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o run --output-format csv -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-host-frames --no-schedule \
       --no-cpu-baseline --no-stable-targets > "$OUT/pmc_$C.log" 2>&1 || exit 1
 done
 python3 "$ROOT/scripts/pmc_summary.py" "$OUT/pmc_FETCH_SIZE/run_counter_collection.csv" \
@@ -32,7 +35,7 @@ echo "[profile] hbm passes done"
 # 3. what the resident waves do: SQ pass (8 slots)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
     SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES -d "$OUT/pmc_sq" -o run --output-format csv -- python3 "$ROOT/bench.py" \
-    --steps 5 --warmup 2 --no-cpu-baseline --no-stable-targets > "$OUT/pmc_sq.log" 2>&1 || exit 1
+    --steps 5 --warmup 2 --no-cpu-baseline --no-stable-targets --no-host-frames --no-schedule > "$OUT/pmc_sq.log" 2>&1 || exit 1
 python3 "$ROOT/scripts/pmc_sq_summary.py" "$OUT/pmc_sq/run_counter_collection.csv" \
     "$SUM/${TAG}_pmc_sq_c3.csv" || exit 1
 echo "[profile] sq pass done"
@@ -41,7 +44,7 @@ echo "[profile] sq pass done"
 #    this summary)
 if rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM \
     SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES -d "$OUT/pmc_lds" -o run --output-format csv -- python3 "$ROOT/bench.py" \
-    --steps 5 --warmup 2 --no-cpu-baseline --no-stable-targets > "$OUT/pmc_lds.log" 2>&1; then
+    --steps 5 --warmup 2 --no-cpu-baseline --no-stable-targets --no-host-frames --no-schedule > "$OUT/pmc_lds.log" 2>&1; then
   python3 "$ROOT/scripts/pmc_sq_summary.py" "$OUT/pmc_lds/run_counter_collection.csv" "$SUM/${TAG}_pmc_lds_c3.csv"
   echo "[profile] lds pass done"
 else
