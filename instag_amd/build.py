@@ -72,6 +72,8 @@ def _headers():
 
 
 def _compile(cc, name, flags, force):
+    # (experiments: INSTAG_EXTRA_FLAGS_<stem>="-DFOO=1 ..." adds flags to one source, e.g. INSTAG_EXTRA_FLAGS_mlp)
+    flags = flags + os.environ.get("INSTAG_EXTRA_FLAGS_" + name.split(".")[0], "").split()
     src = os.path.join(CSRC, name)
     obj = os.path.join(OBJDIR, name.replace(".hip", ".o"))
     stamp = obj + ".sha"

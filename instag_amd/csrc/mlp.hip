@@ -652,68 +652,97 @@ mlp2_backward_kernel(Mlp2Dims d, const float* __restrict__ dYA, const float* __r
 }
 
 // ---- dW[o][k] = sum_rows dZ[row][o] * In[row][k] ---------------------------------------------------
+// A workgroup owns a contiguous range of rows and produces one partial [O][K] matrix.  Round 3: the OB x KB output
+// tiles (32 x 32 each) are DEALT OUT to the four waves instead of every wave holding all of them over a quarter of the
+// rows: a wave keeps at most two accumulator tiles (32 AGPRs instead of up to 96) and fetches only the operand columns
+// of its tiles, so the kernel needs 120 registers instead of 231 (4 waves per SIMD instead of 2) and 12 KB of LDS instead
+// of 24, and jobs of four or more tiles need no cross-wave combine at all.  (It did not make the launch faster -- see the
+// A/B at weight_grad_batched_kernel -- but it takes half the register file and LDS from the kernels it runs beside.)  The waves of a workgroup read the same rows at the same time, so the
+// operand columns two of them share come from L1.  Jobs of fewer than four tiles split the workgroup's rows between
+// wave groups as before and combine through LDS in a fixed order (bitwise reproducible either way).
 template <int OB, int KB>
 __device__ __forceinline__ void weight_grad_body(const float* __restrict__ dZ, const float* __restrict__ In, int N, int O,
                                                  int K, float* __restrict__ partial, float* s_acc, int block,
                                                  int nblocks) {
+  constexpr int TILES = OB * KB;
+  constexpr int TW = TILES >= 4 ? 4 : TILES;           // waves holding distinct tile sets
+  constexpr int RS = 4 / TW;                           // row splits inside the workgroup (3 tiles: one wave idles)
+  constexpr int MYT = (TILES + TW - 1) / TW;           // tiles per wave at most: 6 -> 2, else 1
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
-  const int nwaves = nblocks * 4;
-  const int per_wave = (((N + nwaves - 1) / nwaves) + 1) & ~1;       // even number of rows per wave
-  const int gw = block * 4 + wave;
-  const long w0 = (long)gw * per_wave;
-  const long w1 = min((long)N, w0 + per_wave);
-  f32x16 acc[OB][KB];
+  const int tw = wave % TW, rs = wave / TW;
+  const bool busy = wave < TW * RS;
+  // rows of this workgroup, then of this wave's row split (even counts: a k-step is a row pair)
+  const int per_block = (((N + nblocks - 1) / nblocks) + 1) & ~1;
+  const long b0 = (long)block * per_block, b1 = min((long)N, b0 + per_block);
+  const int per_split = ((((int)max(0l, b1 - b0) + RS - 1) / RS) + 1) & ~1;
+  const long w0 = b0 + (long)rs * per_split;
+  const long w1 = busy ? min(b1, w0 + per_split) : w0;
+  int tt[MYT], tb[MYT];
+  bool live[MYT], oin[MYT], kin[MYT];
 #pragma unroll
-  for (int t = 0; t < OB; ++t)
+  for (int j = 0; j < MYT; ++j) {
+    const int idx = tw + j * TW;
+    live[j] = idx < TILES;
+    tt[j] = live[j] ? idx / KB : 0;
+    tb[j] = live[j] ? idx % KB : 0;
+    oin[j] = live[j] && 32 * tt[j] + l31 < O;
+    kin[j] = live[j] && 32 * tb[j] + l31 < K;
+  }
+  f32x16 acc[MYT];
 #pragma unroll
-    for (int b = 0; b < KB; ++b)
+  for (int j = 0; j < MYT; ++j)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][b][i] = 0.f;
-  bool oin[OB], kin[KB];
-#pragma unroll
-  for (int t = 0; t < OB; ++t) oin[t] = 32 * t + l31 < O;
-#pragma unroll
-  for (int b = 0; b < KB; ++b) kin[b] = 32 * b + l31 < K;
-  constexpr int UNROLL = 8;
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+#ifndef INSTAG_WG_UNROLL
+#define INSTAG_WG_UNROLL 6
+#endif
+  constexpr int UNROLL = INSTAG_WG_UNROLL;             // 2 * UNROLL rows of both operands in flight per wave
   for (long r0 = w0; r0 < w1; r0 += 2 * UNROLL) {
-    float a[UNROLL][OB], bb[UNROLL][KB];
+    float a[UNROLL][MYT], bb[UNROLL][MYT];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const long row = r0 + 2 * u + h;
       const bool ok = row < w1;
 #pragma unroll
-      for (int t = 0; t < OB; ++t) a[u][t] = (ok && oin[t]) ? dZ[row * O + 32 * t + l31] : 0.f;
-#pragma unroll
-      for (int b = 0; b < KB; ++b) bb[u][b] = (ok && kin[b]) ? In[row * K + 32 * b + l31] : 0.f;
+      for (int j = 0; j < MYT; ++j) {
+        a[u][j] = (ok && oin[j]) ? dZ[row * O + 32 * tt[j] + l31] : 0.f;
+        bb[u][j] = (ok && kin[j]) ? In[row * K + 32 * tb[j] + l31] : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-      for (int t = 0; t < OB; ++t)
-#pragma unroll
-        for (int b = 0; b < KB; ++b)
-          acc[t][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], bb[u][b], acc[t][b], 0, 0, 0);
+      for (int j = 0; j < MYT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], bb[u][j], acc[j], 0, 0, 0);
   }
-  // combine the 4 waves in a fixed order
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  float* dst = partial + (size_t)block * O * K;
+  if (RS == 1) {
+    // every tile belongs to exactly one wave: straight from the accumulators (128-byte row segments)
 #pragma unroll
-      for (int t = 0; t < OB; ++t)
+    for (int j = 0; j < MYT; ++j) {
+      if (!live[j] || !busy) continue;
 #pragma unroll
-        for (int b = 0; b < KB; ++b)
+      for (int i = 0; i < 16; ++i) {
+        const int o = 32 * tt[j] + feat(i, h), k = 32 * tb[j] + l31;
+        if (o < O && k < K) dst[o * K + k] = acc[j][i];
+      }
+    }
+    return;
+  }
+  // TILES < 4 (MYT == 1): combine the RS row splits of every tile in a fixed order, then store
+  for (int r = 0; r < RS; ++r) {
+    if (busy && rs == r) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float* p = &s_acc[((t * KB + b) * 16 + i) * 64 + lane];
-            *p = (w == 0) ? acc[t][b][i] : (*p + acc[t][b][i]);
-          }
+      for (int i = 0; i < 16; ++i) {
+        float* p = &s_acc[(tw * 16 + i) * 64 + lane];
+        *p = (r == 0) ? acc[0][i] : (*p + acc[0][i]);
+      }
     }
     __syncthreads();
   }
-  // partial[block][o][k] for o < O, k < K
-  float* dst = partial + (size_t)block * O * K;
-  for (int idx = threadIdx.x; idx < OB * KB * 1024; idx += MLP_BLOCK) {
-    const int ln = idx & 63, i = (idx >> 6) & 15, tb = idx >> 10;
-    const int t = tb / KB, b = tb - t * KB;
+  for (int idx = threadIdx.x; idx < TILES * 1024; idx += MLP_BLOCK) {
+    const int ln = idx & 63, i = (idx >> 6) & 15, tile = idx >> 10;
+    const int t = tile / KB, b = tile - t * KB;
     const int o = 32 * t + feat(i, ln >> 5), k = 32 * b + (ln & 31);
     if (o < O && k < K) dst[o * K + k] = s_acc[idx];
   }
@@ -723,7 +752,7 @@ template <int OB, int KB>
 __global__ void __launch_bounds__(MLP_BLOCK)
 weight_grad_kernel(const float* __restrict__ dZ, const float* __restrict__ In, int N, int O, int K,
                    float* __restrict__ partial) {
-  __shared__ float s_acc[OB * KB * 1024];
+  __shared__ float s_acc[(OB * KB < 4 ? OB * KB : 1) * 1024];
   weight_grad_body<OB, KB>(dZ, In, N, O, K, partial, s_acc, blockIdx.x, gridDim.x);
 }
 
@@ -734,9 +763,15 @@ constexpr int WG_MAX_JOBS = 16;
 struct WgJob { const float* dz; const float* in; float* partial; float* dw; int N, O, K, pad; };
 struct WgBatch { WgJob j[WG_MAX_JOBS]; };
 
-__global__ void __launch_bounds__(MLP_BLOCK)
+// (same-box A/B of the C3 step, round 3: 3 waves per SIMD x 16 rows in flight 0.9000 ms, 4 x 12 0.8989, 5 x 8 0.9014 --
+// and 0.9005 for the round-2 kernel that held every tile in every wave at 2 waves per SIMD: the launch is not bound by
+// its own occupancy; kept for the smaller footprint)
+#ifndef INSTAG_WG_WAVES
+#define INSTAG_WG_WAVES 4
+#endif
+__global__ void __launch_bounds__(MLP_BLOCK) __attribute__((amdgpu_waves_per_eu(INSTAG_WG_WAVES)))
 weight_grad_batched_kernel(WgBatch b) {
-  __shared__ float s_acc[2 * 3 * 1024];
+  __shared__ float s_acc[3 * 1024];          // only jobs of fewer than four tiles combine through LDS
   const WgJob job = b.j[blockIdx.y];
   const int ob = (job.O + 31) / 32, kb = (job.K + 31) / 32;
   if (ob == 1 && kb == 1) weight_grad_body<1, 1>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
