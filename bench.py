@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--no-schedule", action="store_true",
                     help="skip the reference_schedule workload (700 iterations across density-control events)")
     ap.add_argument("--schedule-iterations", type=int, default=700)
+    ap.add_argument("--all-workloads", action="store_true",
+                    help="several ranks: also run the secondary workloads (by default a multi-rank run measures the "
+                         "headline workload only: its line must not depend on the extras)")
     ap.add_argument("--allow-eager-fallback", action="store_true",
                     help="several ranks: if the step cannot be captured next to the collective library, time eager "
                          "launches instead of failing (the line then says so in config.execution)")
@@ -539,6 +542,8 @@ def main():
                     recapture_ms=1e3 * getattr(trainer, "recapture_seconds", 0.0),
                     density_ms=1e3 * getattr(trainer, "density_seconds", 0.0), start=start)
 
+    if world > 1 and not args.all_workloads:
+        args.no_stable_targets = args.no_host_frames = args.no_schedule = True
     log(f"config: {N} Gaussians, {size}x{size}, world {world}")
     main_run = measure(False, max(1, args.windows))
     stable_run = None
