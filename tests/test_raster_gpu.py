@@ -55,10 +55,20 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("n,size,deg", CASES)
+@pytest.mark.parametrize("n,size,deg", CASES + [pytest.param(6000, 160, 1, id="6k-160-deep-scene")])
 def test_binning_bit_exact(n, size, deg):
     from instag_amd.diff_gauss import debug_export, rasterize_forward, _f32c
     a, settings = make_scene(n, size, sh_degree=deg)
+    if size == 160:
+        # a scene four times as deep: view-space z on both sides of 0.5 and of 1.0, so the depth keys do NOT share their
+        # top byte and the depth sort's last pass really sorts (in the other cases every key has the top byte 0x3F and
+        # that pass takes its identity shortcut, csrc/raster_sort.hip)
+        a["means3D"] = a["means3D"] * 4.0
+        z = a["means3D"] @ settings["viewmatrix"][:3, 2] + settings["viewmatrix"][3, 2]
+        assert float(z.min()) < 0.5 < 1.0 < float(z.max()), (float(z.min()), float(z.max()))
+    else:
+        z = a["means3D"] @ settings["viewmatrix"][:3, 2] + settings["viewmatrix"][3, 2]
+        assert 0.5 <= float(z.min()) and float(z.max()) < 2.0
     outs_o, aux, _ = run_oracle(a, settings)
     s = hip_settings(settings)
     g = {k: v.cuda().contiguous() for k, v in a.items()}
