@@ -519,6 +519,32 @@ def test_extreme_values_match_topk(n, k):
     assert torch.equal(bottom.cpu(), v.topk(kk, largest=False, sorted=True).values)
 
 
+@pytest.mark.parametrize("kind", ["constant", "many-per-chunk", "short-tail", "all-negative"])
+def test_extreme_values_adversarial_inputs(kind):
+    """The two-launch selection (512-value chunks, then one workgroup over the candidates >= the best chunk's k-th value)
+    on inputs that defeat its pruning: every value tied at the threshold, 63 large values in every chunk (all of them pass
+    the threshold), a last chunk shorter than k, and a vector without positive values."""
+    from instag_amd.renderer import _extreme_values
+    g = torch.Generator().manual_seed(3)
+    n, k = 100000, 50
+    if kind == "constant":
+        v = torch.full((n,), 0.25)
+    elif kind == "many-per-chunk":
+        v = torch.randn(n, generator=g) * 1e-3
+        idx = (torch.arange(n) % 512) < 49                       # 49 large values in every 512-value chunk
+        v[idx] = 10.0 + torch.rand(int(idx.sum()), generator=g)
+        v[~idx & ((torch.arange(n) % 512) < 98)] -= 10.0         # ... and 49 small ones
+    elif kind == "short-tail":
+        n = 512 * 9 + 7                                           # the last chunk holds 7 values
+        v = torch.randn(n, generator=g)
+        v[-7:] = torch.tensor([9.0, -9.0, 8.0, -8.0, 7.0, -7.0, 6.0])
+    else:
+        v = -torch.rand(n, generator=g) - 1.0
+    top, bottom = _extreme_values(v.cuda(), k)
+    assert torch.equal(top.cpu(), v.topk(k, largest=True, sorted=True).values)
+    assert torch.equal(bottom.cpu(), v.topk(k, largest=False, sorted=True).values)
+
+
 def test_mouth_activate_matches_plain_torch():
     """glue.mouth_activate = the mouth render's elementwise tail (gaussian_renderer/__init__.py:404-420 with
     scene/motion_net.py:446-452) -- values and all six gradients against the torch expressions."""
