@@ -328,6 +328,14 @@ typedef struct {
 } instag_wgrad_job;
 int instag_linear_weight_grad_batched(const instag_wgrad_job* jobs, int32_t n_jobs, void* workspace,
                                       size_t workspace_bytes, instag_stream_t stream);
+/* The same with ONE job (index glue_job) whose input rows are not stored: row r of its `in` is
+ * cat(in[r] (KX = K - KA - KE values), aud[r] * enc_a (KA), relu(eye_pre[r]) * enc_e (KE)) -- sigma_net's input as the glue
+ * forms it (scene/motion_net.py:291-306).  instag_mlp_forward_glue then takes h_in = NULL and does not write those rows
+ * (30 MB at 100k Gaussians).  65 <= K <= 96. */
+int instag_linear_weight_grad_batched_glue(const instag_wgrad_job* jobs, int32_t n_jobs, int32_t glue_job,
+                                           const float* aud, const float* eye_pre, const float* enc_a,
+                                           const float* enc_e, int32_t KA, int32_t KE, void* workspace,
+                                           size_t workspace_bytes, instag_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused per-Gaussian glue (csrc/glue.hip).

@@ -237,6 +237,7 @@ _PROTOS = {
     "instag_mlp_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_mlp_backward_add": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "instag_linear_weight_grad_batched": (C.c_int, [vp, i32, vp, sz, vp]),
+    "instag_linear_weight_grad_batched_glue": (C.c_int, [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
     "instag_mlp_backward_glue_supported": (C.c_int, [i32] * 6),
     "instag_mlp_backward_glue_num_partials": (C.c_int, [i32]),
     "instag_mlp_backward_glue": (C.c_int, [vp] * 18 + [i32] * 3 + [vp]),
@@ -305,7 +306,7 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 
 
-ABI_VERSION = 9     # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
+ABI_VERSION = 10    # instag_abi_version() in csrc/raster_api.hip: a stale libinstag_hip.so must not be driven with these prototypes
 
 
 def lib():

@@ -660,10 +660,18 @@ mlp2_backward_kernel(Mlp2Dims d, const float* __restrict__ dYA, const float* __r
 // A/B at weight_grad_batched_kernel -- but it takes half the register file and LDS from the kernels it runs beside.)  The waves of a workgroup read the same rows at the same time, so the
 // operand columns two of them share come from L1.  Jobs of fewer than four tiles split the workgroup's rows between
 // wave groups as before and combine through LDS in a fixed order (bitwise reproducible either way).
-template <int OB, int KB>
+// VIRT: the input rows are not stored anywhere -- row r of `In` is cat(xa[r] (Ka), xb[r] * mb (Kb), relu(xc[r]) * mc (Kc)),
+// sigma_net's input as the glue forms it (scene/motion_net.py:291-306); the forward then does not write those 30 MB.
+struct WgVirt {
+  int job;                                   // index of the job whose input is virtual, -1: none
+  const float *xb, *xc, *mb, *mc;            // xa = the job's `in` pointer
+  int Ka, Kb, Kc, pad;
+};
+
+template <int OB, int KB, bool VIRT = false>
 __device__ __forceinline__ void weight_grad_body(const float* __restrict__ dZ, const float* __restrict__ In, int N, int O,
                                                  int K, float* __restrict__ partial, float* s_acc, int block,
-                                                 int nblocks) {
+                                                 int nblocks, const WgVirt* virt = nullptr) {
   constexpr int TILES = OB * KB;
   constexpr int TW = TILES >= 4 ? 4 : TILES;           // waves holding distinct tile sets
   constexpr int RS = 4 / TW;                           // row splits inside the workgroup (3 tiles: one wave idles)
@@ -688,6 +696,25 @@ __device__ __forceinline__ void weight_grad_body(const float* __restrict__ dZ, c
     oin[j] = live[j] && 32 * tt[j] + l31 < O;
     kin[j] = live[j] && 32 * tb[j] + l31 < K;
   }
+  // this lane's input column of every tile it holds: where it lives (VIRT: in which of the three pieces)
+  const float* bp[MYT];
+  int bs[MYT];
+  float bm[MYT];
+  bool brelu[MYT];
+#pragma unroll
+  for (int j = 0; j < MYT; ++j) {
+    const int col = 32 * tb[j] + l31;
+    bp[j] = In + col; bs[j] = K; bm[j] = 1.f; brelu[j] = false;
+    if (VIRT && kin[j]) {
+      if (col < virt->Ka) { bp[j] = In + col; bs[j] = virt->Ka; }
+      else if (col < virt->Ka + virt->Kb) {
+        bp[j] = virt->xb + (col - virt->Ka); bs[j] = virt->Kb; bm[j] = virt->mb[col - virt->Ka];
+      } else {
+        const int c2 = col - virt->Ka - virt->Kb;
+        bp[j] = virt->xc + c2; bs[j] = virt->Kc; bm[j] = virt->mc[c2]; brelu[j] = true;
+      }
+    }
+  }
   f32x16 acc[MYT];
 #pragma unroll
   for (int j = 0; j < MYT; ++j)
@@ -706,7 +733,12 @@ __device__ __forceinline__ void weight_grad_body(const float* __restrict__ dZ, c
 #pragma unroll
       for (int j = 0; j < MYT; ++j) {
         a[u][j] = (ok && oin[j]) ? dZ[row * O + 32 * tt[j] + l31] : 0.f;
-        bb[u][j] = (ok && kin[j]) ? In[row * K + 32 * tb[j] + l31] : 0.f;
+        float v = (ok && kin[j]) ? bp[j][row * bs[j]] : 0.f;
+        if (VIRT) {
+          v = brelu[j] ? fmaxf(v, 0.f) : v;
+          v *= bm[j];
+        }
+        bb[u][j] = v;
       }
     }
 #pragma unroll
@@ -761,7 +793,7 @@ weight_grad_kernel(const float* __restrict__ dZ, const float* __restrict__ In, i
 // the optimizer runs.
 constexpr int WG_MAX_JOBS = 16;
 struct WgJob { const float* dz; const float* in; float* partial; float* dw; int N, O, K, pad; };
-struct WgBatch { WgJob j[WG_MAX_JOBS]; };
+struct WgBatch { WgJob j[WG_MAX_JOBS]; WgVirt virt; };
 
 // (same-box A/B of the C3 step, round 3: 3 waves per SIMD x 16 rows in flight 0.9000 ms, 4 x 12 0.8989, 5 x 8 0.9014 --
 // and 0.9005 for the round-2 kernel that held every tile in every wave at 2 waves per SIMD: the launch is not bound by
@@ -774,6 +806,11 @@ weight_grad_batched_kernel(WgBatch b) {
   __shared__ float s_acc[3 * 1024];          // only jobs of fewer than four tiles combine through LDS
   const WgJob job = b.j[blockIdx.y];
   const int ob = (job.O + 31) / 32, kb = (job.K + 31) / 32;
+  if ((int)blockIdx.y == b.virt.job) {           // (host side: only shapes with kb == 3 are accepted)
+    if (ob == 1) weight_grad_body<1, 3, true>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x, &b.virt);
+    else weight_grad_body<2, 3, true>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x, &b.virt);
+    return;
+  }
   if (ob == 1 && kb == 1) weight_grad_body<1, 1>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
   else if (ob == 1 && kb == 2) weight_grad_body<1, 2>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
   else if (ob == 1 && kb == 3) weight_grad_body<1, 3>(job.dz, job.in, job.N, job.O, job.K, job.partial, s_acc, blockIdx.x, gridDim.x);
@@ -1004,8 +1041,9 @@ int instag_mlp_forward_glue(const float* enc_x, const float* aud, const float* e
   const int K0 = GLUE_KX + GLUE_KA + GLUE_KE;
   INSTAG_REQUIRE(instag_mlp_backward_glue_supported(K0, H, O, GLUE_KX, GLUE_KA, GLUE_KE), "mlp_forward_glue: unsupported shape");
   INSTAG_REQUIRE(enc_x && aud && eye_pre && enc_a && enc_e && w1 && w2 && w3 && y && amb, "mlp_forward_glue: NULL tensor");
-  INSTAG_REQUIRE((h_in == nullptr) == (a1 == nullptr) && (a1 == nullptr) == (a2 == nullptr),
-                 "mlp_forward_glue: h_in, a1 and a2 go together (all NULL: forward only, nothing is kept for a backward)");
+  INSTAG_REQUIRE((a1 == nullptr) == (a2 == nullptr) && (h_in == nullptr || a1 != nullptr),
+                 "mlp_forward_glue: a1 and a2 go together (NULL: forward only); h_in (may be NULL: the caller's weight "
+                 "gradient assembles the rows itself, instag_linear_weight_grad_batched_glue) needs them");
   if (N <= 0) return INSTAG_OK;
   const MlpDims d{N, K0, H, O};
   const GlueFwd gf{enc_x, aud, eye_pre, enc_a, enc_e, h_in, amb};
@@ -1087,10 +1125,11 @@ int instag_linear_weight_grad(const float* dz, const float* in, float* dw, void*
   return run_wg<2, 3>(dz, in, N, O, K, part, dw, s);
 }
 
-int instag_linear_weight_grad_batched(const instag_wgrad_job* jobs, int32_t n_jobs, void* workspace,
-                                      size_t workspace_bytes, instag_stream_t stream) {
+static int weight_grad_batched_impl(const instag_wgrad_job* jobs, int32_t n_jobs, const WgVirt& virt, void* workspace,
+                                   size_t workspace_bytes, instag_stream_t stream) {
   INSTAG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= WG_MAX_JOBS, "linear_weight_grad_batched: 1..16 jobs");
   WgBatch b;
+  b.virt = virt;
   size_t off = 0;
   int N0 = jobs[0].N, max_count = 0;
   for (int i = 0; i < n_jobs; ++i) {
@@ -1114,6 +1153,24 @@ int instag_linear_weight_grad_batched(const instag_wgrad_job* jobs, int32_t n_jo
   weight_grad_reduce_batched_kernel<<<dim3((max_count + 63) / 64, n_jobs), 256, 0, s>>>(b, blocks);
   INSTAG_CHECK_LAUNCH();
   return INSTAG_OK;
+}
+
+int instag_linear_weight_grad_batched(const instag_wgrad_job* jobs, int32_t n_jobs, void* workspace,
+                                      size_t workspace_bytes, instag_stream_t stream) {
+  return weight_grad_batched_impl(jobs, n_jobs, WgVirt{-1, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0}, workspace,
+                                  workspace_bytes, stream);
+}
+
+int instag_linear_weight_grad_batched_glue(const instag_wgrad_job* jobs, int32_t n_jobs, int32_t glue_job,
+                                           const float* aud, const float* eye_pre, const float* enc_a,
+                                           const float* enc_e, int32_t KA, int32_t KE, void* workspace,
+                                           size_t workspace_bytes, instag_stream_t stream) {
+  INSTAG_REQUIRE(jobs && glue_job >= 0 && glue_job < n_jobs, "linear_weight_grad_batched_glue: glue_job out of range");
+  INSTAG_REQUIRE(aud && eye_pre && enc_a && enc_e && KA >= 1 && KE >= 1, "linear_weight_grad_batched_glue: NULL tensor");
+  const int K = jobs[glue_job].K, KX = K - KA - KE;
+  INSTAG_REQUIRE(KX >= 1 && (K + 31) / 32 == 3, "linear_weight_grad_batched_glue: the glue job needs 65 <= K <= 96 and KX >= 1");
+  return weight_grad_batched_impl(jobs, n_jobs, WgVirt{glue_job, aud, eye_pre, enc_a, enc_e, KX, KA, KE, 0}, workspace,
+                                  workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -312,7 +312,7 @@ using namespace instag;
 extern "C" {
 
 const char* instag_last_error(void) { return g_err.c_str(); }
-int instag_abi_version(void) { return 9; }
+int instag_abi_version(void) { return 10; }
 
 size_t instag_raster_geom_bytes(int32_t N) { return geom_layout(N).total; }
 size_t instag_raster_image_bytes(int32_t H, int32_t W) { return image_layout(H, W).total; }

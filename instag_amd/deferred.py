@@ -43,9 +43,9 @@ def flush_async(device):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         _flush(jobs)
-    for dz, inp, _ in jobs:
-        _keepalive.cross_stream(dz, side)
-        _keepalive.cross_stream(inp, side)
+    for dz, inp, _, virt in jobs:
+        for t in (dz, inp) + tuple(virt or ()):
+            _keepalive.cross_stream(t, side)
     _STATE["forked"].add(key)
 
 
@@ -61,9 +61,24 @@ def join_at_exit(stream):
         _STATE["extra"].append(stream)
 
 
-def defer_weight_grad(dz, inp, weight):
-    """Queue dW = dz^T @ inp for the leaf parameter ``weight`` ([O,K]); dz [N,O], inp [N,K] contiguous fp32."""
-    _STATE["jobs"].append((dz, inp, weight))
+def defer_weight_grad(dz, inp, weight, virt=None):
+    """Queue dW = dz^T @ inp for the leaf parameter ``weight`` ([O,K]); dz [N,O], inp [N,K] contiguous fp32.
+    ``virt`` = (aud, eye_pre, enc_a, enc_e): the input rows were never stored, they are cat(inp, aud * enc_a,
+    relu(eye_pre) * enc_e) (glue._GlueSigma; instag_linear_weight_grad_batched_glue assembles them while loading)."""
+    _STATE["jobs"].append((dz, inp, weight, virt))
+
+
+def _chunks(group):
+    """Launches of at most MAX_JOBS jobs, at most one of them with virtual input rows."""
+    out, cur = [], []
+    for job in group:
+        if len(cur) == MAX_JOBS or (job[3] is not None and any(j[3] is not None for j in cur)):
+            out.append(cur)
+            cur = []
+        cur.append(job)
+    if cur:
+        out.append(cur)
+    return out
 
 
 def _flush(jobs):
@@ -72,20 +87,29 @@ def _flush(jobs):
     for job in jobs:
         by_n.setdefault((job[0].device, job[0].shape[0]), []).append(job)
     for (dev, N), group in by_n.items():
-        for start in range(0, len(group), MAX_JOBS):
-            chunk = group[start:start + MAX_JOBS]
+        for chunk in _chunks(group):
             arr = (_lib.WgradJob * len(chunk))()
-            dws, total = [], 0
-            for i, (dz, inp, w) in enumerate(chunk):
+            dws, total, glue = [], 0, None
+            for i, (dz, inp, w, virt) in enumerate(chunk):
                 O, K = dz.shape[1], inp.shape[1]
+                if virt is not None:
+                    glue = (i, virt)
+                    K += virt[0].shape[1] + virt[1].shape[1]
                 dw = torch.empty(O, K, dtype=torch.float32, device=dev)
                 dws.append(dw)
                 arr[i] = _lib.WgradJob(dz.data_ptr(), inp.data_ptr(), dw.data_ptr(), N, O, K)
                 total += (L.instag_linear_weight_grad_workspace_bytes(N, O, K) + 255) // 256 * 256
             ws = torch.empty(total, dtype=torch.uint8, device=dev)
-            check(L.instag_linear_weight_grad_batched(arr, len(chunk), ptr(ws), total, _lib.current_stream()),
-                  "linear_weight_grad_batched")
-            for (dz, inp, w), dw in zip(chunk, dws):
+            if glue is None:
+                check(L.instag_linear_weight_grad_batched(arr, len(chunk), ptr(ws), total, _lib.current_stream()),
+                      "linear_weight_grad_batched")
+            else:
+                i, (aud, eye_pre, enc_a, enc_e) = glue
+                check(L.instag_linear_weight_grad_batched_glue(arr, len(chunk), i, ptr(aud), ptr(eye_pre), ptr(enc_a),
+                                                               ptr(enc_e), aud.shape[1], eye_pre.shape[1], ptr(ws),
+                                                               total, _lib.current_stream()),
+                      "linear_weight_grad_batched_glue")
+            for (dz, inp, w, _), dw in zip(chunk, dws):
                 dw = dw.reshape(w.shape).to(w.dtype)
                 w.grad = dw if w.grad is None else w.grad.add_(dw)
 

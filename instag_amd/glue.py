@@ -6,6 +6,8 @@ composition and the loss block.  Each replaces a chain of eager elementwise ops 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -62,13 +64,18 @@ class _MotionGlue(torch.autograd.Function):
         return d_enc_x, d_aud, d_eye, d_vec[:KA], d_vec[KA:], None
 
 
+# sigma_net's input rows [N,74] are not written by the forward (30 MB of its 85 MB at 100k Gaussians); =0 stores them
+VIRTUAL_INPUT = os.environ.get("INSTAG_GLUE_VIRTUAL_INPUT", "1") == "1"
+
+
 class _GlueSigma(torch.autograd.Function):
     """motion_glue followed by sigma_net (scene/motion_net.py:291-306) as ONE autograd node whose backward is one
     kernel: sigma_net's backward writes d_enc_x / d_aud / d_eye_pre from its accumulators and keeps the per-frame
     vectors' column sums in registers (csrc/mlp.hip: mlp_backward_kernel<..., GLUE>), instead of storing the [N,74]
     input gradient for motion_glue_backward to read back (35 us + a column-sum launch on the backward's critical path
     at 100k rows).  The forward forms sigma_net's input rows in the registers that feed its first layer (GLUE variant
-    of mlp_forward_kernel) instead of in a kernel of its own."""
+    of mlp_forward_kernel) instead of in a kernel of its own, and (VIRTUAL_INPUT) does not store them: their only later
+    reader is the first layer's weight gradient, which assembles them again from the same three tensors."""
 
     @staticmethod
     def forward(ctx, enc_x, aud, eye_pre, enc_a, enc_e, w1, w2, w3, frame_stream):
@@ -84,7 +91,7 @@ class _GlueSigma(torch.autograd.Function):
         stream = _lib.current_stream()
         # (forward only -- no input needs a gradient: inference, the mouth branch's jaw feature -- nothing is kept)
         keep = any(ctx.needs_input_grad)
-        h_in = torch.empty(N, K0, dtype=torch.float32, device=dev) if keep else None
+        h_in = torch.empty(N, K0, dtype=torch.float32, device=dev) if keep and not VIRTUAL_INPUT else None
         amb = torch.empty(N, 3, dtype=torch.float32, device=dev)
         y = torch.empty(N, O, dtype=torch.float32, device=dev)
         a1 = torch.empty(N, H, dtype=torch.float32, device=dev) if keep else None
@@ -93,7 +100,9 @@ class _GlueSigma(torch.autograd.Function):
                                         ptr(w3c), ptr(y), ptr(a1), ptr(a2), ptr(h_in), ptr(amb), N, H, O, stream),
               "mlp_forward_glue")
         _mlp.STATS["fwd_flops"] += 2 * N * (K0 * H + H * H + H * O)
-        ctx.save_for_backward(aud, eye_pre, enc_a, enc_e, amb, h_in, w1c, w2c, w3c, a1, a2)
+        ctx.save_for_backward(aud, eye_pre, enc_a, enc_e, amb, h_in if h_in is not None or not keep else enc_x, w1c,
+                              w2c, w3c, a1, a2)
+        ctx.virtual = keep and h_in is None
         ctx.weights = (w1, w2, w3)
         ctx.dims = (N, KX, KA, KE, H, O)
         ctx.frame_stream = frame_stream
@@ -123,12 +132,17 @@ class _GlueSigma(torch.autograd.Function):
                                          _lib.current_stream()), "mlp_backward_glue")
         _mlp.STATS["bwd_flops"] += 2 * N * (H * O + H * H + (KX + KA + KE) * H)
         d_vec = _column_sums(parts, ctx.frame_stream, dev)
-        jobs = [(dz1, h_in, 0), (dz2, a1, 1), (dy, a2, 2)]
+        virt = (aud, eye_pre, enc_a, enc_e) if ctx.virtual else None
         grads = [None, None, None]
-        if deferred.active() and all(w.is_leaf for w in ctx.weights):
+        queue = deferred.active() and all(w.is_leaf for w in ctx.weights)
+        if virt is not None and not queue and ctx.needs_input_grad[5]:
+            # (h_in holds enc_x here; outside a deferred block the single-job entry point wants the rows in memory)
+            h_in = torch.cat([h_in, aud * enc_a, torch.relu(eye_pre) * enc_e], dim=1)
+        jobs = [(dz1, h_in, 0), (dz2, a1, 1), (dy, a2, 2)]
+        if queue:
             for dz, inp, idx in jobs:
                 if ctx.needs_input_grad[5 + idx]:
-                    deferred.defer_weight_grad(dz, inp, ctx.weights[idx])
+                    deferred.defer_weight_grad(dz, inp, ctx.weights[idx], virt if idx == 0 else None)
         else:
             for dz, inp, idx in jobs:
                 if ctx.needs_input_grad[5 + idx]:

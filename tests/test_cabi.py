@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/instag_hip.h but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), set(names) ^ set(_lib.EXPORTED_SYMBOLS)
-    assert lib.instag_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.instag_abi_version() == _lib.ABI_VERSION == 10
     assert lib.instag_last_error() is not None
 
 

@@ -505,6 +505,40 @@ def test_glue_sigma_backward_kernel_matches_the_two_operators(hidden, with_amb):
         assert float((r - g).abs().max()) <= 2e-5 * scale + 1e-6, (n_, float((r - g).abs().max()), scale)
 
 
+@pytest.mark.parametrize("hidden", [64, 32])
+@pytest.mark.parametrize("in_block", [True, False])
+def test_glue_sigma_unstored_input_rows_give_the_same_bits(hidden, in_block, monkeypatch):
+    """sigma_net's input rows not written by the forward, assembled again by the first layer's weight gradient
+    (instag_linear_weight_grad_batched_glue; outside a deferred block by torch) == rows stored by the forward: the same
+    products in the same order, so every output and gradient bit for bit."""
+    from instag_amd import glue
+    from instag_amd.deferred import deferred_grads
+    from instag_amd.motion_net import MLP
+    torch.manual_seed(6)
+    N = 7001
+    net = MLP(74, 11, hidden, 3).cuda()
+    base = [torch.randn(N, 36), torch.randn(N, 32), torch.randn(N, 6), torch.randn(32), torch.randn(6)]
+    gy, gamb = torch.randn(N, 11).cuda(), torch.randn(N, 3).cuda()
+
+    def run(virtual):
+        monkeypatch.setattr(glue, "VIRTUAL_INPUT", virtual)
+        ins = [t.clone().cuda().requires_grad_(True) for t in base]
+        for p in net.parameters():
+            p.grad = None
+        y, amb = glue.glue_sigma(*ins, net)
+        loss = (y * gy).sum() + (amb * gamb).sum()
+        if in_block:
+            with deferred_grads("cuda"):
+                loss.backward()
+        else:
+            loss.backward()
+        return [y.detach(), amb.detach()] + [t.grad for t in ins] + [p.grad.clone() for p in net.parameters()]
+
+    stored, virtual = run(False), run(True)
+    for i, (a, b) in enumerate(zip(stored, virtual)):
+        assert torch.equal(a, b), i
+
+
 @pytest.mark.parametrize("n,k", [(1, 1), (37, 50), (4096, 50), (4097, 10), (100000, 50), (400003, 64)])
 def test_extreme_values_match_topk(n, k):
     """csrc/select.hip (the jaw-movement feature's two selections) == torch.topk values, largest and smallest."""
