@@ -144,6 +144,11 @@ typedef struct instag_raster_args {
      separate parameters and concatenates them on every call, :183-186): when shs_rest != NULL, `shs` holds only the
      DC coefficient [N,1,3] and shs_rest the other M-1; M is still the total count.  NULL = `shs` is [N,M,3]. */
   const float* shs_rest;
+  /* optional (NULL: none): device uint32[tiles] (tiles = ceil(W/16) * ceil(H/16)) that PERSISTS between the calls of one
+     render slot, any initial content.  The forward blend keeps every tile's recent walk length there (1/8 of a
+     128-entry segment per unit: up at once, down one unit per call) and starts helper workgroups for the tiles that
+     walked far lately; results do not depend on it. */
+  uint32_t* walk_hints;
 } instag_raster_args;
 
 size_t instag_raster_geom_bytes(int32_t N);
@@ -591,7 +596,8 @@ int instag_adam_step_grads(const void* tensors, const void* host_grads, int32_t 
                            instag_stream_t stream);
 /* The same in ONE launch (no counter launch in front): tickets = int32[n_tensors] in device memory, zero before the first
  * call and left zero by every call; the workgroup of each tensor that finishes last stores the tensor's new step count.
- * chunks must list every chunk of every tensor exactly once. */
+ * chunks must list every chunk of every tensor it names exactly once (a step may be made of several calls over
+ * disjoint sets of tensors). */
 int instag_adam_step_grads_ticketed(const void* tensors, const void* host_grads, int32_t n_tensors, const void* groups,
                                     const float* lrs, const int32_t* chunks, int32_t n_chunks, float* step,
                                     int32_t* tickets, instag_stream_t stream);

@@ -44,7 +44,7 @@ class RasterArgs(C.Structure):
         ("bg", vp), ("viewmatrix", vp), ("projmatrix", vp), ("campos", vp),
         ("means3D", vp), ("shs", vp), ("colors_precomp", vp), ("opacities", vp),
         ("scales", vp), ("rotations", vp), ("cov3Ds_precomp", vp), ("extra_attrs", vp),
-        ("shs_rest", vp),
+        ("shs_rest", vp), ("walk_hints", vp),
     ]
 
 

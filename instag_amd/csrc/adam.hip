@@ -171,7 +171,8 @@ int instag_adam_step_grads(const void* tensors, const void* host_grads, int32_t 
 
 /* As instag_adam_step_grads in ONE launch: `tickets` = int32[n_tensors] in device memory, zero before the first call
  * and left zero by every call; the step counters are incremented by the kernel itself (by the workgroup of each tensor
- * that finishes last).  `chunks` must list every chunk of every tensor exactly once. */
+ * that finishes last).  `chunks` must list every chunk of every tensor it names exactly once (a step may be made
+ * of several calls over disjoint sets of tensors). */
 int instag_adam_step_grads_ticketed(const void* tensors, const void* host_grads, int32_t n_tensors, const void* groups,
                                     const float* lrs, const int32_t* chunks, int32_t n_chunks, float* step,
                                     int32_t* tickets, instag_stream_t stream) {

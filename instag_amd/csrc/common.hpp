@@ -116,10 +116,13 @@ struct BinningLayout {
   // gradient rows a backward blend wrote (two sets: the main and the auxiliary pass may run side by side); the
   // reducing kernel clears what it consumes.  seg_count and row_flag follow tsort_zero and are cleared with it.
   size_t seg_state, seg_slots, seg_queue, seg_count, row_flag, row_flag_stride;
+  // segment-wise forward blend: per tile {next segment to claim, segments walked, ~(first finished segment), resolved},
+  // per segment slot a "posted" flag -- both inside the region the duplicate kernel clears
+  size_t fwd_sync, seg_flag;
   size_t total;
 };
 constexpr int SEG_LEN = 128;                 // list entries per blend segment (divides the forward blend's batch of 256)
-constexpr int SEG_FLOATS = 12;
+constexpr int SEG_FLOATS = 14;               // + t_seg, the segment's last contributor (raster_blend.hip: segment-wise forward)
 constexpr int TILE_PIX = TILE_X * TILE_Y;
 BinningLayout binning_layout(int64_t R, int32_t H, int32_t W);
 

@@ -215,15 +215,17 @@ BinningLayout binning_layout(int64_t R, int32_t H, int32_t W) {
   // [tickets + look-back words][seg_count + pad][row flags, two sets]: one region, cleared by the duplicate kernel
   const size_t sort_words = 16 + (size_t)3 * L.tsort_blocks * 256;
   L.row_flag_stride = align_up(r, 16);
-  L.tsort_zero_words = sort_words + 4 + 2 * L.row_flag_stride / 4;
+  L.seg_slots = r / SEG_LEN + tiles + 2;
+  L.tsort_zero_words = sort_words + 4 + 2 * L.row_flag_stride / 4 + 4 * tiles + L.seg_slots;
   L.tsort_zero = o;
   L.seg_count = o + sort_words * sizeof(uint32_t);
   L.row_flag = L.seg_count + 4 * sizeof(uint32_t);
+  L.fwd_sync = L.row_flag + 2 * L.row_flag_stride;
+  L.seg_flag = L.fwd_sync + 4 * tiles * sizeof(uint32_t);
   o = align_up(o + L.tsort_zero_words * sizeof(uint32_t), 256);
   L.tsort_digit_base = o; o = align_up(o + (size_t)HIST_SLICES * 3 * 256 * sizeof(uint32_t), 256);
   L.tsort_partials = o; o = align_up(o + (size_t)1024 * 3 * 256 * sizeof(uint32_t), 256);
   L.sort_count = o; o = align_up(o + sizeof(uint32_t), 256);
-  L.seg_slots = r / SEG_LEN + tiles + 2;
   L.seg_queue = o; o = align_up(o + 2 * L.seg_slots * sizeof(uint32_t), 256);
   L.seg_state = o; o = align_up(o + L.seg_slots * SEG_FLOATS * TILE_PIX * sizeof(float), 256);
   L.total = o;
@@ -407,11 +409,13 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
   } else {
     INSTAG_CHECK_HIP(hipMemsetAsync(ranges, 0, (size_t)tiles * 2 * sizeof(int32_t), s));
   }
+  // (R == 0: no duplicate kernel ran, nothing cleared the claim words -- the whole-tile kernel handles empty lists)
   return launch_blend_forward(c, ranges, point_list, (const float*)(gb + GL.rec2d), (uint32_t*)(ib + IL.n_contrib),
                               (float*)(ib + IL.final_T), out_color, out_depth, out_normal, out_alpha,
                               a->E > 0 ? out_extra : nullptr, aux_colors, out_aux, (uint32_t*)(bb + BL.seg_queue),
                               (uint32_t*)(bb + BL.seg_count), (float*)(bb + BL.seg_state),
-                              (uint32_t*)(ib + IL.tile_rounds), s);
+                              (uint32_t*)(ib + IL.tile_rounds), R > 0 ? (uint32_t*)(bb + BL.fwd_sync) : nullptr,
+                              (uint32_t*)(bb + BL.seg_flag), a->walk_hints, s);
 }
 
 int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,

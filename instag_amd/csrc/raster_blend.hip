@@ -13,6 +13,9 @@
 // among the Gaussian's kept tiles).  The reduction of a Gaussian's gradient over the 256 pixels of the tile runs
 // as two small fp32 GEMMs on the matrix cores (see blend_backward_kernel) and the row is written once
 // with plain 16-byte stores.  The per-Gaussian sum over its rows happens in raster_backward.hip.
+#include <cstdlib>
+#include <cstring>
+
 #include "raster_internal.hpp"
 
 namespace instag {
@@ -42,6 +45,11 @@ constexpr float T_MIN = 0.0001f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float FAR_PIXEL = 1e18f;
 
+#ifdef BLEND_DBG
+// (diagnostic build only: when each tile's workgroup started and ended, and where it ran -- scripts/probes/blend_tile_profile.py)
+__device__ uint32_t g_blend_dbg[4096 * 8];
+#endif
+
 template <bool AUX>
 __global__ void __launch_bounds__(BLOCK)
 blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -67,6 +75,9 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
   const int start = ranges[2 * tile], end = ranges[2 * tile + 1];
   const int rounds = (end - start + BLOCK - 1) / BLOCK;
   int toDo = end - start;
+#ifdef BLEND_DBG
+  const uint64_t dbg_t0 = wall_clock64();
+#endif
   // every SEG_LEN entries of the list are a segment with a slot of its own (common.hpp BinningLayout): the per-pixel
   // state after each segment the tile walks is kept there, so that the backward pass can start anywhere
   static_assert(BLOCK % SEG_LEN == 0 && SEG_LEN % 4 == 0, "a batch is a whole number of segments");
@@ -203,6 +214,17 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
     if (tid == 0) {
       tile_rounds[tile] = (uint32_t)walked;
       s_base = nseg ? atomicAdd(seg_count, nseg) : 0u;
+#ifdef BLEND_DBG
+      if (tile < 4096) {
+        const uint64_t t1 = wall_clock64();
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        uint32_t* d = g_blend_dbg + 8 * tile;
+        d[0] = (uint32_t)dbg_t0; d[1] = (uint32_t)(dbg_t0 >> 32); d[2] = (uint32_t)t1; d[3] = (uint32_t)(t1 >> 32);
+        d[4] = hw; d[5] = xcc; d[6] = tile_last; d[7] = (uint32_t)(end - start);
+      }
+#endif
     }
     __syncthreads();
     for (uint32_t k = tid; k < nseg; k += BLOCK) {
@@ -230,6 +252,439 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
       out_aux[pix_i] = xacc[0] + T * c.bg[0];
       out_aux[P + pix_i] = xacc[1] + T * c.bg[1];
       out_aux[2 * P + pix_i] = xacc[2] + T * c.bg[2];
+    }
+  }
+}
+
+// ---- forward, one SEGMENT at a time ------------------------------------------------------------------------------------
+// The kernel above walks a tile's list front to back in one workgroup: its duration is the longest tile's chain (C3: a
+// few dozen tiles of the 650 populated ones walk 700-960 entries -- rays through hair never saturate -- and run alone
+// for the last 60 of 110 us, scripts/probes/blend_tile_profile.py).  Here the unit of work is one SEG_LEN-entry segment:
+// workgroups CLAIM the segments of a tile in order (one atomic), so several workgroups -- the tile's own plus helper
+// workgroups started for tiles that walked far in the previous launch (walk hints) -- walk one tile's list on several
+// CUs at a time.  What a segment needs from the segments in front of it is one number per pixel, the transmittance in
+// front of it, and the arithmetic is arranged so that this number does not depend on WHO computed what, or when:
+//   * inside a segment the recurrence runs on the LOCAL transmittance t (1 at the segment's first entry) and the local
+//     weights alpha_k t_(k-1); a pixel stops at the first entry with fl(P t_k) < T_MIN, P = the transmittance in front
+//     of the segment;
+//   * a segment's product t_seg (0 for a pixel that stopped in it) is posted per pixel; P of segment s is the ordered
+//     product fl(fl(t_seg(0) t_seg(1)) ...) -- `chain_step` below, used by every reader alike;
+//   * the channel sums in front of segment s+1 are acc(s) = fma(P(s), local sums of s, acc(s-1)), formed by ONE
+//     workgroup per tile (the one that finds the tile complete) from the posted local sums.
+// A workgroup whose segment's predecessors are all posted walks it once, with the stop rule; otherwise it first runs a
+// transmittance-only pass (no colours, no stop rule: 0.6 of a walk), posts t_seg, waits for the predecessors' posts --
+// their owners are running and wait for nothing themselves -- and walks again with P known.  A tile nobody helps with
+// is therefore walked exactly once, as before; results are bit-identical whoever takes part.
+constexpr int FWD_HELPERS = 3;            // helper workgroups per tile in a launch with walk hints
+constexpr uint32_t FWD_LONG_SEGS = 3;     // a tile that walked this many segments lately gets helpers
+constexpr uint32_t FWD_HINT_UNIT = 8;     // walk hints are kept in 1/8 segments (they decay by one unit per call)
+constexpr int SYNC_CLAIM = 0, SYNC_DONE = 1, SYNC_INV_DEAD = 2, SYNC_RESOLVED = 3;
+
+// What workgroups of different CUs hand each other inside the launch (the per-segment planes, the flags) goes through
+// agent-scope relaxed atomics -- write-through stores, cache-bypassing loads -- ordered by the workgroup barrier's
+// wait for outstanding memory operations; release / acquire fences write back or invalidate whole caches and cost
+// the kernel 4x its duration (0.56 ms against 0.12).
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void chain_step(float& P, bool& alive, float tseg) {
+  // the transmittance in front of the next segment, and whether the pixel is still unfinished there
+  const float next = P * tseg;
+  if (alive) {
+    if (next < T_MIN) alive = false;
+    else P = next;
+  }
+}
+
+// the per-pixel state in front of a segment, as the workgroup that adds a tile up carries it from segment to segment
+struct FwdSums {
+  float P, Tf, acc[NCH], xacc[3];
+  uint32_t last;
+  bool alive;
+};
+
+__device__ __forceinline__ void fold_segment(FwdSums& r, int q, float T_after, const float* loc /*[NCH]*/,
+                                             const float* xloc /*[3]*/, float tseg, uint32_t last_local) {
+  if (r.alive) {
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) r.acc[k] = __builtin_fmaf(r.P, loc[k], r.acc[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.xacc[k] = __builtin_fmaf(r.P, xloc[k], r.xacc[k]);
+    r.Tf = T_after;
+    r.last = last_local ? (uint32_t)(q * SEG_LEN) + last_local : r.last;
+  }
+  chain_step(r.P, r.alive, tseg);
+}
+
+template <bool AUX>
+__global__ void __launch_bounds__(BLOCK, 4)           // (<= 128 registers: four workgroups per CU, every tile's own one resident)
+blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+                           const float* __restrict__ rec2d, uint32_t* __restrict__ n_contrib,
+                           float* __restrict__ final_T, float* __restrict__ out_color,
+                           float* __restrict__ out_depth, float* __restrict__ out_normal,
+                           float* __restrict__ out_alpha, float* __restrict__ out_extra,
+                           const float* __restrict__ aux_colors, float* __restrict__ out_aux,
+                           uint32_t* __restrict__ seg_queue, uint32_t* __restrict__ seg_count,
+                           float* seg_state, uint32_t* __restrict__ tile_rounds, uint32_t* tile_sync,
+                           uint32_t* seg_flag, uint32_t* walk_hints, uint32_t* stalls, int ntiles, int share_all) {
+  __shared__ float4 s_geo[SEG_LEN];                // x y A' C'   (one LDS array per read of the inner loop, see above)
+  __shared__ float2 s_bo[SEG_LEN];                 // B' opacity
+  __shared__ float4 s_c0[SEG_LEN], s_c1[SEG_LEN];  // r g b depth | nx ny nz extra
+  __shared__ float4 s_c2[AUX ? SEG_LEN : 1];       // aux r g b -
+  __shared__ uint32_t s_word[2];
+  const int tid = threadIdx.x;
+  // helpers have the LOWEST block numbers of a launch that has any: they are dispatched first and take their tiles'
+  // first segments at once (most of them find their tile is not shared and leave)
+  const int nhelp = (int)gridDim.x - ntiles;
+  const bool helper = (int)blockIdx.x < nhelp;
+  const int tile = helper ? (int)blockIdx.x / FWD_HELPERS : (int)blockIdx.x - nhelp;
+  // (any content of the hint will do: the tile's own workgroup and its helpers read the same word -- nobody writes it
+  // before the tile is complete -- and helpers only take work that is there)
+  // share_all (tests): every tile long enough is shared, hints or not
+  const uint32_t hint = walk_hints != nullptr ? walk_hints[tile] : 0u;
+  const bool helped = share_all != 0 || hint >= FWD_LONG_SEGS * FWD_HINT_UNIT;
+  const int start = ranges[2 * tile], end = ranges[2 * tile + 1];
+  const int nsegs = (end - start + SEG_LEN - 1) / SEG_LEN;
+  // direct: the tile has no helpers -- its workgroup walks the segments in order without claims, flags or a second look
+  // at what it stored (the same arithmetic, segment by segment, as the tiles that are shared)
+  const bool direct = !(helped && nsegs >= (int)FWD_LONG_SEGS);
+  uint32_t* sync = tile_sync + 4 * (size_t)tile;
+  if (helper && direct) return;
+  if (direct && walk_hints != nullptr && tid == 0) {
+    // This workgroup writes the new hint when it is done; a helper that starts after that reads the NEW value and may
+    // take the tile for a shared one: it then finds every segment "finished" and the tile added up already
+    atomicMax(&sync[SYNC_INV_DEAD], 0xFFFFFFFFu);
+    atomicExch(&sync[SYNC_RESOLVED], 1u);
+  }
+  const int tx = tile % c.grid_x, ty = tile / c.grid_x;
+  const int pxi = tx * TILE_X + (tid & 15), pyi = ty * TILE_Y + (tid >> 4);
+  const bool inside = pxi < c.W && pyi < c.H;
+  const int slot0 = start / SEG_LEN + tile;
+  constexpr size_t SLOT = (size_t)SEG_FLOATS * TILE_PIX;
+  const f32x2 pix_in = inside ? f32x2{(float)pxi, (float)pyi} : f32x2{FAR_PIXEL, FAR_PIXEL};
+#ifdef BLEND_DBG
+  const uint64_t dbg_t0 = wall_clock64();
+#endif
+
+  // the records of the segment this workgroup will probably take next are fetched while it walks the current one
+  float4 nrec0, nrec1, nrec2, nrec3;
+  float nauxb = 0.f;
+  int fetched = -1;
+  auto fetch = [&](int seg) {
+    fetched = seg;
+    nrec0 = make_float4(0.f, 0.f, 0.f, 0.f); nrec1 = nrec0; nrec2 = nrec0; nrec3 = nrec0; nauxb = 0.f;
+    const int pos = start + seg * SEG_LEN + tid;
+    if (tid < SEG_LEN && seg < nsegs && pos < end) {
+      const uint32_t gid = point_list[pos];
+      const float4* r = reinterpret_cast<const float4*>(rec2d + (size_t)gid * REC_FLOATS);
+      const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+      nrec0 = make_float4(r0.x, r0.y, (-0.5f * LOG2E) * r0.z, (-0.5f * LOG2E) * r1.x);
+      nrec1 = make_float4(-LOG2E * r0.w, r1.y, r1.z, r1.w);
+      nrec2 = r2;
+      nrec3 = make_float4(r3.x, r3.y, 0.f, 0.f);
+      if (AUX) {
+        nrec3.z = aux_colors[3 * (size_t)gid]; nrec3.w = aux_colors[3 * (size_t)gid + 1];
+        nauxb = aux_colors[3 * (size_t)gid + 2];
+      }
+    }
+  };
+  // what this workgroup knows of the chain: P / alive in front of segment `known`
+  float P = 1.0f;
+  bool alive = inside;
+  int known = 0;
+  FwdSums sums;                                        // (direct tiles, and whoever adds a shared tile up)
+  sums.P = 1.0f; sums.Tf = 1.0f; sums.last = 0u; sums.alive = inside;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) sums.acc[k] = 0.f;
+  sums.xacc[0] = sums.xacc[1] = sums.xacc[2] = 0.f;
+  int walked = 0;
+  if (!helper) fetch(0);
+
+  for (int next_direct = 0;; ++next_direct) {
+    int seg = next_direct;
+    __syncthreads();                                  // (s_word, the record arrays: the previous round is done with them)
+    if (!direct) {
+      if (tid == 0) {
+        s_word[0] = atomicAdd(&sync[SYNC_CLAIM], 1u);
+        s_word[1] = ~ld_agent(&sync[SYNC_INV_DEAD]);
+      }
+      __syncthreads();
+      seg = (int)s_word[0];
+    }
+    const int slot = slot0 + seg;
+    if (seg >= nsegs || (!direct && (uint32_t)seg >= s_word[1])) {
+      // nothing left to take: the list ends here (or the tile is known to be finished in front of this segment).  A
+      // claimed segment is always posted -- a workgroup that took a later one before the tile was known to be
+      // finished may be waiting for it (every pixel is finished there: it will not look at the numbers)
+      if (!direct && tid == 0) {
+        if (seg >= nsegs) atomicMax(&sync[SYNC_INV_DEAD], ~(uint32_t)nsegs);
+        else st_agent(&seg_flag[slot], 1u);
+      }
+      walked = nsegs;
+      break;
+    }
+    if (fetched != seg) fetch(seg);
+    if (tid < SEG_LEN) {
+      s_geo[tid] = nrec0; s_bo[tid] = make_float2(nrec1.x, nrec1.y);
+      s_c0[tid] = make_float4(nrec1.z, nrec1.w, nrec2.x, nrec2.y);
+      s_c1[tid] = make_float4(nrec2.z, nrec2.w, nrec3.x, nrec3.y);
+      if (AUX) s_c2[tid] = make_float4(nrec3.z, nrec3.w, nauxb, 0.f);
+    }
+    // are the segments in front of this one posted (those this workgroup has not folded into P yet)?
+    bool posted = true;
+    if (!direct)
+      for (int q = known + tid; q < seg; q += BLOCK) posted = posted && ld_agent(&seg_flag[slot0 + q]) != 0u;
+    const bool all_posted = __syncthreads_and(posted) != 0;     // (also: the records are staged)
+    fetch(seg + 1);
+    const int groups = (min(SEG_LEN, end - start - seg * SEG_LEN) + 3) >> 2;
+    float* st = seg_state + (size_t)slot * SLOT + tid;
+
+    if (!all_posted) {
+      // ---- transmittance-only pass: t_seg of every pixel, as if none stopped ---------------------------------------
+      float t = 1.0f;
+      if (__builtin_amdgcn_ballot_w64(inside) != 0) {
+        for (int g = 0; g < groups; ++g) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float4 a = s_geo[4 * g + k];
+            const float2 b = s_bo[4 * g + k];
+            const f32x2 d = f32x2{a.x, a.y} - pix_in;
+            const f32x2 u = (d * f32x2{a.z, a.w}) * d;
+            const float p2 = __builtin_fmaf(b.x, d.x * d.y, u.x + u.y);
+            const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
+            const bool hit = !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
+            t = t * (1.0f - (hit ? alpha : 0.f));
+          }
+        }
+      }
+      st_agent(&st[12 * TILE_PIX], t);
+      __syncthreads();                                 // (every wave's stores have been acknowledged)
+      if (tid == 0) {
+        st_agent(&seg_flag[slot], 1u);
+        // the predecessors' owners are running and wait for nothing: their posts come (bounded all the same)
+        for (int q = known; q < seg; ++q) {
+          uint32_t spins = 0;
+          while (ld_agent(&seg_flag[slot0 + q]) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 19)) {                      // gave up: the result is wrong, say so (sort_stalls())
+              if (stalls) atomicAdd(stalls, 1u);
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!direct) {
+      for (int q = known; q < seg; ++q)
+        chain_step(P, alive, ld_agent(seg_state + (size_t)(slot0 + q) * SLOT + 12 * TILE_PIX + tid));
+      known = seg;
+    }
+    if (__syncthreads_or(alive) == 0) {
+      // every pixel finished in front of this segment: the tile's walk ends here (posted all the same, see above)
+      if (!direct && tid == 0) {
+        atomicMax(&sync[SYNC_INV_DEAD], ~(uint32_t)seg);
+        if (all_posted) st_agent(&seg_flag[slot], 1u);
+      }
+      walked = seg;
+      break;
+    }
+
+    // ---- the walk proper: local transmittance, local sums, the stop rule against P -----------------------------------
+    f32x2 pix = alive ? pix_in : f32x2{FAR_PIXEL, FAR_PIXEL};
+    const float Pe = alive ? P : 1.0f;                 // (a finished pixel never trips the stop test)
+    bool wave_done = __builtin_amdgcn_ballot_w64(alive) == 0;
+    float T = 1.0f;
+    uint32_t last_local = 0;
+    f32x2 acc2[NCH / 2];
+#pragma unroll
+    for (int k = 0; k < NCH / 2; ++k) acc2[k] = f32x2{0.f, 0.f};
+    f32x2 xacc2 = {0.f, 0.f}, xacc3 = {0.f, 0.f};
+    for (int g = 0; g < groups && !wave_done; ++g) {
+      float al[4], w[4];
+      bool hit[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 a = s_geo[4 * g + k];
+        const float2 b = s_bo[4 * g + k];
+        const f32x2 d = f32x2{a.x, a.y} - pix;
+        const f32x2 u = (d * f32x2{a.z, a.w}) * d;
+        const float p2 = __builtin_fmaf(b.x, d.x * d.y, u.x + u.y);
+        const float alpha = fminf(0.99f, b.y * __builtin_amdgcn_exp2f(p2));
+        hit[k] = !(p2 > 0.0f) && !(alpha < ALPHA_MIN);
+        al[k] = hit[k] ? alpha : 0.f;
+      }
+      const float t1 = T * (1.0f - al[0]);
+      const float t2 = t1 * (1.0f - al[1]);
+      const float t3 = t2 * (1.0f - al[2]);
+      float t4 = t3 * (1.0f - al[3]);
+      w[0] = al[0] * T; w[1] = al[1] * t1; w[2] = al[2] * t2; w[3] = al[3] * t3;
+      uint32_t code = hit[0] ? 1u : 0u;
+      code = hit[1] ? 2u : code;
+      code = hit[2] ? 3u : code;
+      code = hit[3] ? 4u : code;
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(Pe * t4 < T_MIN) != 0, 0)) {
+        // some pixel of this wave finishes within these four: redo them with the per-lane stop rule (a lane that
+        // does not stop gets the same numbers again)
+        bool dead = false;
+        float Tc = T;
+        code = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float a = dead ? 0.f : al[k];
+          const float tt = Tc * (1.0f - a);
+          const bool stop = Pe * tt < T_MIN;
+          dead = dead || stop;
+          a = stop ? 0.f : a;
+          code = (a > 0.f) ? (uint32_t)(k + 1) : code;
+          w[k] = a * Tc;
+          Tc = stop ? Tc : tt;
+        }
+        t4 = Tc;
+        if (dead) pix = f32x2{FAR_PIXEL, FAR_PIXEL};
+        wave_done = __builtin_amdgcn_ballot_w64(pix.x < 0.5f * FAR_PIXEL) == 0;
+      }
+      T = t4;
+      last_local = code ? (uint32_t)(4 * g) + code : last_local;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 c0 = s_c0[4 * g + k];
+        const float4 c1 = s_c1[4 * g + k];
+        const f32x2 w2 = {w[k], w[k]};
+        acc2[0] = __builtin_elementwise_fma(f32x2{c0.x, c0.y}, w2, acc2[0]);
+        acc2[1] = __builtin_elementwise_fma(f32x2{c0.z, c0.w}, w2, acc2[1]);
+        acc2[2] = __builtin_elementwise_fma(f32x2{c1.x, c1.y}, w2, acc2[2]);
+        acc2[3] = __builtin_elementwise_fma(f32x2{c1.z, c1.w}, w2, acc2[3]);
+        if (AUX) {
+          const float4 c2 = s_c2[4 * g + k];
+          xacc2 = __builtin_elementwise_fma(f32x2{c2.x, c2.y}, w2, xacc2);
+          xacc3 = __builtin_elementwise_fma(f32x2{c2.z, c2.w}, w2, xacc3);
+        }
+      }
+    }
+    // what the segment leaves behind: the transmittance after it (where the pixel stopped, if it did), the LOCAL sums,
+    // t_seg (0 for a pixel that stopped here or before), the last contributor
+    const bool stopped = alive && !(pix.x < 0.5f * FAR_PIXEL);
+    const float tseg = (alive && !stopped) ? T : 0.0f;
+    const float loc[NCH] = {acc2[0].x, acc2[0].y, acc2[1].x, acc2[1].y, acc2[2].x, acc2[2].y, acc2[3].x, acc2[3].y};
+    const float xloc[3] = {xacc2.x, xacc2.y, xacc3.x};
+    if (direct) {
+      // the tile is this workgroup's alone: the running sums stay in registers, the state behind the segment is stored
+      // in the form the backward pass reads
+      fold_segment(sums, seg, P * T, loc, xloc, tseg, alive ? last_local : 0u);
+      P = sums.P; alive = sums.alive;
+      st[0] = sums.Tf;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) st[(1 + k) * TILE_PIX] = sums.acc[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) st[(9 + k) * TILE_PIX] = sums.xacc[k];
+      continue;
+    }
+    st_agent(&st[0], P * T);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) st_agent(&st[(1 + k) * TILE_PIX], loc[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st_agent(&st[(9 + k) * TILE_PIX], xloc[k]);
+    if (all_posted) st_agent(&st[12 * TILE_PIX], tseg);   // (else: posted by the transmittance pass -- same verdict for the chain)
+    st_agent(&st[13 * TILE_PIX], __uint_as_float(alive ? last_local : 0u));
+    chain_step(P, alive, tseg);
+    known = seg + 1;
+    __syncthreads();                                   // (every wave's stores have been acknowledged)
+    if (tid == 0) {
+      if (all_posted) st_agent(&seg_flag[slot], 1u);
+      atomicAdd(&sync[SYNC_DONE], 1u);
+    }
+  }
+
+  if (!direct) {
+    // ---- whoever finds the tile complete (every segment in front of the first finished one walked) adds it up -----
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t done = atomicAdd(&sync[SYNC_DONE], 0u);
+      const uint32_t dead = ~atomicMax(&sync[SYNC_INV_DEAD], 0u);
+      s_word[0] = (done == dead && atomicCAS(&sync[SYNC_RESOLVED], 0u, 1u) == 0u) ? 1u : 0u;
+      s_word[1] = dead;
+    }
+    __syncthreads();
+    if (s_word[0] == 0u) return;
+    walked = (int)s_word[1];
+    for (int q = 0; q < walked; ++q) {
+      float* sq = seg_state + (size_t)(slot0 + q) * SLOT + tid;
+      float v[SEG_FLOATS];
+#pragma unroll
+      for (int k = 0; k < SEG_FLOATS; ++k) v[k] = ld_agent(sq + k * TILE_PIX);
+      fold_segment(sums, q, v[0], v + 1, v + 9, v[12], __float_as_uint(v[13]));
+      // the state after segment q as the backward pass reads it: T, the sums so far
+      sq[0] = sums.Tf;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) sq[(1 + k) * TILE_PIX] = sums.acc[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sq[(9 + k) * TILE_PIX] = sums.xacc[k];
+    }
+  }
+
+  {
+    __shared__ uint32_t s_last[BLOCK / 64], s_base;
+    uint32_t m = inside ? sums.last : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((tid & 63) == 0) s_last[tid >> 6] = m;
+    __syncthreads();
+    const uint32_t tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+    const uint32_t nseg = (tile_last + SEG_LEN - 1) / SEG_LEN;
+    if (tid == 0) {
+      tile_rounds[tile] = (uint32_t)walked;
+      // the hint follows the walk up at once and down slowly: steps of a training run alternate between views, and a
+      // tile that walked far in one of the last FWD_HINT_UNIT * (length - 2) calls is worth its helpers' first look
+      if (walk_hints) walk_hints[tile] = max((uint32_t)walked * FWD_HINT_UNIT, hint > 0u && hint < (1u << 20) ? hint - 1u : 0u);
+      s_base = nseg ? atomicAdd(seg_count, nseg) : 0u;
+#ifdef BLEND_DBG
+      if (tile < 4096) {
+        const uint64_t t1 = wall_clock64();
+        uint32_t hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        uint32_t* d = g_blend_dbg + 8 * tile;
+        d[0] = (uint32_t)dbg_t0; d[1] = (uint32_t)(dbg_t0 >> 32); d[2] = (uint32_t)t1; d[3] = (uint32_t)(t1 >> 32);
+        d[4] = hw; d[5] = xcc; d[6] = tile_last; d[7] = (uint32_t)(end - start);
+      }
+#endif
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < nseg; k += BLOCK) {
+      seg_queue[2 * (s_base + k)] = (uint32_t)tile;
+      seg_queue[2 * (s_base + k) + 1] = k;
+    }
+  }
+  if (inside) {
+    const float Tf = sums.Tf;
+    const size_t Pn = (size_t)c.H * c.W;
+    const size_t pix_i = (size_t)pyi * c.W + pxi;
+    final_T[pix_i] = Tf;
+    n_contrib[pix_i] = sums.last;
+    out_color[pix_i] = sums.acc[0] + Tf * c.bg[0];
+    out_color[Pn + pix_i] = sums.acc[1] + Tf * c.bg[1];
+    out_color[2 * Pn + pix_i] = sums.acc[2] + Tf * c.bg[2];
+    out_depth[pix_i] = sums.acc[3];
+    out_normal[pix_i] = sums.acc[4];
+    out_normal[Pn + pix_i] = sums.acc[5];
+    out_normal[2 * Pn + pix_i] = sums.acc[6];
+    out_alpha[pix_i] = 1.0f - Tf;
+    if (out_extra) out_extra[pix_i] = sums.acc[7];
+    if (AUX) {
+      out_aux[pix_i] = sums.xacc[0] + Tf * c.bg[0];
+      out_aux[Pn + pix_i] = sums.xacc[1] + Tf * c.bg[1];
+      out_aux[2 * Pn + pix_i] = sums.xacc[2] + Tf * c.bg[2];
     }
   }
 }
@@ -586,11 +1041,37 @@ int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t*
                          const float* rec2d, uint32_t* n_contrib, float* final_T, float* out_color,
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
                          const float* aux_colors, float* out_aux, uint32_t* seg_queue, uint32_t* seg_count,
-                         float* seg_state, uint32_t* tile_rounds, hipStream_t s) {
+                         float* seg_state, uint32_t* tile_rounds, uint32_t* tile_sync, uint32_t* seg_flag,
+                         uint32_t* walk_hints, hipStream_t s) {
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
+  // INSTAG_BLEND_FWD=tile: the one-workgroup-per-tile kernel (A/B; also what runs when nothing cleared the claim words)
+  static const bool by_segment = [] { const char* e = getenv("INSTAG_BLEND_FWD"); return !(e && strcmp(e, "tile") == 0); }();
   { ProfScope calibration(K_EMPTY_BRACKET, s); }
   ProfScope p(K_BLEND_FWD, s);
+  if (by_segment && tile_sync != nullptr) {
+    // helper workgroups (behind the tiles' own in dispatch order) only with walk hints
+    // INSTAG_BLEND_FWD_SHARE_ALL=1 (tests): helpers for every tile of three or more segments, with or without hints
+    const char* e_all = getenv("INSTAG_BLEND_FWD_SHARE_ALL");
+    const int share_all = (e_all && e_all[0] == '1') ? 1 : 0;
+#ifdef FWD_NO_HELP
+    walk_hints = nullptr;
+#endif
+    const int grid = (walk_hints || share_all) ? tiles * (1 + FWD_HELPERS) : tiles;
+    uint32_t* stalls = sort_stalls_device_ptr();
+    if (aux_colors)
+      blend_forward_claim_kernel<true><<<grid, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
+                                                              out_depth, out_normal, out_alpha, out_extra, aux_colors,
+                                                              out_aux, seg_queue, seg_count, seg_state, tile_rounds,
+                                                              tile_sync, seg_flag, walk_hints, stalls, tiles, share_all);
+    else
+      blend_forward_claim_kernel<false><<<grid, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
+                                                               out_depth, out_normal, out_alpha, out_extra, nullptr,
+                                                               nullptr, seg_queue, seg_count, seg_state, tile_rounds,
+                                                               tile_sync, seg_flag, walk_hints, stalls, tiles, share_all);
+    INSTAG_CHECK_LAUNCH();
+    return INSTAG_OK;
+  }
   if (aux_colors)
     blend_forward_kernel<true><<<tiles, BLOCK, 0, s>>>(c, ranges, point_list, rec2d, n_contrib, final_T, out_color,
                                                        out_depth, out_normal, out_alpha, out_extra, aux_colors, out_aux,
@@ -642,3 +1123,9 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
 }
 
 }  // namespace instag
+
+#ifdef BLEND_DBG
+extern "C" int instag_debug_blend_timing(uint32_t* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(instag::g_blend_dbg), sizeof(uint32_t) * (size_t)n_words);
+}
+#endif

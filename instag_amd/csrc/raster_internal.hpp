@@ -57,6 +57,7 @@ int launch_radix_pass(int ipt, bool has_values, bool write_keys, const uint32_t*
                       uint32_t* lookback, hipStream_t s, uint64_t* stamps = nullptr);
 int read_sort_stalls(uint32_t* host_out, hipStream_t s, bool synchronize);
 int clear_sort_stalls(hipStream_t s);
+uint32_t* sort_stalls_device_ptr();
 int launch_hist_reduce(const uint32_t* partials, int nblk, int npass, int slices, uint32_t* out, hipStream_t s);
 int launch_scan_counts(int N, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* point_offsets,
                        uint64_t* state, hipStream_t s);
@@ -71,7 +72,8 @@ int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t*
                          const float* rec2d, uint32_t* n_contrib, float* final_T, float* out_color,
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
                          const float* aux_colors, float* out_aux, uint32_t* seg_queue, uint32_t* seg_count,
-                         float* seg_state, uint32_t* tile_rounds, hipStream_t s);
+                         float* seg_state, uint32_t* tile_rounds, uint32_t* tile_sync /* zeroed, or NULL */,
+                         uint32_t* seg_flag /* zeroed */, uint32_t* walk_hints /* persistent, or NULL */, hipStream_t s);
 int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
                           const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,

@@ -406,6 +406,20 @@ int read_sort_stalls(uint32_t* host_out, hipStream_t s, bool synchronize) {
   return INSTAG_OK;
 }
 
+uint32_t* sort_stalls_device_ptr() {
+  // (other kernels of the rasterizer that wait for a neighbour -- the segment-wise forward blend -- count into the same
+  // sticky word; the address is looked up once per device, outside any capture: warm-up calls come first)
+  static uint32_t* cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (cached[dev] == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sort_stalls)) != hipSuccess) return nullptr;
+    cached[dev] = (uint32_t*)p;
+  }
+  return cached[dev];
+}
+
 int clear_sort_stalls(hipStream_t s) {
   const uint32_t zero = 0;
   INSTAG_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_sort_stalls), &zero, sizeof(uint32_t), 0, hipMemcpyHostToDevice, s));

@@ -49,6 +49,26 @@ def flush_async(device):
     _STATE["forked"].add(key)
 
 
+_MILESTONES = {}
+
+
+def on_milestone(name, fn):
+    """Run ``fn()`` once, when the backward pass reaches ``milestone(name)`` (right after that operator's backward
+    kernel was enqueued; the current stream is the operator's).  A trainer forks side work there that must not start
+    earlier -- e.g. an optimizer launch that would otherwise share the chip with the largest MLP backward."""
+    _MILESTONES[name] = fn
+
+
+def clear_milestones():
+    _MILESTONES.clear()
+
+
+def milestone(name):
+    fn = _MILESTONES.pop(name, None)
+    if fn is not None:
+        fn()
+
+
 def active() -> bool:
     return _STATE["active"]
 

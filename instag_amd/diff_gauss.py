@@ -70,6 +70,9 @@ class CapacityPlan:
         self.capacities = [int(c) for c in capacities]
         self._all = torch.zeros(len(self.capacities), 4, dtype=torch.int32, device=device)
         self.status = [self._all[k] for k in range(len(self.capacities))]       # views: one copy reads every slot
+        # per slot: how far every tile's walk went in the slot's previous call (instag_raster_args.walk_hints) -- the
+        # forward blend starts helper workgroups for the tiles that walked far; up to 16,384 tiles (2048 x 2048 pixels)
+        self.walk_hints = [torch.zeros(16384, dtype=torch.int32, device=device) for _ in self.capacities]
         self.index = 0
         self._host = None
         self._event = None
@@ -82,7 +85,7 @@ class CapacityPlan:
             raise RuntimeError("CapacityPlan: more rasterizer calls in a step than planned capacities")
         k = self.index
         self.index += 1
-        return self.capacities[k], self.status[k]
+        return self.capacities[k], self.status[k], self.walk_hints[k]
 
     def overflowed(self):
         """Host check (synchronises): list of (slot, largest R needed) of every slot whose capacity was exceeded by ANY
@@ -197,7 +200,9 @@ def rasterize_forward(settings, means3D, shs, colors, opac, scales, rots, cov3D,
     extra_img = torch.empty(E, H, W, dtype=torch.float32, device=dev)
     aux_img = torch.empty(3, H, W, dtype=torch.float32, device=dev) if aux_colors is not None else None
     if _CAPACITY_PLAN is not None:
-        R, status = _CAPACITY_PLAN.next_slot()
+        R, status, hints = _CAPACITY_PLAN.next_slot()
+        if ((H + 15) // 16) * ((W + 15) // 16) <= hints.numel():
+            a.walk_hints = ptr(hints)
         binning = torch.empty(L.instag_raster_binning_bytes(R, H, W), dtype=torch.uint8, device=dev)
         check(L.instag_raster_forward_capacity(C.byref(a), ptr(geom), geom.numel(), ptr(binning), binning.numel(),
                                                ptr(image), image.numel(), R, ptr(radii), ptr(status), ptr(color),
@@ -254,7 +259,7 @@ def join_pending_aux(final: bool = False):
         while _PENDING_AUX:
             entry = _PENDING_AUX.pop()
             leaf, m2d_aux = entry["leaf"], entry["m2d_aux"]
-            if FOLD_AUX_M2D and leaf.grad is not None:
+            if FOLD_AUX_M2D and (leaf.grad is not None or FOLD_AUX_M2D == "always"):
                 _FOLDED.append((leaf, m2d_aux))          # the caller adds it (take_folded_aux)
             else:
                 leaf.grad = m2d_aux if leaf.grad is None else leaf.grad.add_(m2d_aux)
@@ -263,6 +268,7 @@ def join_pending_aux(final: bool = False):
 # A trainer whose next launch after backward reads means2D.grad anyway (the densification statistics) may take the aux
 # image's share from here and add it in that launch (glue.densify_stats(grad_add=...)) instead of paying an elementwise
 # launch on the tail of the step: set FOLD_AUX_M2D around backward, call take_folded_aux(leaf) right after it.
+# ("always": also when the leaf has no .grad at that point -- its gradient was asked for with torch.autograd.grad.)
 FOLD_AUX_M2D = False
 _FOLDED = []
 

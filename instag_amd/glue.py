@@ -131,6 +131,7 @@ class _GlueSigma(torch.autograd.Function):
                                          ptr(d_enc_x), ptr(d_aud), ptr(d_eye), ptr(parts), N, H, O,
                                          _lib.current_stream()), "mlp_backward_glue")
         _mlp.STATS["bwd_flops"] += 2 * N * (H * O + H * H + (KX + KA + KE) * H)
+        deferred.milestone("sigma_backward")
         d_vec = _column_sums(parts, ctx.frame_stream, dev)
         virt = (aud, eye_pre, enc_a, enc_e) if ctx.virtual else None
         grads = [None, None, None]

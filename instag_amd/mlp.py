@@ -174,6 +174,7 @@ class _SharedInputMLPs(torch.autograd.Function):
                                          ptr(wb2), ptr(dz1a), ptr(dz1b), ptr(dx), ptr(add) if want_dx else None,
                                          N, K0, HA, OA, HB, OB, stream), "mlp2_backward")
             STATS["bwd_flops"] += 2 * N * (HA * OA + HB * OB + (K0 * (HA + HB) if want_dx else 0))
+            deferred.milestone("heads_backward")
             add = dx if want_dx else add
             jobs = [(dz1a, x, 1, (HA, K0)), (dya, a1a, 2, (OA, HA)), (dz1b, x, 3, (HB, K0)), (dyb, a1b, 4, (OB, HB))]
         for k, dy in enumerate(() if fused else (dya, dyb)):

@@ -40,6 +40,7 @@ class MultiTensorAdam:
         self._dev = None
         self._step = None
         self._layout_key = None
+        self._partition = None
 
     # ---- torch.optim surface ----------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
@@ -104,6 +105,12 @@ class MultiTensorAdam:
                                "capturing step() into a graph")
         # static part: chunk table, group table, pinned staging buffers
         chunks = [(ti, c) for ti, t in enumerate(tensors) for c in range((t[0].numel() + chunk - 1) // chunk)]
+        self._n_late_chunks = len(chunks)
+        if self._partition is not None:
+            # step(part): "late" tensors' chunks first, "early" ones behind them -- each part is one range of the table
+            early = [bool(self._partition(t[0])) for t in tensors]
+            chunks = [c for c in chunks if not early[c[0]]] + [c for c in chunks if early[c[0]]]
+            self._n_late_chunks = sum(1 for c in chunks if not early[c[0]])
         self._chunks = torch.tensor(chunks, dtype=torch.int32, device=dev).contiguous()
         garr = np.zeros(len(self.param_groups), dtype=_GROUP_DT)
         for i, g in enumerate(self.param_groups):
@@ -143,7 +150,9 @@ class MultiTensorAdam:
             self._layout(tensors)
 
     @torch.no_grad()
-    def step(self):
+    def step(self, part=None):
+        """``part`` (with a ``partition`` set): "early" / "late" steps only the tensors the partition function sends
+        there -- a step as two launches at different points of the backward pass; both parts together are one step()."""
         L = _lib.lib()
         tensors = self._gather()
         if not tensors:
@@ -154,12 +163,19 @@ class MultiTensorAdam:
             gh = self._grads_host
             for i, t in enumerate(tensors):
                 gh[i] = 0 if t[1] is None else t[1].data_ptr()
-            # (one launch: the kernel counts the steps itself)
+            first, count = 0, self._chunks.shape[0]
+            if part is not None:
+                assert self._partition is not None and part in ("early", "late")
+                first, count = (0, self._n_late_chunks) if part == "late" else \
+                    (self._n_late_chunks, count - self._n_late_chunks)
+            # (one launch: the kernel counts the steps itself, per tensor)
             check(L.instag_adam_step_grads_ticketed(ptr(self._tensors_dev), gh.ctypes.data, len(tensors),
-                                                    ptr(self._groups_dev), ptr(self._lr_dev), ptr(self._chunks),
-                                                    self._chunks.shape[0], ptr(self._step), ptr(self._tickets),
-                                                    _lib.current_stream()), "adam_step")
+                                                    ptr(self._groups_dev), ptr(self._lr_dev),
+                                                    self._chunks.data_ptr() + 8 * first, count, ptr(self._step),
+                                                    ptr(self._tickets), _lib.current_stream()), "adam_step")
             return
+        if part is not None:
+            raise RuntimeError("MultiTensorAdam.step(part): more tensors than one launch's gradient table holds")
         tarr = self._tensors_host.numpy().view(_TENSOR_DT)
         for i, (p, grad, m, v, gi) in enumerate(tensors):
             tarr[i] = (p.data_ptr(), 0 if grad is None else grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), gi, 0)
@@ -212,11 +228,13 @@ class CombinedAdam(MultiTensorAdam):
     ``motion_optimizer`` back to back, train_face.py:781-788).  The member optimizers keep their own ``param_groups``
     and ``state`` (densify / prune / lr schedules keep working on them); this object only steps them together."""
 
-    def __init__(self, optimizers):
+    def __init__(self, optimizers, partition=None):
+        """``partition(param) -> bool``: True = the parameter belongs to step("early"), False to step("late")."""
         self.optimizers = list(optimizers)
         self._dev = None
         self._step = None
         self._layout_key = None
+        self._partition = partition
 
     @property
     def param_groups(self):

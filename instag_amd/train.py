@@ -320,11 +320,15 @@ class FaceTrainer:
             from .optim import CombinedAdam, MultiTensorAdam
             if isinstance(self.g.optimizer, MultiTensorAdam):
                 # one launch steps both optimizers (train_face.py:781-788 steps them back to back)
-                self._combined = CombinedAdam([self.motion_optimizer, self.g.optimizer])
+                # step("early") / step("late") = the same step as two launches (GraphedStep's single-graph form): the
+                # per-Gaussian parameters whose gradients are final when the backward pass reaches the motion fields
+                # (_forward_backward_cut) are stepped beside the rest of the pass, positions and networks behind it
+                early = lambda q: any(q is v for k, v in self.g._p.items() if k != "xyz")
+                self._combined = CombinedAdam([self.motion_optimizer, self.g.optimizer], partition=early)
 
-    def _step_optimizers(self):
+    def _step_optimizers(self, part=None):
         if self._combined is not None:
-            self._combined.step()
+            self._combined.step(part)
         else:
             self.motion_optimizer.step()
             self.g.optimizer.step()
@@ -420,7 +424,7 @@ class FaceTrainer:
             pkg["_m2d_aux"] = diff_gauss.take_folded_aux(pkg["viewspace_points"])
         return pkg, loss, Ll1
 
-    def _forward_backward_cut(self, frame: Frame, phase: FacePhase = C3_PHASE):
+    def _forward_backward_cut(self, frame: Frame, phase: FacePhase = C3_PHASE, fold_aux: bool = False):
         """The step's forward and the FIRST part of its backward: from the loss through the loss block, the rasterizer
         and the deform operator -- up to the tensors render_motion names as the cut (the motion fields' head outputs,
         the routed position, the attention colours).  Afterwards the gradients of every per-Gaussian parameter except
@@ -454,6 +458,7 @@ class FaceTrainer:
         early = [q for k, q in self.g._p.items() if k != "xyz" and q.requires_grad]
         if getattr(self, "_one", None) is None:
             self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        diff_gauss.FOLD_AUX_M2D = "always" if fold_aux else False    # (see _forward_backward)
         try:
             with deferred_grads(self.device):
                 got = torch.autograd.grad(loss, cut + early + [vs], grad_outputs=self._one, allow_unused=True,
@@ -461,6 +466,10 @@ class FaceTrainer:
         except BaseException:
             diff_gauss.reset_aux_state()
             raise
+        finally:
+            diff_gauss.FOLD_AUX_M2D = False
+        if fold_aux:
+            pkg["_m2d_aux"] = diff_gauss.take_folded_aux(vs)
         g_cut, g_early, g_vs = got[:len(cut)], got[len(cut):len(cut) + len(early)], got[-1]
         have = []
         for q, gq in zip(early, g_early):
@@ -796,6 +805,8 @@ class GraphedStep:
         # on every rank -- takes the two-graph form)
         self.early = split_for_allreduce == "early" and bool(phase.align)
         self.split = bool(split_for_allreduce)
+        self.early_optimizer = (not self.split and bool(phase.align) and t._combined is not None
+                                and os.environ.get("INSTAG_EARLY_OPTIMIZER", "0") == "1")
         self.static = example.clone_static()
         cold = warmup_steps > 0
         if cold:
@@ -854,7 +865,42 @@ class GraphedStep:
             self.graph_a.enable_debug_mode()
         self.plan.begin_step()
         self.graph_a2 = None
-        if not self.split:
+        # single graph, optimizers in two launches (INSTAG_EARLY_OPTIMIZER=1, off by default): statistics and the
+        # per-Gaussian parameters except the positions (20 of 24 floats per Gaussian) on a side stream beside the motion
+        # fields' backward, positions + networks behind it.  The last launch of the step shrinks from 24 to 15 us, but
+        # whatever the side launches run beside pays for it (sigma_net's backward 64 -> 73 us): no gain measured from
+        # any fork point
+        if self.early_optimizer:
+            side = _lib.side_stream(dev, "early_optimizer")
+            with _no_gc(cold), _lib.graph_capture(self.graph_a, **mode):
+                main = torch.cuda.current_stream(dev)
+                pkg, loss, l1, early, finish = t._forward_backward_cut(self.static, phase, fold_aux=True)
+
+                def early_launches():
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side), torch.no_grad():
+                        t._update_stats(pkg["viewspace_points"].grad, pkg["radii"], dict.get(pkg, "_m2d_aux"))
+                        t._step_optimizers("early")
+
+                # where the side launches start: beside the largest MLP's backward they cost it 9 us and take 65 us
+                # themselves (24 alone); behind it they run beside the heads' and the encoder's backward
+                at = os.environ.get("INSTAG_EARLY_OPTIMIZER_AT", "sigma_backward")
+                from . import deferred
+                if at == "cut":
+                    early_launches()
+                else:
+                    deferred.on_milestone(at, early_launches)
+                try:
+                    finish()
+                    deferred.milestone(at)          # (an operator path without that milestone: launch now)
+                finally:
+                    deferred.clear_milestones()
+                main.wait_stream(side)
+                with torch.no_grad():
+                    t._step_optimizers("late")
+                t._zero_grad()
+            del pkg, finish
+        elif not self.split:
             with _no_gc(cold), _lib.graph_capture(self.graph_a, **mode):
                 pkg, loss, l1 = t._forward_backward(self.static, phase, fold_aux=True)
                 t._stats_and_optimizers(pkg, False)

@@ -8,6 +8,6 @@ for setting in "$@"; do
 import json, sys
 d = json.loads(sys.argv[2])
 k = d["kernels_us"]
-print(f"{sys.argv[1]:45s} ms/step {d['ms_per_step']:.4f}  windows {d['windows_ms_per_step']}  mlp_bwd {k.get('mlp_bwd')} wgrad {k.get('mlp_wgrad')} grid_bwd {k.get('grid_bwd')} blend_fwd {k.get('blend_fwd')}")
+print(f"{sys.argv[1]:45s} ms/step {d['ms_per_step']:.4f}  windows {d['windows_ms_per_step']}  mlp_bwd {k.get('mlp_bwd')} wgrad {k.get('mlp_wgrad')} grid_bwd {k.get('grid_bwd')} blend_fwd {k.get('blend_fwd')} replay: {d['roofline'].get('kernel')} {d['roofline'].get('avg_launch_us')}")
 PY
 done

@@ -6,7 +6,10 @@ d = sys.argv[1]
 f = (glob.glob(f'{d}/*/*_kernel_trace.csv') + glob.glob(f'{d}/*_kernel_trace.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-ends = [i for i, r in enumerate(rows) if 'adam_step' in r['Kernel_Name']]
+# a step ends with its LAST optimizer launch: the one that no kernel of the same step follows (the next step begins with
+# the frame's copy; a step in two optimizer launches has the first one in the middle of the backward pass)
+ends = [i for i, r in enumerate(rows) if 'adam_step' in r['Kernel_Name']
+        and (i + 1 == len(rows) or 'copyBuffer' in rows[i + 1]['Kernel_Name'])]
 prev, info = -1, []
 for k, e in enumerate(ends):
     sub = rows[prev + 1:e + 1]; prev = e

@@ -26,8 +26,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from instag_amd._lib import RasterArgs
-    # 11 x 4-byte scalars (44 B) padded to 48, then 13 pointers (the last one: shs_rest)
-    assert ctypes.sizeof(RasterArgs) == 48 + 13 * 8
+    # 11 x 4-byte scalars (44 B) padded to 48, then 14 pointers (the last two: shs_rest, walk_hints)
+    assert ctypes.sizeof(RasterArgs) == 48 + 14 * 8
     assert RasterArgs.bg.offset == 48 and RasterArgs.extra_attrs.offset == 48 + 11 * 8
 
 

@@ -296,7 +296,7 @@ def test_capacity_mode_matches_sync_mode():
             assert all(torch.isfinite(v.grad).all() for v in inp.values() if v is not None and v.grad is not None)
 
 
-def test_graphed_train_step_matches_eager():
+def test_graphed_train_step_matches_eager(monkeypatch):
     """The hipGraph-replayed train step performs the same arithmetic as the eager step."""
     from instag_amd import diff_gauss
     from instag_amd.scene_synth import synthetic_frame, toy_cameras
@@ -306,8 +306,11 @@ def test_graphed_train_step_matches_eager():
     frames = [make_frame(cams[i].to(dev), synthetic_frame(128, i, dev)) for i in range(3)]
     losses = {}
     params = {}
-    for mode in ("eager", "graph", "graph-split", "graph-early"):
+    for mode in ("eager", "graph", "graph-two-optimizer-launches", "graph-split", "graph-early"):
         tr = build_trainer(3000, dev, seed=1)
+        # "graph-two-optimizer-launches": one graph, statistics + the optimizer step of SH / opacity / scale / rotation
+        # on a side stream beside the motion fields' backward, positions + networks at the end (off by default)
+        monkeypatch.setenv("INSTAG_EARLY_OPTIMIZER", "1" if mode == "graph-two-optimizer-launches" else "0")
         try:
             if mode != "eager":
                 # 2 eager + 2 capacity-mode steps on frame 0; "graph-split" = the two-graph form used with several
@@ -315,7 +318,8 @@ def test_graphed_train_step_matches_eager():
                 # three-graph form whose first bucket (SH, opacity, scale, rotation gradients, final before the motion
                 # fields' backward runs) is exchanged beside that backward
                 tr.enable_graph(frames[0], warmup_steps=2,
-                                split_for_allreduce={"graph": False, "graph-split": True, "graph-early": "early"}[mode])
+                                split_for_allreduce={"graph-split": True, "graph-early": "early"}.get(mode, False))
+                assert tr._graph.early_optimizer == (mode == "graph-two-optimizer-launches")
                 if mode == "graph-early":
                     g = tr._graph
                     assert g.graph_a2 is not None and g.graph_b is not None
@@ -336,7 +340,7 @@ def test_graphed_train_step_matches_eager():
         losses[mode] = ls
         params[mode] = tr.g.get_xyz.detach().clone()
     assert tr.iteration == 10
-    for mode in ("graph", "graph-split", "graph-early"):
+    for mode in ("graph", "graph-two-optimizer-launches", "graph-split", "graph-early"):
         for a_, b_ in zip(losses["eager"], losses[mode]):
             assert abs(a_ - b_) <= 1e-5 * max(1.0, abs(a_)), (mode, losses["eager"], losses[mode])
         assert float((params["eager"] - params[mode]).abs().max()) <= 1e-5
@@ -649,13 +653,17 @@ def test_full_c3_train_step_100k_512():
     assert float((params["eager"] - params["graph"]).abs().max()) <= 1e-5
 
 
-def test_long_walks_cross_many_segments():
-    """Dense, faint scene on a small image: the tiles' lists are thousands of entries long and rays walk far beyond one
+@pytest.mark.parametrize("shared", [False, True], ids=["own-workgroup", "shared-tiles"])
+def test_long_walks_cross_many_segments(shared, monkeypatch):
+    """(shared-tiles: every tile of three or more segments is walked by four workgroups claiming segments, the form
+    the forward blend uses for tiles that walked far in the previous call of a captured step.)
+    Dense, faint scene on a small image: the tiles' lists are thousands of entries long and rays walk far beyond one
     128-entry segment, so the backward pass starts most of its workgroups from the per-segment state the forward pass
     left behind (csrc/raster_blend.hip: seg_state) -- every gradient against the fp64 oracle, with the same bars as
     test_backward_gradients."""
     from instag_amd import diff_gauss
     from oracle import rasterize_ref as R
+    monkeypatch.setenv("INSTAG_BLEND_FWD_SHARE_ALL", "1" if shared else "0")
     n, size = 12000, 96
     a, settings = make_scene(n, size, sh_degree=1, seed=11)
     a["opacities"] = a["opacities"] * 0.12            # faint: a ray needs hundreds of Gaussians to saturate
@@ -681,6 +689,37 @@ def test_long_walks_cross_many_segments():
             assert (h.detach().cpu().double() - o.detach()).abs().max().item() <= 1e-5, name
     for k in ("means3D", "means2D", "opacities", "extra", "shs", "scales", "rotations"):
         _grad_check(inp_o[k].grad, inp_h[k].grad, k, "long-walks")
+
+
+def test_shared_tiles_give_the_same_bits(monkeypatch):
+    """A tile walked by its own workgroup and the same tile shared between four workgroups (segments claimed in order,
+    transmittance-only passes where a predecessor is not posted yet, one workgroup adding the segments up): the images,
+    the per-pixel state and every gradient bit for bit -- the arithmetic is per segment and does not depend on who
+    computed what (csrc/raster_blend.hip: blend_forward_claim_kernel)."""
+    from instag_amd import diff_gauss
+    results = []
+    for shared in ("0", "1", "1"):
+        monkeypatch.setenv("INSTAG_BLEND_FWD_SHARE_ALL", shared)
+        a, settings = make_scene(12000, 96, sh_degree=1, seed=11)
+        a["opacities"] = a["opacities"] * 0.12
+        diff_gauss.KEEP_LAST_STATE = True
+        try:
+            outs, inp = run_hip(a, settings)
+            state = diff_gauss.debug_export(diff_gauss.LAST_STATS.pop("state"))
+        finally:
+            diff_gauss.KEEP_LAST_STATE = False
+        g = torch.Generator().manual_seed(2)
+        sum((o * torch.randn(o.shape, generator=g).cuda()).sum() for o in outs if o.is_floating_point()).backward()
+        results.append(([o.detach().clone() for o in outs], state["n_contrib"].clone(),
+                        {k: v.grad.clone() for k, v in inp.items() if v is not None and v.grad is not None}))
+    assert diff_gauss.sort_stalls() == 0
+    for other in results[1:]:
+        for x, y in zip(results[0][0], other[0]):
+            assert torch.equal(x, y)
+        assert torch.equal(results[0][1], other[1])
+        assert results[0][2].keys() == other[2].keys()
+        for k in results[0][2]:
+            assert torch.equal(results[0][2][k], other[2][k]), k
 
 
 def test_second_backward_and_masked_gradient_reuse_the_state():
