@@ -116,8 +116,8 @@ struct BinningLayout {
   // gradient rows a backward blend wrote (two sets: the main and the auxiliary pass may run side by side); the
   // reducing kernel clears what it consumes.  seg_count and row_flag follow tsort_zero and are cleared with it.
   size_t seg_state, seg_slots, seg_queue, seg_count, row_flag, row_flag_stride;
-  // segment-wise forward blend: per tile {next segment to claim, segments walked, ~(first finished segment), resolved},
-  // per segment slot a "posted" flag -- both inside the region the duplicate kernel clears
+  // segment-wise forward blend: per tile 8 words {next segment to claim, segments walked, ~(first finished segment),
+  // resolved, helpers joined, -, -, -}, per segment slot a "posted" flag -- both inside the region the duplicate kernel clears
   size_t fwd_sync, seg_flag;
   size_t total;
 };

@@ -216,12 +216,12 @@ BinningLayout binning_layout(int64_t R, int32_t H, int32_t W) {
   const size_t sort_words = 16 + (size_t)3 * L.tsort_blocks * 256;
   L.row_flag_stride = align_up(r, 16);
   L.seg_slots = r / SEG_LEN + tiles + 2;
-  L.tsort_zero_words = sort_words + 4 + 2 * L.row_flag_stride / 4 + 4 * tiles + L.seg_slots;
+  L.tsort_zero_words = sort_words + 4 + 2 * L.row_flag_stride / 4 + 8 * tiles + L.seg_slots;
   L.tsort_zero = o;
   L.seg_count = o + sort_words * sizeof(uint32_t);
   L.row_flag = L.seg_count + 4 * sizeof(uint32_t);
   L.fwd_sync = L.row_flag + 2 * L.row_flag_stride;
-  L.seg_flag = L.fwd_sync + 4 * tiles * sizeof(uint32_t);
+  L.seg_flag = L.fwd_sync + 8 * tiles * sizeof(uint32_t);
   o = align_up(o + L.tsort_zero_words * sizeof(uint32_t), 256);
   L.tsort_digit_base = o; o = align_up(o + (size_t)HIST_SLICES * 3 * 256 * sizeof(uint32_t), 256);
   L.tsort_partials = o; o = align_up(o + (size_t)1024 * 3 * 256 * sizeof(uint32_t), 256);

@@ -275,8 +275,14 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
 // transmittance-only pass (no colours, no stop rule: 0.6 of a walk), posts t_seg, waits for the predecessors' posts --
 // their owners are running and wait for nothing themselves -- and walks again with P known.  A tile nobody helps with
 // is therefore walked exactly once, as before; results are bit-identical whoever takes part.
-constexpr int FWD_HELPERS = 3;            // helper workgroups per tile in a launch with walk hints
-constexpr uint32_t FWD_LONG_SEGS = 3;     // a tile that walked this many segments lately gets helpers
+#ifndef FWD_HELPERS_N
+#define FWD_HELPERS_N 3
+#endif
+#ifndef FWD_LONG_SEGS_N
+#define FWD_LONG_SEGS_N 3
+#endif
+constexpr int FWD_HELPERS = FWD_HELPERS_N;            // helper workgroups per tile in a launch with walk hints
+constexpr uint32_t FWD_LONG_SEGS = FWD_LONG_SEGS_N;     // a tile that walked this many segments lately gets helpers
 constexpr uint32_t FWD_HINT_UNIT = 8;     // walk hints are kept in 1/8 segments (they decay by one unit per call)
 constexpr int SYNC_CLAIM = 0, SYNC_DONE = 1, SYNC_INV_DEAD = 2, SYNC_RESOLVED = 3;
 
@@ -295,6 +301,15 @@ __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) {
 }
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Before a flag or a count tells other workgroups that this one's stores are there: every wave waits for the
+// acknowledgement of its own (write-through) stores, then the workgroup meets.  __syncthreads() alone does not wait
+// for outstanding global stores -- a flag written after it can overtake them (seen: a captured step whose loss differed
+// from the eager one in the fifth digit once in a few steps).
+__device__ __forceinline__ void fwd_publish_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 __device__ __forceinline__ void chain_step(float& P, bool& alive, float tseg) {
@@ -327,7 +342,11 @@ __device__ __forceinline__ void fold_segment(FwdSums& r, int q, float T_after, c
 }
 
 template <bool AUX>
+#ifdef FWD_NOCAP
+__global__ void __launch_bounds__(BLOCK)
+#else
 __global__ void __launch_bounds__(BLOCK, 4)           // (<= 128 registers: four workgroups per CU, every tile's own one resident)
+#endif
 blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                            const float* __restrict__ rec2d, uint32_t* __restrict__ n_contrib,
                            float* __restrict__ final_T, float* __restrict__ out_color,
@@ -358,7 +377,7 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
   // direct: the tile has no helpers -- its workgroup walks the segments in order without claims, flags or a second look
   // at what it stored (the same arithmetic, segment by segment, as the tiles that are shared)
   const bool direct = !(helped && nsegs >= (int)FWD_LONG_SEGS);
-  uint32_t* sync = tile_sync + 4 * (size_t)tile;
+  uint32_t* sync = tile_sync + 8 * (size_t)tile;
   if (helper && direct) return;
   if (direct && walk_hints != nullptr && tid == 0) {
     // This workgroup writes the new hint when it is done; a helper that starts after that reads the NEW value and may
@@ -468,7 +487,7 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
         }
       }
       st_agent(&st[12 * TILE_PIX], t);
-      __syncthreads();                                 // (every wave's stores have been acknowledged)
+      fwd_publish_barrier();
       if (tid == 0) {
         st_agent(&seg_flag[slot], 1u);
         // the predecessors' owners are running and wait for nothing: their posts come (bounded all the same)
@@ -599,7 +618,7 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
     st_agent(&st[13 * TILE_PIX], __uint_as_float(alive ? last_local : 0u));
     chain_step(P, alive, tseg);
     known = seg + 1;
-    __syncthreads();                                   // (every wave's stores have been acknowledged)
+    fwd_publish_barrier();
     if (tid == 0) {
       if (all_posted) st_agent(&seg_flag[slot], 1u);
       atomicAdd(&sync[SYNC_DONE], 1u);
@@ -610,6 +629,9 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
     // ---- whoever finds the tile complete (every segment in front of the first finished one walked) adds it up -----
     __syncthreads();
     if (tid == 0) {
+      // (this workgroup's own count / end-of-walk updates have been performed before it looks at the others': of the
+      // two workgroups that make the tile complete, at least one then sees both updates)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const uint32_t done = atomicAdd(&sync[SYNC_DONE], 0u);
       const uint32_t dead = ~atomicMax(&sync[SYNC_INV_DEAD], 0u);
       s_word[0] = (done == dead && atomicCAS(&sync[SYNC_RESOLVED], 0u, 1u) == 0u) ? 1u : 0u;
