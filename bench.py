@@ -40,7 +40,7 @@ NON_RASTER = ("grid_fwd", "grid_bwd", "mlp_fwd", "mlp_bwd", "mlp_wgrad", "empty_
 #   blend_bwd       colour pass, aux colours' gradient in idle GEMM columns  124 R + 44 P  
 #   blend_bwd_mean  the attention map's d/dmean pass: reads id 4 + xy 8 + conic, opacity 16 + aux colour 12, writes the
 #                   8-byte mean gradient per entry; per pixel dL/daux 12 + n_contrib 4 + final_T 4   48 R + 20 P
-BLEND_VARIANTS = {"blend_fwd": ("blend_forward_kernel<true>", 60, 44),
+BLEND_VARIANTS = {"blend_fwd": ("blend_forward_claim_kernel<true>", 60, 44),
                   "blend_bwd": ("blend_backward_kernel<false, 2, false>", 124, 44),
                   "blend_bwd_mean": ("blend_backward_kernel<false, 0, true>", 48, 20)}
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)

@@ -342,10 +342,12 @@ __device__ __forceinline__ void fold_segment(FwdSums& r, int q, float T_after, c
 }
 
 template <bool AUX>
-#ifdef FWD_NOCAP
-__global__ void __launch_bounds__(BLOCK)
+#ifdef FWD_CAP128
+__global__ void __launch_bounds__(BLOCK, 4)
 #else
-__global__ void __launch_bounds__(BLOCK, 4)           // (<= 128 registers: four workgroups per CU, every tile's own one resident)
+// (three workgroups per CU at ~140 registers.  Held to 128 -- four per CU, every tile's own workgroup resident from the
+// start -- the inner loop waits for its LDS reads one by one: 112 us against 104)
+__global__ void __launch_bounds__(BLOCK)
 #endif
 blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
                            const float* __restrict__ rec2d, uint32_t* __restrict__ n_contrib,
@@ -356,11 +358,15 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
                            uint32_t* __restrict__ seg_queue, uint32_t* __restrict__ seg_count,
                            float* seg_state, uint32_t* __restrict__ tile_rounds, uint32_t* tile_sync,
                            uint32_t* seg_flag, uint32_t* walk_hints, uint32_t* stalls, int ntiles, int share_all) {
-  __shared__ float4 s_geo[SEG_LEN];                // x y A' C'   (one LDS array per read of the inner loop, see above)
-  __shared__ float2 s_bo[SEG_LEN];                 // B' opacity
-  __shared__ float4 s_c0[SEG_LEN], s_c1[SEG_LEN];  // r g b depth | nx ny nz extra
-  __shared__ float4 s_c2[AUX ? SEG_LEN : 1];       // aux r g b -
+  // two sets of record arrays: an unshared tile's workgroup stages segment s + 1 into the other set while slower waves
+  // still read segment s -- ONE workgroup barrier per segment, and "is any pixel unfinished" rides on it (a flag per
+  // wave instead of __syncthreads_or: the voting barriers cost the short tiles 10 % of their walk)
+  __shared__ float4 s_geo[2 * SEG_LEN];            // x y A' C'   (one LDS array per read of the inner loop, see above)
+  __shared__ float2 s_bo[2 * SEG_LEN];             // B' opacity
+  __shared__ float4 s_c0[2 * SEG_LEN], s_c1[2 * SEG_LEN];  // r g b depth | nx ny nz extra
+  __shared__ float4 s_c2[AUX ? 2 * SEG_LEN : 1];   // aux r g b -
   __shared__ uint32_t s_word[2];
+  __shared__ uint32_t s_alive[2][BLOCK / 64];
   const int tid = threadIdx.x;
   // helpers have the LOWEST block numbers of a launch that has any: they are dispatched first and take their tiles'
   // first segments at once (most of them find their tile is not shared and leave)
@@ -431,7 +437,8 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
 
   for (int next_direct = 0;; ++next_direct) {
     int seg = next_direct;
-    __syncthreads();                                  // (s_word, the record arrays: the previous round is done with them)
+    const int lds0 = direct ? (seg & 1) * SEG_LEN : 0;
+    if (!direct) __syncthreads();                     // (s_word, the record arrays: the previous round is done with them)
     if (!direct) {
       if (tid == 0) {
         s_word[0] = atomicAdd(&sync[SYNC_CLAIM], 1u);
@@ -454,16 +461,22 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
     }
     if (fetched != seg) fetch(seg);
     if (tid < SEG_LEN) {
-      s_geo[tid] = nrec0; s_bo[tid] = make_float2(nrec1.x, nrec1.y);
-      s_c0[tid] = make_float4(nrec1.z, nrec1.w, nrec2.x, nrec2.y);
-      s_c1[tid] = make_float4(nrec2.z, nrec2.w, nrec3.x, nrec3.y);
-      if (AUX) s_c2[tid] = make_float4(nrec3.z, nrec3.w, nauxb, 0.f);
+      s_geo[lds0 + tid] = nrec0; s_bo[lds0 + tid] = make_float2(nrec1.x, nrec1.y);
+      s_c0[lds0 + tid] = make_float4(nrec1.z, nrec1.w, nrec2.x, nrec2.y);
+      s_c1[lds0 + tid] = make_float4(nrec2.z, nrec2.w, nrec3.x, nrec3.y);
+      if (AUX) s_c2[lds0 + tid] = make_float4(nrec3.z, nrec3.w, nauxb, 0.f);
     }
-    // are the segments in front of this one posted (those this workgroup has not folded into P yet)?
-    bool posted = true;
-    if (!direct)
+    bool all_posted = true;
+    if (direct) {
+      const uint32_t wave_alive = __builtin_amdgcn_ballot_w64(alive) != 0 ? 1u : 0u;   // (all lanes vote)
+      if ((tid & 63) == 0) s_alive[seg & 1][tid >> 6] = wave_alive;
+      __syncthreads();                                 // (the records are staged)
+    } else {
+      // are the segments in front of this one posted (those this workgroup has not folded into P yet)?
+      bool posted = true;
       for (int q = known + tid; q < seg; q += BLOCK) posted = posted && ld_agent(&seg_flag[slot0 + q]) != 0u;
-    const bool all_posted = __syncthreads_and(posted) != 0;     // (also: the records are staged)
+      all_posted = __syncthreads_and(posted) != 0;     // (also: the records are staged)
+    }
     fetch(seg + 1);
     const int groups = (min(SEG_LEN, end - start - seg * SEG_LEN) + 3) >> 2;
     float* st = seg_state + (size_t)slot * SLOT + tid;
@@ -475,8 +488,8 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
         for (int g = 0; g < groups; ++g) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float4 a = s_geo[4 * g + k];
-            const float2 b = s_bo[4 * g + k];
+            const float4 a = s_geo[lds0 + 4 * g + k];
+            const float2 b = s_bo[lds0 + 4 * g + k];
             const f32x2 d = f32x2{a.x, a.y} - pix_in;
             const f32x2 u = (d * f32x2{a.z, a.w}) * d;
             const float p2 = __builtin_fmaf(b.x, d.x * d.y, u.x + u.y);
@@ -509,7 +522,9 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
         chain_step(P, alive, ld_agent(seg_state + (size_t)(slot0 + q) * SLOT + 12 * TILE_PIX + tid));
       known = seg;
     }
-    if (__syncthreads_or(alive) == 0) {
+    const bool any_alive = direct ? (s_alive[seg & 1][0] | s_alive[seg & 1][1] | s_alive[seg & 1][2] | s_alive[seg & 1][3]) != 0u
+                                  : __syncthreads_or(alive) != 0;
+    if (!any_alive) {
       // every pixel finished in front of this segment: the tile's walk ends here (posted all the same, see above)
       if (!direct && tid == 0) {
         atomicMax(&sync[SYNC_INV_DEAD], ~(uint32_t)seg);
@@ -534,8 +549,8 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
       bool hit[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float4 a = s_geo[4 * g + k];
-        const float2 b = s_bo[4 * g + k];
+        const float4 a = s_geo[lds0 + 4 * g + k];
+        const float2 b = s_bo[lds0 + 4 * g + k];
         const f32x2 d = f32x2{a.x, a.y} - pix;
         const f32x2 u = (d * f32x2{a.z, a.w}) * d;
         const float p2 = __builtin_fmaf(b.x, d.x * d.y, u.x + u.y);
@@ -577,15 +592,15 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
       last_local = code ? (uint32_t)(4 * g) + code : last_local;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float4 c0 = s_c0[4 * g + k];
-        const float4 c1 = s_c1[4 * g + k];
+        const float4 c0 = s_c0[lds0 + 4 * g + k];
+        const float4 c1 = s_c1[lds0 + 4 * g + k];
         const f32x2 w2 = {w[k], w[k]};
         acc2[0] = __builtin_elementwise_fma(f32x2{c0.x, c0.y}, w2, acc2[0]);
         acc2[1] = __builtin_elementwise_fma(f32x2{c0.z, c0.w}, w2, acc2[1]);
         acc2[2] = __builtin_elementwise_fma(f32x2{c1.x, c1.y}, w2, acc2[2]);
         acc2[3] = __builtin_elementwise_fma(f32x2{c1.z, c1.w}, w2, acc2[3]);
         if (AUX) {
-          const float4 c2 = s_c2[4 * g + k];
+          const float4 c2 = s_c2[lds0 + 4 * g + k];
           xacc2 = __builtin_elementwise_fma(f32x2{c2.x, c2.y}, w2, xacc2);
           xacc3 = __builtin_elementwise_fma(f32x2{c2.z, c2.w}, w2, xacc3);
         }

@@ -102,7 +102,11 @@ def main():
         if not ls:
             continue
         deepest = max(d for _, d, _, _ in ls)
-        label, depth, a, b = [x for x in ls if x[1] == deepest][0]      # first innermost loop = the unrolled one
+        inner = [x for x in ls if x[1] == deepest]
+        # the walk: of the innermost loops that evaluate an exponential, the longest (the segment-wise forward kernel has
+        # a second, shorter one: its transmittance-only pass)
+        with_exp = [x for x in inner if any("v_exp_f32" in ln for ln in body[x[2]:x[3] + 1])] or inner[:1]
+        label, depth, a, b = max(with_exp, key=lambda x: sum(count(body, x[2], x[3]).values()))
         c = count(body, a, b)
         per = {k: round(v / PER_ITER, 2) for k, v in sorted(c.items())}
         per["all"] = round(sum(c.values()) / PER_ITER, 2)
