@@ -66,7 +66,10 @@ class MultiTensorAdam:
         """Push the groups' current python-float learning rates to the device (one small copy)."""
         if self._dev is None:
             return
-        host = self._lr_host
+        # a ring of pinned rows: the copy reads its row when it EXECUTES, and a host that replays captured steps runs a
+        # few steps ahead of the device -- one row would be overwritten with a later step's rates before it was read
+        self._lr_slot = (getattr(self, "_lr_slot", -1) + 1) % self._lr_host.shape[0]
+        host = self._lr_host[self._lr_slot]
         for i, g in enumerate(self.param_groups):
             host[i] = float(g["lr"])
         self._lr_dev.copy_(host, non_blocking=True)
@@ -118,7 +121,7 @@ class MultiTensorAdam:
         self._groups_dev = torch.from_numpy(garr.view(np.uint8).copy()).to(dev)
         self._tensors_host = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8).pin_memory()
         self._tensors_dev = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8, device=dev)
-        self._lr_host = torch.zeros(len(self.param_groups), dtype=torch.float32).pin_memory()
+        self._lr_host = torch.zeros(256, len(self.param_groups), dtype=torch.float32).pin_memory()
         self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
         # per-tensor step counters follow their parameter's state across re-layouts (densify / prune)
         steps = torch.zeros(len(tensors), dtype=torch.float32, device=dev)

@@ -49,10 +49,37 @@ def _settings(cam, pc, bg_color, scaling_modifier, debug=False):
         sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug)
 
 
+_ZEROS = {}
+
+
+def prepare_screenspace(pc):
+    """Allocate the zeros behind _screenspace_points for this Gaussian count now (a trainer calls it in front of a stream
+    capture: inside one, a first use could only allocate from the capture's pool and would be replayed as a fill)."""
+    xyz = pc.get_xyz
+    key = (xyz.device, xyz.shape[0], xyz.dtype)
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) >= 8:
+            _ZEROS.clear()               # (Gaussian counts of past density-control events)
+        z = _ZEROS[key] = torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device)
+    return z
+
+
 def _screenspace_points(pc):
     # gradient carrier of the screen-space means (gaussian_renderer/__init__.py:47-52 builds it as zeros + 0 with
-    # retain_grad(); a leaf receives the same .grad and saves a launch)
-    return torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True)
+    # retain_grad(); a leaf receives the same .grad and saves a launch).  Nothing reads or writes its VALUE -- the
+    # rasterizer takes it for the gradient's sake only -- so on the GPU every step's leaf is a fresh view of one zeroed
+    # buffer per Gaussian count instead of a fill launch at the head of the step (4 us + a launch gap on the chain)
+    xyz = pc.get_xyz
+    if not xyz.is_cuda:
+        return torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True)
+    key = (xyz.device, xyz.shape[0], xyz.dtype)
+    z = _ZEROS.get(key)
+    if z is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True)
+        z = prepare_screenspace(pc)
+    return z.detach().requires_grad_(True)
 
 
 def render(viewpoint_camera, pc, pipe=None, bg_color=None, scaling_modifier=1.0, override_color=None):

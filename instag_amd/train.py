@@ -829,6 +829,8 @@ class GraphedStep:
             assert min_capacity > 0, "a warm capture needs the capacity of an earlier one"
             cap = int(min_capacity)
             t._prepare_optimizers()          # tables of the new parameter set: allocations / uploads outside the capture
+            from . import renderer
+            renderer.prepare_screenspace(t.g)      # (likewise the zeros behind the screen-space gradient carrier)
         self.plan = diff_gauss.CapacityPlan([cap, cap], dev)
         self._replays = 0
         diff_gauss.set_capacity_plan(self.plan)
