@@ -415,7 +415,7 @@ static int forward_tail(const instag_raster_args* a, void* geom, size_t geom_byt
                               a->E > 0 ? out_extra : nullptr, aux_colors, out_aux, (uint32_t*)(bb + BL.seg_queue),
                               (uint32_t*)(bb + BL.seg_count), (float*)(bb + BL.seg_state),
                               (uint32_t*)(ib + IL.tile_rounds), R > 0 ? (uint32_t*)(bb + BL.fwd_sync) : nullptr,
-                              (uint32_t*)(bb + BL.seg_flag), a->walk_hints, s);
+                              (uint32_t*)(bb + BL.seg_flag), a->walk_hints, R, s);
 }
 
 int instag_raster_forward_stage2(const instag_raster_args* a, void* geom, size_t geom_bytes, void* binning,

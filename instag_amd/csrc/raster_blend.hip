@@ -1079,11 +1079,16 @@ int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t*
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
                          const float* aux_colors, float* out_aux, uint32_t* seg_queue, uint32_t* seg_count,
                          float* seg_state, uint32_t* tile_rounds, uint32_t* tile_sync, uint32_t* seg_flag,
-                         uint32_t* walk_hints, hipStream_t s) {
+                         uint32_t* walk_hints, int64_t instances, hipStream_t s) {
   const int tiles = c.grid_x * c.grid_y;
   if (tiles == 0) return INSTAG_OK;
-  // INSTAG_BLEND_FWD=tile: the one-workgroup-per-tile kernel (A/B; also what runs when nothing cleared the claim words)
-  static const bool by_segment = [] { const char* e = getenv("INSTAG_BLEND_FWD"); return !(e && strcmp(e, "tile") == 0); }();
+  // Which forward kernel: the segment-wise one pays where tiles walk far (its helpers cut those chains); on a small
+  // scene -- the mouth's 20k Gaussians -- every tile is short and its bookkeeping costs 5 %.  By the instance count, so
+  // that the eager and the captured form of one scene run the same arithmetic.  INSTAG_BLEND_FWD=tile / segment forces
+  // one (tests run both); the tile kernel also runs when nothing cleared the claim words (an empty frame).
+  const char* e_fwd = getenv("INSTAG_BLEND_FWD");
+  const bool by_segment = e_fwd && strcmp(e_fwd, "tile") == 0 ? false
+                          : e_fwd && strcmp(e_fwd, "segment") == 0 ? true : instances >= 500000;
   { ProfScope calibration(K_EMPTY_BRACKET, s); }
   ProfScope p(K_BLEND_FWD, s);
   if (by_segment && tile_sync != nullptr) {

@@ -73,7 +73,8 @@ int launch_blend_forward(const Camera& c, const int32_t* ranges, const uint32_t*
                          float* out_depth, float* out_normal, float* out_alpha, float* out_extra,
                          const float* aux_colors, float* out_aux, uint32_t* seg_queue, uint32_t* seg_count,
                          float* seg_state, uint32_t* tile_rounds, uint32_t* tile_sync /* zeroed, or NULL */,
-                         uint32_t* seg_flag /* zeroed */, uint32_t* walk_hints /* persistent, or NULL */, hipStream_t s);
+                         uint32_t* seg_flag /* zeroed */, uint32_t* walk_hints /* persistent, or NULL */,
+                         int64_t instances, hipStream_t s);
 int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t* point_list,
                           const uint32_t* slot_list, const float* rec2d, const uint32_t* n_contrib, const float* final_T,
                           const float* dL_dcolor, const float* dL_ddepth, const float* dL_dnormal,

@@ -121,6 +121,14 @@ def test_forward_images(n, size, deg):
         assert err <= 1e-4, f"{name}: max abs err {err}"
 
 
+@pytest.fixture(autouse=True, params=["tile", "segment"])
+def forward_blend_kernel(request, monkeypatch):
+    """Every test of this file runs with each of the two forward blend kernels forced (csrc/raster_blend.hip: by default
+    the instance count picks one)."""
+    monkeypatch.setenv("INSTAG_BLEND_FWD", request.param)
+    return request.param
+
+
 PARITY_LOG = {}
 
 
