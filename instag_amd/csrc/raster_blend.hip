@@ -276,7 +276,7 @@ blend_forward_kernel(Camera c, const int32_t* __restrict__ ranges, const uint32_
 // their owners are running and wait for nothing themselves -- and walks again with P known.  A tile nobody helps with
 // is therefore walked exactly once, as before; results are bit-identical whoever takes part.
 #ifndef FWD_HELPERS_N
-#define FWD_HELPERS_N 3
+#define FWD_HELPERS_N 6
 #endif
 #ifndef FWD_LONG_SEGS_N
 #define FWD_LONG_SEGS_N 3
@@ -368,11 +368,17 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
   __shared__ uint32_t s_word[2];
   __shared__ uint32_t s_alive[2][BLOCK / 64];
   const int tid = threadIdx.x;
-  // helpers have the LOWEST block numbers of a launch that has any: they are dispatched first and take their tiles'
-  // first segments at once (most of them find their tile is not shared and leave)
+  // The tiles' own workgroups come first in block order, the helpers behind them: at 128 registers all 1,024 of C3's
+  // tiles are resident at once, a third of them are empty and leave within a microsecond, and the helpers take those
+  // slots (helpers in FRONT delay every tile's start by the dispatch of 3 x tiles blocks that mostly leave: +6 us)
+#ifdef FWD_HELPERS_FIRST
   const int nhelp = (int)gridDim.x - ntiles;
   const bool helper = (int)blockIdx.x < nhelp;
   const int tile = helper ? (int)blockIdx.x / FWD_HELPERS : (int)blockIdx.x - nhelp;
+#else
+  const bool helper = (int)blockIdx.x >= ntiles;
+  const int tile = helper ? ((int)blockIdx.x - ntiles) / FWD_HELPERS : (int)blockIdx.x;
+#endif
   // (any content of the hint will do: the tile's own workgroup and its helpers read the same word -- nobody writes it
   // before the tile is complete -- and helpers only take work that is there)
   // share_all (tests): every tile long enough is shared, hints or not
