@@ -514,7 +514,7 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
           uint32_t spins = 0;
           while (ld_agent(&seg_flag[slot0 + q]) == 0u) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 19)) {                      // gave up: the result is wrong, say so (sort_stalls())
+            if (++spins > (1u << 15)) {                      // (~30 ms) gave up: the result is wrong, say so (sort_stalls())
               if (stalls) atomicAdd(stalls, 1u);
               break;
             }
