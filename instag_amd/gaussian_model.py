@@ -380,7 +380,11 @@ class GaussianModel:
 
     @torch.no_grad()
     def _rebuild(self, keep: Optional[torch.Tensor], extra: Optional[Dict[str, torch.Tensor]]):
-        """New parameter set = cat(old[keep], extra); Adam moments follow (zeros for new rows)."""
+        """New parameter set = cat(old[keep], extra); Adam moments follow (zeros for new rows).  ``keep``: a boolean mask
+        or the row indices to keep (one ``nonzero`` -- one host round trip for the count -- serves all 21 tensors; a
+        boolean index per tensor is a round trip each)."""
+        if keep is not None and keep.dtype == torch.bool:
+            keep = keep.nonzero(as_tuple=False).squeeze(1)
         for group in self.optimizer.param_groups:
             name = group.get("name", "")
             if name not in self._p:
@@ -389,7 +393,7 @@ class GaussianModel:
             state = self.optimizer.state.pop(old, None)
 
             def remap(t, fill_zero):
-                t = t if keep is None else t[keep]
+                t = t if keep is None else t.index_select(0, keep)
                 if extra is not None:
                     add = torch.zeros_like(extra[name]) if fill_zero else extra[name]
                     t = torch.cat((t, add), dim=0)
@@ -406,11 +410,11 @@ class GaussianModel:
 
     @torch.no_grad()
     def prune_points(self, mask):
-        keep = ~mask
+        keep = (~mask).nonzero(as_tuple=False).squeeze(1)
         self._rebuild(keep, None)
-        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
-        self.denom = self.denom[keep]
-        self.max_radii2D = self.max_radii2D[keep]
+        self.xyz_gradient_accum = self.xyz_gradient_accum.index_select(0, keep)
+        self.denom = self.denom.index_select(0, keep)
+        self.max_radii2D = self.max_radii2D.index_select(0, keep)
 
     @torch.no_grad()
     def _append(self, extra):
@@ -424,7 +428,8 @@ class GaussianModel:
     def densify_and_clone(self, grads, grad_threshold, scene_extent):
         sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
               (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
-        self._append({k: self._p[k].data[sel] for k in PARAM_NAMES})
+        idx = sel.nonzero(as_tuple=False).squeeze(1)
+        self._append({k: self._p[k].data.index_select(0, idx) for k in PARAM_NAMES})
 
     @torch.no_grad()
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2, generator=None):
@@ -432,15 +437,17 @@ class GaussianModel:
         padded = torch.zeros(n0, device=grads.device)
         padded[:grads.shape[0]] = grads.squeeze(-1)
         sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
-        stds = self.get_scaling[sel].repeat(N, 1)
+        idx = sel.nonzero(as_tuple=False).squeeze(1)
+        scaling_sel = self.get_scaling.index_select(0, idx)
+        stds = scaling_sel.repeat(N, 1)
         samples = torch.randn(stds.shape, device=stds.device, generator=generator) * stds
-        rots = quat_to_rotmat(self._p["rotation"].data[sel]).repeat(N, 1, 1)
-        extra = {k: self._p[k].data[sel].repeat(N, *([1] * (self._p[k].dim() - 1))) for k in PARAM_NAMES}
+        rots = quat_to_rotmat(self._p["rotation"].data.index_select(0, idx)).repeat(N, 1, 1)
+        extra = {k: self._p[k].data.index_select(0, idx).repeat(N, *([1] * (self._p[k].dim() - 1))) for k in PARAM_NAMES}
         # (R @ sample written elementwise: torch.bmm would load the BLAS library -- 0.9 s on first use, inside the event)
-        extra["xyz"] = (rots * samples.unsqueeze(1)).sum(dim=-1) + self._p["xyz"].data[sel].repeat(N, 1)
-        extra["scaling"] = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
+        extra["xyz"] = (rots * samples.unsqueeze(1)).sum(dim=-1) + extra["xyz"]
+        extra["scaling"] = self.scaling_inverse_activation(scaling_sel.repeat(N, 1) / (0.8 * N))
         self._append(extra)
-        prune = torch.cat((sel, torch.zeros(N * int(sel.sum()), device=sel.device, dtype=torch.bool)))
+        prune = torch.cat((sel, torch.zeros(N * idx.numel(), device=sel.device, dtype=torch.bool)))
         self.prune_points(prune)
 
     @torch.no_grad()
