@@ -379,8 +379,9 @@ class GaussianModel:
         self.denom += m
 
     @torch.no_grad()
-    def _rebuild(self, keep: Optional[torch.Tensor], extra: Optional[Dict[str, torch.Tensor]]):
-        """New parameter set = cat(old[keep], extra); Adam moments follow (zeros for new rows).  ``keep``: a boolean mask
+    def _rebuild(self, keep: Optional[torch.Tensor], extra: Optional[Dict[str, torch.Tensor]], append_first: bool = False):
+        """New parameter set = cat(old[keep], extra) -- or, ``append_first``, cat(old, extra)[keep]; Adam moments follow
+        (zeros for new rows).  ``keep``: a boolean mask
         or the row indices to keep (one ``nonzero`` -- one host round trip for the count -- serves all 21 tensors; a
         boolean index per tensor is a round trip each)."""
         if keep is not None and keep.dtype == torch.bool:
@@ -393,10 +394,13 @@ class GaussianModel:
             state = self.optimizer.state.pop(old, None)
 
             def remap(t, fill_zero):
-                t = t if keep is None else t.index_select(0, keep)
+                if keep is not None and not append_first:
+                    t = t.index_select(0, keep)
                 if extra is not None:
                     add = torch.zeros_like(extra[name]) if fill_zero else extra[name]
                     t = torch.cat((t, add), dim=0)
+                if keep is not None and append_first:
+                    t = t.index_select(0, keep)
                 return t
             new = nn.Parameter(remap(old.data, False).contiguous().requires_grad_(True))
             if state is not None and "exp_avg" in state:
@@ -452,6 +456,49 @@ class GaussianModel:
 
     @torch.no_grad()
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """scene/gaussian_model.py:663-681 -- clone, split, prune -- as ONE rebuild of the parameter set: the reference's
+        sequence rebuilds every parameter and both of its Adam moments four times (append clones, append children, drop
+        the split parents, prune), each a gather + concatenation per tensor and a host round trip for the new count.  The
+        final set is [old rows that are neither split nor pruned, clones, children] in that order either way; what each
+        prune test would see is known before anything is rebuilt (a clone carries its parent's opacity and scale, a
+        child its parent's opacity and 1 / 1.6 of its scale; the screen radii are zero after an append).  Same rows, same
+        values, same random draws as ``densify_and_prune_stepwise`` (tests/test_host_logic.py)."""
+        if max_grad <= 0:
+            return self.densify_and_prune_stepwise(max_grad, min_opacity, extent, max_screen_size, generator)
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        N = 2
+        scal = self.get_scaling
+        big = scal.max(dim=1).values > self.percent_dense * extent
+        hot = torch.norm(grads, dim=-1) >= max_grad
+        sel_split = (grads.squeeze(-1) >= max_grad) & big
+        idx_c = (hot & ~big).nonzero(as_tuple=False).squeeze(1)
+        idx_s = sel_split.nonzero(as_tuple=False).squeeze(1)
+        scaling_sel = scal.index_select(0, idx_s)
+        stds = scaling_sel.repeat(N, 1)
+        samples = torch.randn(stds.shape, device=stds.device, generator=generator) * stds
+        rots = quat_to_rotmat(self._p["rotation"].data.index_select(0, idx_s)).repeat(N, 1, 1)
+        child = {k: self._p[k].data.index_select(0, idx_s).repeat(N, *([1] * (self._p[k].dim() - 1))) for k in PARAM_NAMES}
+        child["xyz"] = (rots * samples.unsqueeze(1)).sum(dim=-1) + child["xyz"]
+        child["scaling"] = self.scaling_inverse_activation(scaling_sel.repeat(N, 1) / (0.8 * N))
+        extra = {k: torch.cat((self._p[k].data.index_select(0, idx_c), child[k]), dim=0) for k in PARAM_NAMES}
+        opacity_all = torch.cat((self._p["opacity"].data, extra["opacity"]), dim=0)
+        remove = (self.opacity_activation(opacity_all) < min_opacity).squeeze(-1)
+        if max_screen_size:
+            # (the screen radii are all zero at this point of the reference's sequence: every append resets them)
+            scaling_all = torch.cat((self._p["scaling"].data, extra["scaling"]), dim=0)
+            remove = remove | (self.scaling_activation(scaling_all).max(dim=1).values > 0.1 * extent)
+        remove[:sel_split.shape[0]] |= sel_split
+        keep = (~remove).nonzero(as_tuple=False).squeeze(1)
+        self._rebuild(keep, extra, append_first=True)
+        dev, n = self._p["xyz"].device, self.num_points
+        self.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
+        self.denom = torch.zeros(n, 1, device=dev)
+        self.max_radii2D = torch.zeros(n, device=dev)
+
+    @torch.no_grad()
+    def densify_and_prune_stepwise(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """The reference's own sequence of four rebuilds (kept as the statement densify_and_prune is tested against)."""
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
         self.densify_and_clone(grads, max_grad, extent)

@@ -568,8 +568,8 @@ class FaceTrainer:
             center = frame.camera_center.to(self.device)
             rgb = sh_to_rgb(self.g.active_sh_degree, self.g.get_features, self.g.get_xyz, center)
             green = (rgb[:, 0] < 30 / 255) & (rgb[:, 1] > 225 / 255) & (rgb[:, 2] < 30 / 255)
-            self.g.prune_points(green)
-            self.g.prune_points(self.g.get_xyz[:, -1] < -0.07)
+            # (two prunes in the reference; both tests are per Gaussian, so one rebuild with the union removes the same rows)
+            self.g.prune_points(green | (self.g.get_xyz[:, -1] < -0.07))
         self._drop_graph(keep_mode=True)          # (graph mode stays on: the next iteration captures its step again)
         self.density_seconds = getattr(self, "density_seconds", 0.0) + time.perf_counter() - t0     # host time (it syncs)
         return True

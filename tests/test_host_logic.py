@@ -58,6 +58,35 @@ def test_densify_prune_keeps_optimizer_state_consistent():
         assert torch.equal(p, q)
 
 
+def test_one_rebuild_density_control_equals_the_four_step_sequence():
+    """densify_and_prune (clone + split + prune as one rebuild) == the reference's sequence of four rebuilds: the same
+    rows in the same order, parameters and both Adam moments bit for bit, with and without the size test."""
+    for max_screen in (None, 20):
+        results = []
+        for fused in (True, False):
+            g = _model(400)
+            torch.manual_seed(3)
+            for p in g.per_gaussian_parameters():
+                p.grad = torch.randn_like(p) * 1e-3
+            g.optimizer.step()
+            g._p["scaling"].data[::7] += 2.5          # some large Gaussians: split, and some over the size limit
+            vs = torch.zeros(400, 3)
+            vs[:, :2] = torch.rand(400, 2) * 2e-3
+            g.add_densification_stats(vs, torch.rand(400) > 0.2)
+            gen = torch.Generator().manual_seed(11)
+            (g.densify_and_prune if fused else g.densify_and_prune_stepwise)(0.0005, 0.05, 0.2, max_screen, generator=gen)
+            state = [p.detach().clone() for p in g.per_gaussian_parameters()]
+            for grp in g.optimizer.param_groups:
+                st = g.optimizer.state.get(grp["params"][0])
+                if st and "exp_avg" in st:
+                    state += [st["exp_avg"].clone(), st["exp_avg_sq"].clone()]
+            state += [g.xyz_gradient_accum.clone(), g.denom.clone(), g.max_radii2D.clone()]
+            results.append(state)
+        assert len(results[0]) == len(results[1]) and results[0][0].shape[0] != 400
+        for a, b in zip(*results):
+            assert a.shape == b.shape and torch.equal(a, b)
+
+
 def test_prune_and_reset_opacity():
     g = _model(100)
     mask = torch.zeros(100, dtype=torch.bool)
