@@ -45,6 +45,12 @@ constexpr float T_MIN = 0.0001f;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float FAR_PIXEL = 1e18f;
 
+#ifdef BLEND_DBG2
+// (diagnostic build only: who claimed which segment slot, and what a wait for a post that gave up was looking at)
+__device__ uint32_t g_seg_owner[1 << 16];
+__device__ uint32_t g_stall_log[8 * 512 + 8];
+__device__ uint32_t* g_stall_host;            // (pinned host memory: readable while a kernel hangs)
+#endif
 #ifdef BLEND_DBG
 // (diagnostic build only: when each tile's workgroup started and ended, and where it ran -- scripts/probes/blend_tile_profile.py)
 __device__ uint32_t g_blend_dbg[4096 * 8];
@@ -382,7 +388,14 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
   // (any content of the hint will do: the tile's own workgroup and its helpers read the same word -- nobody writes it
   // before the tile is complete -- and helpers only take work that is there)
   // share_all (tests): every tile long enough is shared, hints or not
-  const uint32_t hint = walk_hints != nullptr ? walk_hints[tile] : 0u;
+  // ONE thread reads the hint for the workgroup: the word is rewritten when the tile is complete -- by whoever adds it up,
+  // possibly while a late helper (or the tile's own workgroup, at more tiles than the chip holds) is starting -- and
+  // threads that each read it for themselves could disagree about `direct`: some would leave, the others wait for them at
+  // the next barrier for ever (seen as a launch that never ends, once the helpers were made to start early)
+  if (tid == 0) s_word[0] = walk_hints != nullptr ? ld_agent(&walk_hints[tile]) : 0u;
+  __syncthreads();
+  const uint32_t hint = s_word[0];
+  __syncthreads();
   const bool helped = share_all != 0 || hint >= FWD_LONG_SEGS * FWD_HINT_UNIT;
   const int start = ranges[2 * tile], end = ranges[2 * tile + 1];
   const int nsegs = (end - start + SEG_LEN - 1) / SEG_LEN;
@@ -454,6 +467,9 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
       seg = (int)s_word[0];
     }
     const int slot = slot0 + seg;
+#ifdef BLEND_DBG2
+    if (!direct && tid == 0 && slot < (1 << 16)) g_seg_owner[slot] = (helper ? 0x80000000u : 0u) | ((uint32_t)blockIdx.x + 1u);
+#endif
     if (seg >= nsegs || (!direct && (uint32_t)seg >= s_word[1])) {
       // nothing left to take: the list ends here (or the tile is known to be finished in front of this segment).  A
       // claimed segment is always posted -- a workgroup that took a later one before the tile was known to be
@@ -516,6 +532,19 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1u << 15)) {                      // (~30 ms) gave up: the result is wrong, say so (sort_stalls())
               if (stalls) atomicAdd(stalls, 1u);
+#ifdef BLEND_DBG2
+              {
+                const uint32_t r = atomicAdd(&g_stall_log[0], 1u);
+                if (r < 512u && g_stall_host != nullptr) {
+                  uint32_t* d = g_stall_host + 8 + 8 * r;
+                  __hip_atomic_store(&g_stall_host[0], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                  d[0] = (uint32_t)tile; d[1] = (uint32_t)seg; d[2] = (uint32_t)q;
+                  d[3] = (slot0 + q) < (1 << 16) ? g_seg_owner[slot0 + q] : 0u;
+                  d[4] = (helper ? 0x80000000u : 0u) | ((uint32_t)blockIdx.x + 1u);
+                  d[5] = (uint32_t)nsegs; d[6] = ld_agent(&sync[SYNC_CLAIM]); d[7] = ~ld_agent(&sync[SYNC_INV_DEAD]);
+                }
+              }
+#endif
               break;
             }
           }
@@ -689,7 +718,7 @@ blend_forward_claim_kernel(Camera c, const int32_t* __restrict__ ranges, const u
       tile_rounds[tile] = (uint32_t)walked;
       // the hint follows the walk up at once and down slowly: steps of a training run alternate between views, and a
       // tile that walked far in one of the last FWD_HINT_UNIT * (length - 2) calls is worth its helpers' first look
-      if (walk_hints) walk_hints[tile] = max((uint32_t)walked * FWD_HINT_UNIT, hint > 0u && hint < (1u << 20) ? hint - 1u : 0u);
+      if (walk_hints) st_agent(&walk_hints[tile], max((uint32_t)walked * FWD_HINT_UNIT, hint > 0u && hint < (1u << 20) ? hint - 1u : 0u));
       s_base = nseg ? atomicAdd(seg_count, nseg) : 0u;
 #ifdef BLEND_DBG
       if (tile < 4096) {
@@ -1175,5 +1204,14 @@ int launch_blend_backward(const Camera& c, const int32_t* ranges, const uint32_t
 #ifdef BLEND_DBG
 extern "C" int instag_debug_blend_timing(uint32_t* host, int n_words) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(instag::g_blend_dbg), sizeof(uint32_t) * (size_t)n_words);
+}
+#endif
+
+#ifdef BLEND_DBG2
+extern "C" int instag_debug_blend_stalls(uint32_t* host, int n_words) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(instag::g_stall_log), sizeof(uint32_t) * (size_t)n_words);
+}
+extern "C" int instag_debug_blend_stall_host(uint32_t* pinned_device_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(instag::g_stall_host), &pinned_device_ptr, sizeof(pinned_device_ptr));
 }
 #endif
