@@ -97,14 +97,29 @@ adam_step_grads_kernel(const AdamTensor* __restrict__ tensors, AdamGrads grads, 
   const float step_size = lr / bc1;
   const int64_t base = (int64_t)ch.y * ADAM_CHUNK;
   const int64_t end = min(t.n, base + ADAM_CHUNK);
-  for (int64_t i = base + threadIdx.x; i < end; i += ADAM_BLOCK) {
-    float p = t.p[i], g = tg[i], m = t.m[i], v = t.v[i];
+  auto update = [&](float& p, float g, float& m, float& v) {
     if (gr.decoupled) p *= 1.0f - lr * gr.weight_decay;
     else if (gr.weight_decay != 0.f) g += gr.weight_decay * p;
     m = gr.beta1 * m + (1.0f - gr.beta1) * g;
     v = gr.beta2 * v + (1.0f - gr.beta2) * g * g;
     const float denom = sqrtf(v) / bc2_sqrt + gr.eps;
     p -= step_size * (m / denom);
+  };
+  // 16-byte loads and stores where the four arrays allow it (a chunk starts at a multiple of 4,096 elements, so the
+  // tensors' own alignment decides; gradients handed back as views of a flat bucket may sit at any multiple of 4 bytes)
+  const bool wide = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(tg) | reinterpret_cast<uintptr_t>(t.m) |
+                      reinterpret_cast<uintptr_t>(t.v)) & 15u) == 0u;
+  const int64_t end4 = wide ? base + ((end - base) & ~(int64_t)3) : base;
+  for (int64_t i = base + 4 * threadIdx.x; i < end4; i += 4 * ADAM_BLOCK) {
+    float4 p = *reinterpret_cast<const float4*>(t.p + i), m = *reinterpret_cast<const float4*>(t.m + i);
+    float4 v = *reinterpret_cast<const float4*>(t.v + i);
+    const float4 g = *reinterpret_cast<const float4*>(tg + i);
+    update(p.x, g.x, m.x, v.x); update(p.y, g.y, m.y, v.y); update(p.z, g.z, m.z, v.z); update(p.w, g.w, m.w, v.w);
+    *reinterpret_cast<float4*>(t.p + i) = p; *reinterpret_cast<float4*>(t.m + i) = m; *reinterpret_cast<float4*>(t.v + i) = v;
+  }
+  for (int64_t i = end4 + threadIdx.x; i < end; i += ADAM_BLOCK) {
+    float p = t.p[i], m = t.m[i], v = t.v[i];
+    update(p, tg[i], m, v);
     t.p[i] = p; t.m[i] = m; t.v[i] = v;
   }
   if (TICKET) {
