@@ -30,7 +30,10 @@ struct AdamGroup {      // hyper-parameters of one group, 24 bytes
   int32_t pad;
 };
 constexpr int ADAM_BLOCK = 256;
-constexpr int ADAM_CHUNK = 4096;       // elements per workgroup (16 per thread)
+#ifndef ADAM_CHUNK_N
+#define ADAM_CHUNK_N 4096
+#endif
+constexpr int ADAM_CHUNK = ADAM_CHUNK_N;   // elements per workgroup (16 per thread; 2,048 and 8,192 measured: no better)
 
 // per-tensor step counters (torch keeps state['step'] per parameter; a parameter without gradient is not stepped)
 __global__ void adam_tick_kernel(const AdamTensor* __restrict__ tensors, int n, float* __restrict__ steps) {
