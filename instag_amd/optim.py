@@ -41,6 +41,25 @@ class MultiTensorAdam:
         self._step = None
         self._layout_key = None
         self._partition = None
+        self._extra_n, self._extra_vals, self._extra_off = 0, [], 0
+
+    # ---- a few 64-bit words that ride on the learning-rate upload ------------------------------------------------------
+    def reserve_extra_i64(self, n: int):
+        """``n`` int64 words behind the learning rates in the SAME device table and the same per-step upload: a trainer
+        that needs another small per-step value on the device (the mouth stage's random selection size, train_mouth.py:175)
+        sets it with set_extra_i64() in front of set_lrs() instead of paying a fill launch of its own per step."""
+        self._extra_n, self._extra_vals = int(n), [0] * int(n)
+        self._layout_key = None
+
+    def set_extra_i64(self, vals):
+        assert len(vals) == self._extra_n
+        self._extra_vals = [int(v) for v in vals]
+
+    def extra_i64(self):
+        """The device view of the reserved words (None before the first step / prepare(): no table yet)."""
+        if self._extra_n == 0 or getattr(self, "_lr_dev", None) is None or self._dev is None:
+            return None
+        return self._lr_dev[self._extra_off:self._extra_off + 2 * self._extra_n].view(torch.int64)
 
     # ---- torch.optim surface ----------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
@@ -72,6 +91,8 @@ class MultiTensorAdam:
         host = self._lr_host[self._lr_slot]
         for i, g in enumerate(self.param_groups):
             host[i] = float(g["lr"])
+        if self._extra_n:
+            host.numpy()[self._extra_off:self._extra_off + 2 * self._extra_n].view(np.int64)[:] = self._extra_vals
         self._lr_dev.copy_(host, non_blocking=True)
 
     def _gather(self):
@@ -121,8 +142,11 @@ class MultiTensorAdam:
         self._groups_dev = torch.from_numpy(garr.view(np.uint8).copy()).to(dev)
         self._tensors_host = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8).pin_memory()
         self._tensors_dev = torch.zeros(len(tensors) * _TENSOR_DT.itemsize, dtype=torch.uint8, device=dev)
-        self._lr_host = torch.zeros(256, len(self.param_groups), dtype=torch.float32).pin_memory()
-        self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
+        n_lr = len(self.param_groups)
+        self._extra_off = (n_lr + 1) // 2 * 2          # (8-byte aligned: the table itself is 256-byte aligned)
+        words = self._extra_off + 2 * self._extra_n
+        self._lr_host = torch.zeros(256, words, dtype=torch.float32).pin_memory()
+        self._lr_dev = torch.zeros(words, dtype=torch.float32, device=dev)
         # per-tensor step counters follow their parameter's state across re-layouts (densify / prune)
         steps = torch.zeros(len(tensors), dtype=torch.float32, device=dev)
         for i, t in enumerate(tensors):
@@ -238,6 +262,7 @@ class CombinedAdam(MultiTensorAdam):
         self._step = None
         self._layout_key = None
         self._partition = partition
+        self._extra_n, self._extra_vals, self._extra_off = 0, [], 0
 
     @property
     def param_groups(self):

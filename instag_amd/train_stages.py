@@ -234,8 +234,25 @@ class MouthTrainer:
         self._base_lr = [float(g["lr"]) for g in self.motion_optimizer.param_groups]
         self._graph = None
         self._graph_key = None
-        self._k_dev = torch.full((1,), 10, dtype=torch.int64, device=self.device) if self.on_gpu else None
+        # the selection size of a captured step lives on the device; it rides on the optimizers' learning-rate upload
+        # (MultiTensorAdam.reserve_extra_i64) instead of a fill launch per step -- `_k_own` until that table exists
+        self._k_own = torch.full((1,), 10, dtype=torch.int64, device=self.device) if self.on_gpu else None
+        if self._combined is not None:
+            self._combined.reserve_extra_i64(1)
         self.last = {}
+
+    @property
+    def _k_dev(self):
+        view = self._combined.extra_i64() if self._combined is not None else None
+        return view if view is not None else self._k_own
+
+    def _stage_k(self, k):
+        """Call in FRONT of _set_learning_rates (whose upload carries the value)."""
+        view = self._combined.extra_i64() if self._combined is not None else None
+        if view is not None:
+            self._combined.set_extra_i64([k])
+        elif self._k_own is not None:
+            self._k_own.fill_(k)
 
     def _set_learning_rates(self, it):
         f = 0.1 if (it - 1) < self.warm_step else 0.5 ** ((it - 1) / self.opt.iterations)     # LambdaLR, :64
@@ -355,8 +372,8 @@ class MouthTrainer:
 
         def pre():
             self.iteration += 1
+            self._stage_k(self.rng.randint(10, 50))
             self._set_learning_rates(self.iteration)
-            self._k_dev.fill_(self.rng.randint(10, 50))
 
         def body(frame):
             return self._body(frame, phase, self._k_dev, stats_on)
@@ -367,19 +384,20 @@ class MouthTrainer:
     def step(self, frame: Frame):
         self.iteration += 1
         it = self.iteration
+        k = self.rng.randint(10, 50)
+        if self._graph is not None:
+            self._stage_k(k)                    # (travels with the learning rates)
         self._set_learning_rates(it)
         if it % 1000 == 0:
             self.g.oneupSHdegree()                                                                # train_mouth.py:110-111
         phase = mouth_phase(it, self.opt, self.warm_step, self.bg_iter)
         if phase.late:
             self._freeze_late()
-        k = self.rng.randint(10, 50)
         due = self._density_due(it)
         steps = it < self.opt.iterations
         if self._graph is not None and (due or not steps or self._key(it) != self._graph_key):
             _drop_graph(self)
         if self._graph is not None:
-            self._k_dev.fill_(k)
             loss, Ll1 = self._graph.replay(frame)[:2]
             if self._graph.overflow_due():
                 _drop_graph(self)               # the scene outgrew the captured capacities: eager launches from here on
