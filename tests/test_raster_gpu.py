@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): tile ids / bin counts / sort order bit-exact; R
 depth / normal / alpha / extra <= 1e-4; gradients within 2e-3 of the gradient's max magnitude
 (fp32, different summation order)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -728,6 +730,42 @@ def test_shared_tiles_give_the_same_bits(monkeypatch):
         assert results[0][2].keys() == other[2].keys()
         for k in results[0][2]:
             assert torch.equal(results[0][2][k], other[2][k]), k
+
+
+def test_walk_hints_of_a_capacity_slot_change_nothing():
+    """Repeated calls of one capacity slot: from the second call on the slot's walk hints are live and helper workgroups
+    join the tiles that walked far (csrc/raster_blend.hip; more tiles -- 36 x 36 -- than the chip holds workgroups of this
+    kernel, so some of the tiles' own workgroups start late).  Every call returns the eager call's images bit for bit and
+    no wait for a post gives up."""
+    from instag_amd import diff_gauss
+    from instag_amd.diff_gauss import GaussianRasterizer
+    n, size = 40000, 576
+    a, settings = make_scene(n, size, sh_degree=1, seed=21)
+    a["opacities"] = a["opacities"] * 0.15
+    g = {k: v.cuda() for k, v in a.items()}
+    st = hip_settings(settings)
+
+    def call():
+        with torch.no_grad():
+            return GaussianRasterizer(st)(means3D=g["means3D"], means2D=torch.zeros(n, 3, device="cuda"), shs=g["shs"],
+                                          opacities=g["opacities"], scales=g["scales"], rotations=g["rotations"],
+                                          extra_attrs=g["extra"])
+
+    first = call()
+    R = diff_gauss.LAST_STATS["num_rendered"]
+    plan = diff_gauss.CapacityPlan([int(R * 1.1) + 64], "cuda")
+    diff_gauss.set_capacity_plan(plan)
+    try:
+        for rep in range(4):
+            plan.begin_step()
+            outs = call()
+            for x, y in zip(outs, first):
+                assert torch.equal(x, y), rep
+        assert plan.overflowed() == [] and diff_gauss.sort_stalls() == 0
+        if os.environ.get("INSTAG_BLEND_FWD") == "segment":
+            assert int((plan.walk_hints[0][:(size // 16) ** 2] >= 24).sum()) > 50      # (the test did exercise shared tiles)
+    finally:
+        diff_gauss.set_capacity_plan(None)
 
 
 def test_second_backward_and_masked_gradient_reuse_the_state():
