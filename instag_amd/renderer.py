@@ -416,8 +416,17 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
             exp_feat = _zeros_const(viewpoint_camera.talking_dict["au_exp"].to(dev, non_blocking=True))
             motion_net_face.start_audio(audio_feat, 1, exp_feat)
     p_motion_preds = None
+    # (as in render_motion: the positions feed the personalised field, the mouth field and the activation operator; each
+    # encode hands them on as an output, so their three gradients are summed inside the encoders' backward kernels
+    # instead of by two autograd add launches -- gridencoder.passthrough)
+    from . import gridencoder as _ge
+    carrier = {}
+    xyz_route = pc.get_xyz
     if personalized or align:
-        p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat)
+        with _ge.passthrough(carrier):
+            p_motion_preds = pc.neural_motion_grid(pc.get_xyz, audio_feat)
+        xyz_route = carrier.pop("xyz", xyz_route)
+        xyz = xyz_route
     x_shift = None
     if align:
         p_raw = dict.get(p_motion_preds, "_p")
@@ -458,23 +467,27 @@ def render_motion_mouth_con(viewpoint_camera, pc, motion_net, pc_face, motion_ne
                 top, bottom = _extreme_values(dy, k)
                 motion_max, motion_min = top[-1], bottom[-1]
             move_feat = torch.stack([motion_max, motion_min, motion_max - motion_min]).reshape(1, 3) * 1e2
-    if x_shift is not None:
-        motion_preds = motion_net(xyz, audio_feat, move_feat.detach(), x_shift=x_shift)
-    else:
-        motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
+    with _ge.passthrough(carrier):
+        if x_shift is not None:
+            motion_preds = motion_net(xyz, audio_feat, move_feat.detach(), x_shift=x_shift)
+        else:
+            motion_preds = motion_net(xyz, audio_feat, move_feat.detach())
+    if x_shift is not None or not align:
+        xyz_route = carrier.pop("xyz", xyz_route)     # (align without the fused shift encodes xyz + p_xyz, not xyz)
+    carrier.pop("shift", None)
     h_raw, hs_raw = dict.get(motion_preds, "_h"), dict.get(motion_preds, "_hs")
     if (not personalized and torch.is_tensor(h_raw) and torch.is_tensor(hs_raw) and h_raw.is_cuda
             and h_raw.shape[-1] == 7):
         # gated displacement + softplus / normalize / sigmoid in one HIP kernel per pass (instag_amd/glue.py)
         from .glue import mouth_activate
-        means3D, scales, rotations, opacity = mouth_activate(pc.get_xyz, pc._scaling, pc._rotation, pc._opacity, h_raw,
+        means3D, scales, rotations, opacity = mouth_activate(xyz_route, pc._scaling, pc._rotation, pc._opacity, h_raw,
                                                              hs_raw, getattr(motion_net, "XYZ_SCALE",
                                                                              (1e-2 / 5, 1e-2, 1e-2 / 5)))
     else:
         d_xyz = motion_preds["d_xyz"]
         if personalized:
             d_xyz = d_xyz + p_motion_preds["d_xyz"]
-        means3D = pc.get_xyz + d_xyz
+        means3D = xyz_route + d_xyz
         opacity = pc.get_opacity
         scales, rotations = pc.get_scaling, pc.rotation_activation(pc._rotation)
     # (dc and rest coefficients as the pair the model stores: no concatenation, no slice copies in backward)
